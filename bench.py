@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- energy evaluations per second on the BASELINE.json headline workload.
+
+Workload (BASELINE.json configs[3] sharded as configs[4]): a P = 32 bead path-integral ensemble of the 10 000-atom
+polarizable box (LJ + LRC, Ewald real/reciprocal/self with kmax 7, Thole static field + 10 Jacobi dipole
+iterations, polar_ewald on).  One "step" = one SimulationControl::PI_calculate_potential
+(reference PathIntegral.cpp:752-805): a full stateless energy() of every bead + the 4-scalar combine.
+Beads are sharded round-robin over the ranks (one process per GPU); the combine is ONE collective of 4 fp64 per
+bead over torch.distributed (backend nccl = RCCL over xGMI).  Total work is fixed => "scaling": "strong".
+At --gpus 1 all 32 beads run on the one GPU, i.e. 32 evaluations of the config-4 box per step.
+
+value = (P * steps) / wall  [energy evaluations / s, whole job], inputs resident in HBM before the timed region.
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel (the Thole dipole-iteration kernel, one launch per Jacobi iteration), timed with
+                  HIP events on the stream it is launched on (mpmc_set_profiling / mpmc_get_timings).
+  cpu_baseline -- the CPU oracle (kind "port", 1 core) or the reference's own object code (kind "reference",
+                  --cpu-baseline reference) timed on this host on ONE evaluation of the same 10k box.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec)
+
+
+def build_case(natoms: int, workdir: str):
+    """the config-4 box through the reference's own file formats (so every loader sees the same doubles)."""
+    import gen_box
+    from mpmcxx_amd import pqr
+
+    if natoms == 10000:
+        name = "ion10k_polar"
+        inp, _ = gen_box.materialize(name, workdir)
+    else:  # reduced sizes are for quick functional runs only (NOT a valid benchmark number)
+        L = 86.0 * (natoms / 10000.0) ** (1.0 / 3.0)
+        rows = gen_box.lattice_box(natoms, L, 13)
+        gen_box.write_pqr(os.path.join(workdir, "box.pqr"), rows)
+        gen_box.write_input(os.path.join(workdir, "box.in"), "box.pqr", gen_box.cubic(L), dict(gen_box.POLAR_OPTS))
+        inp = os.path.join(workdir, "box.in")
+    return pqr.load_case(inp)
+
+
+def bead_positions(pos: np.ndarray, bead: int) -> np.ndarray:
+    """bead b = base positions + Gaussian bead displacement (sigma 0.05 A), numpy default_rng(17) stream per bead."""
+    rng = np.random.default_rng([17, bead])
+    return pos + rng.normal(scale=0.05, size=pos.shape)
+
+
+def cpu_baseline(kind: str, atoms, basis, opts, workdir: str):
+    if kind == "none":
+        return None
+    n = atoms["pos"].shape[0]
+    if kind == "reference":
+        import subprocess
+
+        harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+        if not os.path.exists(harness):
+            raise RuntimeError("oracle/_ref/ref_harness is not present (built only where /root/reference exists)")
+        name = "ion10k_polar.in" if n == 10000 else "box.in"
+        t0 = time.time()
+        p = subprocess.run([harness, name, "--time", "1"], cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        txt = p.stdout
+        res = json.loads(txt[txt.rfind("\n{") + 1:])
+        sec = res["time_mean_s"]
+        return {"value": 1.0 / sec, "unit": "energy-evals/s", "cores": 1, "kind": "reference",
+                "sample": f"1 steady-state full-recompute System::energy() of the same {n}-atom box by the reference's object code "
+                          f"(oracle/_ref/ref_harness; {sec:.2f} s; harness wall incl. pair-list setup {time.time() - t0:.0f} s)",
+                "energy": res["total"]}
+    from oracle import OracleSystem
+
+    S = OracleSystem(atoms, basis, opts)
+    t0 = time.time()
+    r = S.energy(want_atoms=False)
+    sec = time.time() - t0
+    return {"value": 1.0 / sec, "unit": "energy-evals/s", "cores": 1, "kind": "port",
+            "sample": f"1 full energy() of the same {n}-atom box by the scalar C oracle (oracle/mpmc_oracle.c, dense 3Nx3N A like the reference; {sec:.2f} s)",
+            "energy": r["energy"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--beads", type=int, default=32)
+    ap.add_argument("--natoms", type=int, default=10000)
+    ap.add_argument("--solver", default="auto")
+    ap.add_argument("--concurrency", choices=["async", "serial"], default="async",
+                    help="async: all local beads enqueued on their own streams before the first wait; serial: one bead at a time")
+    ap.add_argument("--cpu-baseline", choices=["port", "reference", "none"], default="port")
+    ap.add_argument("--combine", choices=["gather", "reduce"], default="gather")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from mpmcxx_amd import energy, pi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (the energy path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    P = args.beads
+    if P % world:
+        raise SystemExit("--beads must be a multiple of --gpus")
+    workdir = tempfile.mkdtemp(prefix="mpmc_bench_")
+    atoms, basis, opts = build_case(args.natoms, workdir)
+    opts = dict(opts)
+    opts["solver"] = args.solver
+    n = atoms["pos"].shape[0]
+
+    mine = pi.beads_of_rank(P, rank, world)
+    beads = []
+    for b in mine:
+        a = dict(atoms)
+        a["pos"] = bead_positions(atoms["pos"], b)
+        beads.append(energy.System(a, basis, opts, device=local_rank))
+
+    def local_eval():
+        if args.concurrency == "async":
+            _, per, failed = energy.pi_potential_local(beads)
+        else:
+            per = []
+            for s in beads:
+                s.energy()
+                per.append(s.observables)
+        return np.array([[p["rd_energy"], p["coulombic_energy"], p["polarization_energy"], p["vdw_energy"]] for p in per])
+
+    def step():
+        return pi.pi_calculate_potential(local_eval, P, rank, world, mode=args.combine, device=dev)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        v, obs = step()
+    for s in beads:
+        s.set_profiling(True)
+        s.timings(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        v, obs = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel device time from HIP events on each bead's stream
+    agg = {}
+    for s in beads:
+        for k, tv in s.timings().items():
+            a = agg.setdefault(k, {"ms": 0.0, "launches": 0})
+            a["ms"] += tv["ms"]
+            a["launches"] += tv["launches"]
+    iters = int(beads[0].observables.get("polar_iterations", 0)) if beads else 0
+    mem_total, mem_tensor = beads[0].memory_usage() if beads else (0, 0)
+
+    if rank == 0:
+        evals = P * args.steps
+        value = evals / dt
+        it = agg.get("dipole_iter", {"ms": 0.0, "launches": 0})
+        avg_ms = it["ms"] / max(it["launches"], 1)
+        n_pairs = n * (n - 1) // 2
+        # algorithmic HBM bytes of ONE dipole-iteration launch:
+        #   COMPACT store: 16 B per unordered pair (a = d1/r^3, b = 3 d2/r^5) + atom records and mu in/out
+        #   MATRIX_FREE  : atom records (32 B) + mu (24 B) in, partial field out: nothing per pair
+        solver_used = "compact" if mem_tensor > 0 else "matrix_free"
+        if solver_used == "compact":
+            alg_bytes = 16.0 * n_pairs + n * (32 + 24 + 24)
+        else:
+            alg_bytes = n * (32 + 24 + 24)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # fp64 work of the matrix-free kernel: ~90 flop-equivalent VALU ops per ordered pair
+        flops = 90.0 * n * (n - 1)
+        roof = {"bound": "hbm", "kernel": "k_dipole_iter_" + ("compact" if solver_used == "compact" else "mf"), "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": avg_ms, "launches": it["launches"], "algorithmic_bytes_per_launch": alg_bytes,
+                "concurrency": args.concurrency, "beads_per_gpu": len(beads)}
+        if solver_used == "matrix_free":
+            roof["note"] = ("matrix-free solver: the kernel is fp64-VALU-bound, its algorithmic HBM traffic is only the atom arrays; "
+                            "valu_fp64 gives the compute-side fraction")
+            roof["valu_fp64"] = {"achieved_tflops": flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                                 "frac": (flops / (avg_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if avg_ms > 0 else 0.0,
+                                 "flops_per_launch": flops}
+        cpu = cpu_baseline(args.cpu_baseline, {**atoms, "pos": bead_positions(atoms["pos"], 0)}, basis, opts, workdir) if world == 1 else None
+        if cpu is not None:
+            # parity spot check beside the timing: bead 0 on the GPU vs the CPU evaluation of the same positions
+            e_gpu = beads[0].observables["energy"] if mine and mine[0] == 0 else None
+            if e_gpu is not None and args.cpu_baseline == "port":
+                cpu["gpu_vs_cpu_rel_err"] = abs(e_gpu - cpu["energy"]) / abs(cpu["energy"])
+        out = {
+            "metric": "energy-evals/sec (10k-atom LJ+Ewald+polar box); 1/2/4/8-GPU scaling",
+            "value": value, "unit": "energy-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{P}-bead path-integral ensemble of the {n}-atom polarizable box (BASELINE configs[3] x configs[4]): "
+                                   f"LJ+LRC, Ewald kmax {opts['ewald_kmax']}, Thole exponential damping, {iters} Jacobi iterations, polar_ewald",
+                       "natoms": n, "beads": P, "beads_per_gpu": P // world, "polar_solver": solver_used, "combine": args.combine,
+                       "parallelism": f"beads sharded round-robin over {world} GPU(s); one {'all_gather' if args.combine == 'gather' else 'all_reduce'} of 4 fp64 per bead per step"},
+            "V_mean_K": v, "obs_rd_es_pol_vdw": [float(x) for x in obs],
+            "kernel_ms": {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in agg.items() if tv["launches"]},
+            "device_bytes_per_bead": mem_total,
+            "roofline": roof,
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    for s in beads:
+        s.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,215 @@
+/* include/mpmc_energy.h -- C ABI of the MI355X-native energy hot path (libmpmc_energy.so).
+ *
+ * This is the drop-in boundary for ONE path of b-tudor/mpmcxx: the per-move potential-energy
+ * evaluation `double System::energy()` (reference src/System.h:315, src/System.Energy.cpp:19-171) and the
+ * path-integral per-bead loop around it (src/SimulationControl.PathIntegral.cpp:752-805).
+ * A reference-side adapter flattens the System's Molecule->Atom lists into the arrays below, calls
+ * mpmc_energy(), and copies mpmc_result into System::observables.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; all floating point is IEEE fp64; energies in Kelvin, lengths in Angstrom,
+ *    charges in reduced units sqrt(K*A) (e * 408.7816, reference src/System.cpp:624).
+ *  - every entry point returns MPMC_OK (0) or a negative/positive error code; mpmc_last_error() gives text.
+ *    Codes reuse the reference's throw-int values where one exists (src/constants.h:108-147).
+ *  - a context is the device-side state of ONE System (one box / one PI bead): its own HIP stream and
+ *    device buffers.  Re-entrant per context (the reference calls energy() concurrently from P threads on P
+ *    distinct Systems, PathIntegral.cpp:772-779); never call concurrently on the same context.
+ *  - host pointers unless a name says _device.
+ *  - there is NO CPU fallback: without a usable HIP device mpmc_ctx_create fails with MPMC_ERR_NO_DEVICE.
+ */
+#ifndef MPMC_ENERGY_H
+#define MPMC_ENERGY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPMC_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------------------------------------- */
+#define MPMC_OK 0
+#define MPMC_ERR_INTERNAL 101            /* reference internal_error (constants.h:110)                    */
+#define MPMC_ERR_MEMORY 2000             /* memory_request_fail                                           */
+#define MPMC_ERR_INVALID_SETTING 4000    /* invalid_setting                                               */
+#define MPMC_ERR_INCOMPATIBLE 4002       /* incompatible_settings                                         */
+#define MPMC_ERR_UNSUPPORTED 4004        /* unsupported_setting: physics outside the hot path */
+#define MPMC_ERR_INVALID_DATUM 6001      /* invalid_datum (bad atom arrays)                               */
+#define MPMC_ERR_BOX 6004                /* invalid_box_dimensions                                        */
+#define MPMC_ERR_NO_DEVICE (-1)          /* no HIP device / HIP runtime failure at create                 */
+#define MPMC_ERR_HIP (-2)                /* a HIP call failed (text in mpmc_last_error)                   */
+#define MPMC_ERR_ARG (-3)                /* NULL / out-of-range argument                                  */
+
+/* ---- damping (reference enum constants.h:66-70) -------------------------------------------------------- */
+#define MPMC_DAMPING_OFF 0
+#define MPMC_DAMPING_LINEAR 1
+#define MPMC_DAMPING_EXPONENTIAL 2
+
+/* ---- how the Thole dipole iteration is executed on the device (not a reference option) ------------------ */
+#define MPMC_SOLVER_AUTO 0         /* COMPACT when its store fits, else MATRIX_FREE                         */
+#define MPMC_SOLVER_MATRIX_FREE 1  /* recompute the damped dipole tensor per pair per iteration (VALU-bound)  */
+#define MPMC_SOLVER_COMPACT 2      /* store (d1/r^3, 3 d2/r^5) per unordered pair, 16 B/pair (HBM-bound)      */
+#define MPMC_SOLVER_DENSE 3        /* store the reference's dense 3N x 3N A matrix (thole_amatrix layout)     */
+
+/* ---- out-of-scope reference switches: pass the ones that are ON so the library can refuse them ---------- */
+#define MPMC_FLAG_WOLF (1ull << 0)
+#define MPMC_FLAG_FEYNMAN_HIBBS (1ull << 1)
+#define MPMC_FLAG_RD_CRYSTAL (1ull << 2)
+#define MPMC_FLAG_SPECTRE (1ull << 3)
+#define MPMC_FLAG_GWP (1ull << 4)
+#define MPMC_FLAG_USE_SG (1ull << 5)
+#define MPMC_FLAG_POLARVDW (1ull << 6)
+#define MPMC_FLAG_POLAR_EWALD_FULL (1ull << 7)
+#define MPMC_FLAG_POLAR_WOLF (1ull << 8)
+#define MPMC_FLAG_POLAR_PALMO (1ull << 9)
+#define MPMC_FLAG_POLAR_GS_RANKED (1ull << 10)
+#define MPMC_FLAG_POLAR_SOR (1ull << 11)
+#define MPMC_FLAG_POLAR_ZODID (1ull << 12)
+#define MPMC_FLAG_NON_LB_MIXING (1ull << 13) /* waldmanhagler / halgren / c6_mixing / cdvdw_* */
+#define MPMC_FLAG_OTHER_RD (1ull << 14)      /* dreiding / lj_buffered_14_7 / disp_expansion / anharmonic / exp_repulsion */
+#define MPMC_FLAG_AXILROD_TELLER (1ull << 15)
+#define MPMC_FLAG_CAVITY_AUTOREJECT (1ull << 16)
+#define MPMC_FLAG_POLAR_MATRIX_INVERSION (1ull << 17) /* polarization on with polar_iterative off */
+
+typedef struct mpmc_ctx mpmc_ctx; /* opaque: device buffers + stream of one System */
+
+/* Options = the reference keywords that steer energy() (src/SimulationControl.cpp line in comment) */
+typedef struct mpmc_options {
+	int32_t rd_only;          /* :977  skip electrostatics + polarization                                   */
+	int32_t rd_lrc;           /* :1003 LJ long-range correction (default on)                                */
+	int32_t polarization;     /* :653                                                                       */
+	int32_t polar_iterative;  /* :1240 (required when polarization is on)                                   */
+	int32_t polar_ewald;      /* :718/:1210 static field by Ewald (recip_term + real_term) instead of nopbc */
+	int32_t polar_max_iter;   /* :1303 fixed iteration count when polar_precision == 0                      */
+	int32_t polar_gs;         /* :1256 Gauss-Seidel -- refused (MPMC_ERR_UNSUPPORTED), Jacobi only          */
+	int32_t polar_rrms;       /* :1320 compute per-atom dipole RRMS every iteration                         */
+	int32_t damp_type;        /* :1308 must be MPMC_DAMPING_EXPONENTIAL when polarization is on             */
+	int32_t ewald_kmax;       /* :1199 (default 7)                                                          */
+	int32_t solver;           /* MPMC_SOLVER_*                                                              */
+	int32_t reserved0;
+	double polar_precision;   /* :1298 0 => fixed count; else stop when every |d mu| < precision*DEBYE2SKA  */
+	double polar_gamma;       /* :1288 pre-scaling of the initial dipoles (default 1.0)                     */
+	double polar_damp;        /* :1293 Thole exponential damping length parameter                           */
+	double ewald_alpha;       /* :1192 <= 0 means "unset": 3.5 / cutoff (System.cpp:871-872)                 */
+	double polar_ewald_alpha; /* :1218 <= 0 means "unset": 3.5 / cutoff (System.cpp:873-874)                 */
+	uint64_t unsupported_flags; /* OR of MPMC_FLAG_* that are ON in the caller's System                     */
+} mpmc_options;
+
+/* what energy() leaves in System::observables / nodestats (src/System.h:94-113,151-185) + parity diagnostics */
+typedef struct mpmc_result {
+	double energy;              /* observables->energy  = rd + coulombic + polarization + vdw + three_body  */
+	double rd_energy;           /* observables->rd_energy            (lj(): pairs + pair LRC + self LRC)    */
+	double coulombic_energy;    /* observables->coulombic_energy     (real + reciprocal + self)             */
+	double polarization_energy; /* observables->polarization_energy  (-1/2 sum mu.E0)                       */
+	double vdw_energy;          /* always 0 (polarvdw is out of scope)                                      */
+	double three_body_energy;   /* always 0                                                                 */
+	double kinetic_energy;      /* always 0 (gwp out of scope)                                              */
+	double es_real;             /* coulombic_real()                                                         */
+	double es_recip;            /* coulombic_reciprocal()                                                   */
+	double es_self;             /* coulombic_self()                                                         */
+	double lj_pairs;            /* sum of pair->rd_energy                                                   */
+	double lrc_pair;            /* sum of pair->lrc                                                         */
+	double lrc_self;            /* sum of lj_lrc_self                                                       */
+	double dipole_rrms;         /* observables->dipole_rrms                                                 */
+	double N;                   /* observables->N  (non-frozen molecules, countN System.cpp:909-931)        */
+	double NU;                  /* observables->NU = N * energy                                             */
+	int64_t n_pairs;            /* N(N-1)/2                                                                 */
+	int64_t n_lj_in_cutoff;     /* pairs passing  rimg-1e-12 < rc && !rd_excluded && !frozen                */
+	int64_t n_es_in_cutoff;     /* pairs passing  !frozen && !(rimg > rc || es_excluded)                    */
+	int64_t n_intra;            /* same-molecule pairs                                                      */
+	int64_t n_rd_excluded;
+	int64_t n_es_excluded;
+	int64_t n_frozen;           /* pairs with both atoms frozen                                             */
+	int32_t polar_iterations;   /* nodestats->polarization_iterations                                       */
+	int32_t iterator_failed;    /* System::iterator_failed (=> caller rejects the move)                      */
+} mpmc_result;
+
+/* accumulated device time of the kernels of one context, measured with HIP events on the context's stream
+ * (only while profiling is enabled with mpmc_set_profiling).  Index with MPMC_K_*. */
+#define MPMC_K_PAIR 0        /* LJ + real-space Coulomb pair kernel                 */
+#define MPMC_K_RECIP 1       /* structure factors + reciprocal energy + atom terms  */
+#define MPMC_K_FIELD 2       /* static field (recip + real, or nopbc)               */
+#define MPMC_K_TENSOR 3      /* Thole tensor store build (COMPACT / DENSE solvers)  */
+#define MPMC_K_DIPOLE_ITER 4 /* one launch per Jacobi iteration                     */
+#define MPMC_K_REDUCE 5      /* final reductions / polarization energy              */
+#define MPMC_K_COUNT 6
+typedef struct mpmc_timings {
+	double ms[MPMC_K_COUNT];      /* summed elapsed milliseconds                                           */
+	int64_t launches[MPMC_K_COUNT]; /* number of timed launches                                            */
+} mpmc_timings;
+
+/* ---- library ---------------------------------------------------------------------------------------- */
+int mpmc_abi_version(void);
+int mpmc_device_count(int *count);
+const char *mpmc_last_error(const mpmc_ctx *ctx); /* ctx may be NULL: last create-time error of this thread */
+
+/* ---- PeriodicBoundary::update (src/PeriodicBoundary.cpp:31-101): volume = det(basis), reciprocal = inverse,
+ *      cutoff = half the shortest lattice vector (31^3 search).  Pure host helper. */
+int mpmc_pbc_compute(const double basis[9], double reciprocal[9], double *volume, double *cutoff);
+
+/* ---- context lifetime (one per System; replaces the per-System pair lists of src/System.Pairs.cpp:21) ---- */
+int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out);
+int mpmc_ctx_destroy(mpmc_ctx *ctx);
+
+/* System::update_pbc (src/System.cpp:859-876): basis = pbc.basis[q][p] row-major (rows are lattice vectors).
+ * reciprocal/volume/cutoff may be NULL/0 to have the library compute them exactly like PeriodicBoundary. */
+int mpmc_set_box(mpmc_ctx *ctx, const double basis[9], const double *reciprocal, double volume, double cutoff);
+int mpmc_set_options(mpmc_ctx *ctx, const mpmc_options *opts);
+void mpmc_default_options(mpmc_options *opts); /* reference defaults (src/System.h:21-24,510-831) */
+
+/* Flattened atom list in atom_array order (src/System.cpp:881-904).  mol_id: equal ids = same Molecule.
+ * frozen: Atom::frozen.  has_disp: nonzero iff any of c6,c8,c10 != 0 (only enters the rd_excluded test,
+ * src/System.cpp:1050-1056); may be NULL.  mass may be NULL (only needed by mpmc_update_com). */
+int mpmc_set_atoms(mpmc_ctx *ctx, int n, const double *pos /*[n][3]*/, const double *charge, const double *polarizability,
+                   const double *epsilon, const double *sigma, const int32_t *mol_id, const int32_t *frozen,
+                   const int32_t *has_disp, const double *mass);
+/* after a Monte Carlo move: overwrite positions of atoms [first, first+count) */
+int mpmc_update_positions(mpmc_ctx *ctx, int first, int count, const double *pos /*[count][3]*/);
+/* same, positions already in device memory ([n][3] fp64, e.g. a torch tensor's data_ptr) */
+int mpmc_set_positions_device(mpmc_ctx *ctx, const double *pos_device /*[n][3]*/);
+
+/* ---- double System::energy() -------------------------------------------------------------------------- */
+int mpmc_energy(mpmc_ctx *ctx, mpmc_result *out);
+/* asynchronous pair: enqueue on the context's stream / wait + fetch (lets a caller overlap beads) */
+int mpmc_energy_async(mpmc_ctx *ctx);
+int mpmc_energy_wait(mpmc_ctx *ctx, mpmc_result *out);
+
+/* ---- public component entry points of the reference (src/System.h:346-402), for parity tests ----------- */
+int mpmc_lj(mpmc_ctx *ctx, double *out);                  /* System::lj()                   */
+int mpmc_coulombic(mpmc_ctx *ctx, double *out);           /* System::coulombic()            */
+int mpmc_coulombic_real(mpmc_ctx *ctx, double *out);      /* System::coulombic_real()       */
+int mpmc_coulombic_reciprocal(mpmc_ctx *ctx, double *out);/* System::coulombic_reciprocal() */
+int mpmc_coulombic_self(mpmc_ctx *ctx, double *out);      /* System::coulombic_self()       */
+int mpmc_polar(mpmc_ctx *ctx, double *out);               /* System::polar()                */
+int mpmc_thole_field(mpmc_ctx *ctx, double *ef_static /*[n][3] host, may be NULL*/); /* System::thole_field() */
+/* System::thole_amatrix(): fills rows [row0, row0+nrows) of the dense 3N x 3N matrix into `a` (host, row-major
+ * nrows x 3N).  Diagonal 1/alpha (1e40 when alpha == 0), off-diagonal blocks as src/System.Energy.cpp:2744-2764. */
+int mpmc_thole_amatrix(mpmc_ctx *ctx, int row0, int nrows, double *a);
+
+/* per-atom results written back by energy() in the reference (src/Atom.h:41-47); any pointer may be NULL */
+int mpmc_get_dipoles(mpmc_ctx *ctx, double *mu, double *ef_static, double *ef_induced /* each [n][3] */);
+/* pairs() tail: update_com + wrap_all (src/System.cpp:1347-1425).  Host-side O(N); needs mass in set_atoms.
+ * com / wrapped_com: [n_molecules][3]; wrapped_pos: [n][3]; any may be NULL. */
+int mpmc_update_com(mpmc_ctx *ctx, double *com, double *wrapped_com, double *wrapped_pos, int *n_molecules);
+
+/* ---- SimulationControl::PI_calculate_potential (PathIntegral.cpp:752-805) ------------------------------ */
+/* Evaluates energy() on the n_local beads owned by this process (all enqueued before any wait, one stream per
+ * bead) and returns the UN-normalised ordered sums {rd, coulombic, polarization, vdw} over those beads in
+ * sums4.  per_bead (may be NULL) receives n_local mpmc_result.  The cross-rank combine (4 fp64 all-reduce over
+ * RCCL / MPI_Allgather in the reference, :763-766) is the caller's; mpmc_pi_finish divides by P. */
+int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sums4[4], mpmc_result *per_bead, int *any_iterator_failed);
+/* obs = sums / P ; returns V = rd + coulombic + vdw + polarization (:786-804) */
+double mpmc_pi_finish(const double sums4_global[4], int P, double obs4[4]);
+
+/* ---- measurement ------------------------------------------------------------------------------------- */
+int mpmc_set_profiling(mpmc_ctx *ctx, int enabled); /* HIP-event timing of each kernel class on ctx's stream */
+int mpmc_get_timings(mpmc_ctx *ctx, mpmc_timings *out, int reset);
+int mpmc_synchronize(mpmc_ctx *ctx);
+/* bytes of device memory held by the context and by its Thole tensor store */
+int mpmc_memory_usage(mpmc_ctx *ctx, int64_t *total_bytes, int64_t *tensor_store_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPMC_ENERGY_H */

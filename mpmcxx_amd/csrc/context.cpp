@@ -1,0 +1,921 @@
+// context.cpp -- host side of libmpmc_energy.so: the C ABI of include/mpmc_energy.h.
+//
+// One mpmc_ctx = the device-resident state of one reference `System` (one box / one PI bead):
+// its own HIP stream, struct-of-arrays atom buffers, k-vector tables, work buffers and result scalars.
+// Replaces, for the energy path only, the per-System pair lists (reference src/System.Pairs.cpp:21) and the
+// A matrix (src/System.cpp:1430-1473).  There is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mpmc_energy.h"
+#include "kernels.h"
+
+using namespace mpmc;
+
+static thread_local std::string g_create_error;
+
+struct EvPair {
+	hipEvent_t a, b;
+	int cls;
+};
+
+struct mpmc_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int max_atoms = 0, max_pad = 0;
+	int n = 0, n_pad = 0, n_tiles = 0, n_tile_pairs = 0, n_split = 1;
+	int n_molecules = 0;
+	double N_movable = 0; // countN
+	std::string err;
+
+	// host mirrors of the flattened System
+	std::vector<double> h_pos, h_q, h_alpha, h_eps, h_sigma, h_mass;
+	std::vector<int32_t> h_mol, h_frozen, h_disp;
+
+	// device atom arrays
+	double4 *d_xyzq = nullptr;
+	double2 *d_lj = nullptr;
+	int2 *d_mf = nullptr;
+	double *d_alpha = nullptr, *d_eps = nullptr;
+
+	// pair kernel
+	int2 *d_tile_pairs = nullptr;
+	double *d_block_part = nullptr;
+	int *d_block_cnt = nullptr;
+	size_t cap_tile_pairs = 0;
+
+	// scalars
+	double *d_scal = nullptr;
+	long long *d_cnt = nullptr;
+	double *h_scal = nullptr; // pinned
+	long long *h_cnt = nullptr;
+	int *d_flag = nullptr;
+	int *h_flag = nullptr; // pinned
+
+	// reciprocal tables
+	int K = 0, cap_K = 0;
+	double4 *d_kvec = nullptr, *d_kw = nullptr, *d_sf = nullptr;
+	double *d_w_en = nullptr;
+
+	// polarization work
+	double *d_e_recip_part = nullptr, *d_part = nullptr, *d_e_static = nullptr, *d_mu[2] = {nullptr, nullptr}, *d_e_induced = nullptr,
+	       *d_rrms = nullptr;
+	size_t cap_part = 0;
+	int mu_cur = 0;
+	// dense A rows scratch
+	double *d_arows = nullptr;
+	size_t cap_arows = 0;
+
+	Box box{};
+	bool box_set = false, atoms_set = false, opts_set = false, k_dirty = true;
+	mpmc_options opts{};
+	double ewald_alpha = 0, polar_ewald_alpha = 0;
+
+	// results of the last evaluation
+	bool pending = false;
+	bool have_polar = false;
+	int iters = 0, failed = 0;
+	unsigned run_mask = 0;
+
+	// profiling
+	bool prof = false;
+	std::vector<EvPair> ev_free, ev_used;
+	mpmc_timings tim{};
+
+	int64_t bytes_total = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+#define HIP_TRY(ctx, call)                                                                                        \
+	do {                                                                                                          \
+		hipError_t _e = (call);                                                                                   \
+		if (_e != hipSuccess) {                                                                                   \
+			(ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e);                                       \
+			return MPMC_ERR_HIP;                                                                                  \
+		}                                                                                                         \
+	} while (0)
+
+template <typename T>
+static int dev_alloc(mpmc_ctx *c, T **p, size_t count) {
+	HIP_TRY(c, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+	c->bytes_total += (int64_t)(count * sizeof(T));
+	return MPMC_OK;
+}
+template <typename T>
+static void dev_free(mpmc_ctx *c, T **p, size_t count) {
+	if (*p) {
+		(void)hipFree(*p);
+		c->bytes_total -= (int64_t)(count * sizeof(T));
+		*p = nullptr;
+	}
+}
+
+static int fail(mpmc_ctx *c, int code, const std::string &msg) {
+	if (c) c->err = msg;
+	else g_create_error = msg;
+	return code;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------------
+static void prof_begin(mpmc_ctx *c, int cls, int &cur) {
+	cur = -1;
+	if (!c->prof) return;
+	EvPair e;
+	if (!c->ev_free.empty()) {
+		e = c->ev_free.back();
+		c->ev_free.pop_back();
+	} else {
+		if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+	}
+	e.cls = cls;
+	(void)hipEventRecord(e.a, c->stream);
+	c->ev_used.push_back(e);
+	cur = (int)c->ev_used.size() - 1;
+}
+static void prof_end(mpmc_ctx *c, int cur) {
+	if (cur >= 0 && cur < (int)c->ev_used.size()) (void)hipEventRecord(c->ev_used[cur].b, c->stream);
+}
+static void prof_harvest(mpmc_ctx *c) { // stream must be idle
+	for (auto &e : c->ev_used) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+			c->tim.ms[e.cls] += ms;
+			c->tim.launches[e.cls] += 1;
+		}
+		c->ev_free.push_back(e);
+	}
+	c->ev_used.clear();
+}
+struct ProfScope {
+	mpmc_ctx *c;
+	int cur;
+	ProfScope(mpmc_ctx *c_, int cls) : c(c_) { prof_begin(c, cls, cur); }
+	~ProfScope() { prof_end(c, cur); }
+};
+
+// ---- library --------------------------------------------------------------------------------------------
+extern "C" int mpmc_abi_version(void) { return MPMC_ABI_VERSION; }
+
+extern "C" int mpmc_device_count(int *count) {
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (count) *count = (e == hipSuccess) ? n : 0;
+	return (e == hipSuccess) ? MPMC_OK : MPMC_ERR_NO_DEVICE;
+}
+
+extern "C" const char *mpmc_last_error(const mpmc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+// PeriodicBoundary::update, reference src/PeriodicBoundary.cpp:31-101 (same association order)
+extern "C" int mpmc_pbc_compute(const double b[9], double R[9], double *volume, double *cutoff) {
+	if (!b || !R || !volume || !cutoff) return MPMC_ERR_ARG;
+#define B(i, j) b[3 * (i) + (j)]
+	double vol;
+	vol = B(0, 0) * (B(1, 1) * B(2, 2) - B(1, 2) * B(2, 1));
+	vol += B(0, 1) * (B(1, 2) * B(2, 0) - B(1, 0) * B(2, 2));
+	vol += B(0, 2) * (B(1, 0) * B(2, 1) - B(1, 1) * B(2, 0));
+	*volume = vol;
+	if (vol <= 0) {
+		*cutoff = kMaxValue;
+	} else {
+		double shortest = kMaxValue;
+		for (int i = -15; i <= 15; i++)
+			for (int j = -15; j <= 15; j++)
+				for (int k = -15; k <= 15; k++) {
+					if (!i && !j && !k) continue;
+					double v[3];
+					for (int p = 0; p < 3; p++) v[p] = i * B(0, p) + j * B(1, p) + k * B(2, p);
+					double m = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+					if (m < shortest) shortest = m;
+				}
+		*cutoff = 0.5 * shortest;
+	}
+	const double iv = 1.0 / vol;
+	R[0] = iv * (B(1, 1) * B(2, 2) - B(1, 2) * B(2, 1));
+	R[1] = iv * (B(0, 2) * B(2, 1) - B(0, 1) * B(2, 2));
+	R[2] = iv * (B(0, 1) * B(1, 2) - B(0, 2) * B(1, 1));
+	R[3] = iv * (B(1, 2) * B(2, 0) - B(1, 0) * B(2, 2));
+	R[4] = iv * (B(0, 0) * B(2, 2) - B(0, 2) * B(2, 0));
+	R[5] = iv * (B(0, 2) * B(1, 0) - B(0, 0) * B(1, 2));
+	R[6] = iv * (B(1, 0) * B(2, 1) - B(1, 1) * B(2, 0));
+	R[7] = iv * (B(0, 1) * B(2, 0) - B(0, 0) * B(2, 1));
+	R[8] = iv * (B(0, 0) * B(1, 1) - B(0, 1) * B(1, 0));
+#undef B
+	return (vol > 0) ? MPMC_OK : MPMC_ERR_BOX;
+}
+
+extern "C" void mpmc_default_options(mpmc_options *o) {
+	if (!o) return;
+	std::memset(o, 0, sizeof(*o));
+	o->rd_lrc = 1;          // reference src/System.h: rd_lrc default on
+	o->polar_max_iter = 10; // polar_max_iter default
+	o->ewald_kmax = 7;      // ewald_kmax default
+	o->polar_gamma = 1.0;
+	o->damp_type = MPMC_DAMPING_EXPONENTIAL;
+	o->solver = MPMC_SOLVER_AUTO;
+}
+
+// ---- lifetime --------------------------------------------------------------------------------------------
+extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
+	if (!out || max_atoms <= 0) return fail(nullptr, MPMC_ERR_ARG, "mpmc_ctx_create: bad argument");
+	*out = nullptr;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+		return fail(nullptr, MPMC_ERR_NO_DEVICE,
+		            std::string("mpmc_ctx_create: no HIP device (") + hipGetErrorString(e) + "); this library has no CPU path");
+	if (device < 0 || device >= ndev) return fail(nullptr, MPMC_ERR_ARG, "mpmc_ctx_create: device index out of range");
+	if (hipSetDevice(device) != hipSuccess) return fail(nullptr, MPMC_ERR_NO_DEVICE, "mpmc_ctx_create: hipSetDevice failed");
+
+	mpmc_ctx *c = new mpmc_ctx();
+	c->device = device;
+	c->max_atoms = max_atoms;
+	c->max_pad = ((max_atoms + kTile - 1) / kTile) * kTile;
+	mpmc_default_options(&c->opts);
+	int rc = MPMC_OK;
+	auto A = [&](int r) { if (rc == MPMC_OK) rc = r; };
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+		delete c;
+		return fail(nullptr, MPMC_ERR_HIP, "mpmc_ctx_create: hipStreamCreate failed");
+	}
+	const size_t P = (size_t)c->max_pad;
+	A(dev_alloc(c, &c->d_xyzq, P));
+	A(dev_alloc(c, &c->d_lj, P));
+	A(dev_alloc(c, &c->d_mf, P));
+	A(dev_alloc(c, &c->d_alpha, P));
+	A(dev_alloc(c, &c->d_eps, P));
+	A(dev_alloc(c, &c->d_scal, (size_t)S_COUNT));
+	A(dev_alloc(c, &c->d_cnt, (size_t)C_COUNT));
+	A(dev_alloc(c, &c->d_flag, (size_t)1));
+	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_scal, S_COUNT * sizeof(double)) != hipSuccess) rc = MPMC_ERR_HIP;
+	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_cnt, C_COUNT * sizeof(long long)) != hipSuccess) rc = MPMC_ERR_HIP;
+	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_flag, sizeof(int)) != hipSuccess) rc = MPMC_ERR_HIP;
+	if (rc != MPMC_OK) {
+		g_create_error = "mpmc_ctx_create: device allocation failed: " + c->err;
+		mpmc_ctx_destroy(c);
+		return rc;
+	}
+	*out = c;
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
+	if (!c) return MPMC_ERR_ARG;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	for (auto &e : c->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
+	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
+	                c->d_e_induced, c->d_rrms, c->d_arows};
+	for (void *p : ptrs)
+		if (p) (void)hipFree(p);
+	if (c->h_scal) (void)hipHostFree(c->h_scal);
+	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+	if (c->h_flag) (void)hipHostFree(c->h_flag);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+	return MPMC_OK;
+}
+
+// ---- box / options ---------------------------------------------------------------------------------------
+extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *reciprocal, double volume, double cutoff) {
+	if (!c || !basis) return MPMC_ERR_ARG;
+	double R[9], vol = 0, cut = 0;
+	int rc = mpmc_pbc_compute(basis, R, &vol, &cut);
+	if (rc != MPMC_OK) return fail(c, MPMC_ERR_BOX, "mpmc_set_box: non-positive cell volume");
+	if (reciprocal) std::memcpy(R, reciprocal, sizeof(R));
+	if (volume > 0) vol = volume;
+	if (cutoff > 0) cut = cutoff;
+	if (!(vol > 0) || !(cut > 0)) return fail(c, MPMC_ERR_BOX, "mpmc_set_box: invalid volume / cutoff");
+	std::memcpy(c->box.b, basis, sizeof(R));
+	std::memcpy(c->box.r, R, sizeof(R));
+	c->box.volume = vol;
+	c->box.cutoff = cut;
+	c->box.ortho = 1;
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++)
+			if (i != j && (basis[3 * i + j] != 0.0 || R[3 * i + j] != 0.0)) c->box.ortho = 0;
+	c->box_set = true;
+	c->k_dirty = true;
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
+	if (!c || !o) return MPMC_ERR_ARG;
+	if (o->unsupported_flags) {
+		char buf[160];
+		std::snprintf(buf, sizeof buf, "mpmc_set_options: reference option(s) outside the energy hot path are ON (flag mask 0x%llx)",
+		              (unsigned long long)o->unsupported_flags);
+		return fail(c, MPMC_ERR_UNSUPPORTED, buf);
+	}
+	if (o->polarization && !o->rd_only) {
+		if (!o->polar_iterative)
+			return fail(c, MPMC_ERR_UNSUPPORTED, "mpmc_set_options: polarization by matrix inversion (polar_iterative off) is not supported");
+		if (o->damp_type != MPMC_DAMPING_EXPONENTIAL)
+			return fail(c, MPMC_ERR_UNSUPPORTED, "mpmc_set_options: only polar_damp_type exponential is supported");
+		if (o->polar_gs) return fail(c, MPMC_ERR_UNSUPPORTED, "mpmc_set_options: polar_gs (Gauss-Seidel) is not supported; Jacobi only");
+		if (o->polar_precision == 0.0 && o->polar_max_iter < 1)
+			return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: polar_max_iter must be >= 1 when polar_precision is 0 (the reference never terminates)");
+		if (o->polar_precision < 0.0) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: polar_precision < 0");
+		if (o->solver < MPMC_SOLVER_AUTO || o->solver > MPMC_SOLVER_DENSE) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: bad solver");
+		if (o->solver == MPMC_SOLVER_COMPACT || o->solver == MPMC_SOLVER_DENSE)
+			return fail(c, MPMC_ERR_UNSUPPORTED, "mpmc_set_options: stored-tensor solvers are not built in this version; use AUTO or MATRIX_FREE");
+	}
+	if (o->ewald_kmax < 0 || o->ewald_kmax > 64) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: ewald_kmax out of range");
+	c->opts = *o;
+	c->opts_set = true;
+	c->k_dirty = true;
+	return MPMC_OK;
+}
+
+// ---- atoms -----------------------------------------------------------------------------------------------
+static int upload_atoms(mpmc_ctx *c) {
+	const int n = c->n, np = c->n_pad;
+	std::vector<double4> xyzq(np);
+	std::vector<double2> lj(np);
+	std::vector<int2> mf(np);
+	std::vector<double> al(np, 0.0), ep(np, 0.0);
+	for (int i = 0; i < np; i++) {
+		if (i < n) {
+			xyzq[i] = make_double4(c->h_pos[3 * i], c->h_pos[3 * i + 1], c->h_pos[3 * i + 2], c->h_q[i]);
+			lj[i] = make_double2(std::fabs(c->h_sigma[i]), std::sqrt(c->h_eps[i]));
+			int fl = 0;
+			if (c->h_frozen[i]) fl |= AF_FROZEN;
+			if (c->h_eps[i] == 0.0 || c->h_sigma[i] == 0.0) fl |= AF_NULL_RD;
+			if (c->h_disp[i]) fl |= AF_HAS_DISP;
+			if (c->h_sigma[i] < 0.0) fl |= AF_NEG_SIGMA;
+			if (c->h_sigma[i] == 0.0) fl |= AF_ZERO_SIGMA;
+			if (c->h_q[i] == 0.0) fl |= AF_ZERO_Q;
+			if (c->h_alpha[i] == 0.0) fl |= AF_ZERO_ALPHA;
+			mf[i] = make_int2(c->h_mol[i], fl);
+			al[i] = c->h_alpha[i];
+			ep[i] = c->h_eps[i];
+		} else {
+			xyzq[i] = make_double4(0, 0, 0, 0);
+			lj[i] = make_double2(0, 0);
+			mf[i] = make_int2(-1 - i, AF_PAD | AF_FROZEN | AF_NULL_RD | AF_ZERO_SIGMA | AF_ZERO_Q | AF_ZERO_ALPHA);
+		}
+	}
+	HIP_TRY(c, hipMemcpyAsync(c->d_xyzq, xyzq.data(), np * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_lj, lj.data(), np * sizeof(double2), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_mf, mf.data(), np * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_alpha, al.data(), np * sizeof(double), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_eps, ep.data(), np * sizeof(double), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream)); // staging vectors die here
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const double *charge, const double *polarizability, const double *epsilon,
+                              const double *sigma, const int32_t *mol_id, const int32_t *frozen, const int32_t *has_disp, const double *mass) {
+	if (!c || n <= 0 || !pos || !charge || !polarizability || !epsilon || !sigma || !mol_id || !frozen) return MPMC_ERR_ARG;
+	if (n > c->max_atoms) return fail(c, MPMC_ERR_ARG, "mpmc_set_atoms: n exceeds max_atoms of this context");
+	for (int i = 0; i < n; i++) {
+		if (!std::isfinite(pos[3 * i]) || !std::isfinite(pos[3 * i + 1]) || !std::isfinite(pos[3 * i + 2]))
+			return fail(c, MPMC_ERR_INVALID_DATUM, "mpmc_set_atoms: non-finite position");
+		if (epsilon[i] < 0.0 || !std::isfinite(epsilon[i]) || !std::isfinite(sigma[i]) || !std::isfinite(charge[i]) || !std::isfinite(polarizability[i]))
+			return fail(c, MPMC_ERR_INVALID_DATUM, "mpmc_set_atoms: epsilon < 0 or non-finite atom parameter");
+	}
+	HIP_TRY(c, hipSetDevice(c->device));
+	c->n = n;
+	c->n_pad = ((n + kTile - 1) / kTile) * kTile;
+	c->n_tiles = c->n_pad / kTile;
+	c->h_pos.assign(pos, pos + 3 * (size_t)n);
+	c->h_q.assign(charge, charge + n);
+	c->h_alpha.assign(polarizability, polarizability + n);
+	c->h_eps.assign(epsilon, epsilon + n);
+	c->h_sigma.assign(sigma, sigma + n);
+	c->h_mol.assign(mol_id, mol_id + n);
+	c->h_frozen.assign(frozen, frozen + n);
+	if (has_disp) c->h_disp.assign(has_disp, has_disp + n);
+	else c->h_disp.assign(n, 0);
+	if (mass) c->h_mass.assign(mass, mass + n);
+	else c->h_mass.clear();
+
+	// countN (reference src/System.cpp:909-931): molecules that are not frozen.  A molecule's flag is the
+	// flag of its last atom row (the PQR reader overwrites molecule->frozen per atom, src/System.cpp:687).
+	c->n_molecules = 0;
+	c->N_movable = 0;
+	for (int i = 0; i < n; i++) {
+		const bool last_of_mol = (i == n - 1) || (mol_id[i + 1] != mol_id[i]);
+		if (last_of_mol) {
+			c->n_molecules++;
+			if (!frozen[i]) c->N_movable += 1.0;
+		}
+	}
+
+	int rc = upload_atoms(c);
+	if (rc != MPMC_OK) return rc;
+
+	// upper-triangular tile-pair schedule of the pair kernel
+	const int nt = c->n_tiles;
+	const size_t ntp = (size_t)nt * (nt + 1) / 2;
+	if (ntp > c->cap_tile_pairs) {
+		dev_free(c, &c->d_tile_pairs, c->cap_tile_pairs);
+		dev_free(c, &c->d_block_part, 4 * c->cap_tile_pairs);
+		dev_free(c, &c->d_block_cnt, 6 * c->cap_tile_pairs);
+		c->cap_tile_pairs = 0;
+		if ((rc = dev_alloc(c, &c->d_tile_pairs, ntp)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_block_part, 4 * ntp)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_block_cnt, 6 * ntp)) != MPMC_OK) return rc;
+		c->cap_tile_pairs = ntp;
+	}
+	std::vector<int2> tp;
+	tp.reserve(ntp);
+	for (int I = 0; I < nt; I++)
+		for (int J = I; J < nt; J++) tp.push_back(make_int2(I, J));
+	HIP_TRY(c, hipMemcpy(c->d_tile_pairs, tp.data(), ntp * sizeof(int2), hipMemcpyHostToDevice));
+	c->n_tile_pairs = (int)ntp;
+
+	// j-range split of the per-atom (row) kernels: aim for >= ~4096 one-wave blocks
+	c->n_split = std::max(1, std::min(nt, (4096 + nt - 1) / nt));
+	c->atoms_set = true;
+	c->pending = false;
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_update_positions(mpmc_ctx *c, int first, int count, const double *pos) {
+	if (!c || !pos || first < 0 || count < 0) return MPMC_ERR_ARG;
+	if (!c->atoms_set || first + count > c->n) return fail(c, MPMC_ERR_ARG, "mpmc_update_positions: range outside the atom list");
+	if (count == 0) return MPMC_OK;
+	HIP_TRY(c, hipSetDevice(c->device));
+	std::vector<double4> tmp(count);
+	for (int t = 0; t < count; t++) {
+		const int i = first + t;
+		if (!std::isfinite(pos[3 * t]) || !std::isfinite(pos[3 * t + 1]) || !std::isfinite(pos[3 * t + 2]))
+			return fail(c, MPMC_ERR_INVALID_DATUM, "mpmc_update_positions: non-finite position");
+		c->h_pos[3 * i] = pos[3 * t];
+		c->h_pos[3 * i + 1] = pos[3 * t + 1];
+		c->h_pos[3 * i + 2] = pos[3 * t + 2];
+		tmp[t] = make_double4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], c->h_q[i]);
+	}
+	HIP_TRY(c, hipMemcpyAsync(c->d_xyzq + first, tmp.data(), count * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_set_positions_device(mpmc_ctx *c, const double *pos_device) {
+	if (!c || !pos_device) return MPMC_ERR_ARG;
+	if (!c->atoms_set) return fail(c, MPMC_ERR_ARG, "mpmc_set_positions_device: no atoms set");
+	HIP_TRY(c, hipSetDevice(c->device));
+	launch_set_positions(c->stream, pos_device, c->d_xyzq, 0, c->n);
+	HIP_TRY(c, hipGetLastError());
+	// keep the host mirror coherent (update_com / later partial updates read it)
+	HIP_TRY(c, hipMemcpyAsync(c->h_pos.data(), pos_device, 3 * (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return MPMC_OK;
+}
+
+// ---- k-vector tables (hemisphere enumeration of coulombic_reciprocal :1577-1590 / recip_term :2849-2865) --------
+static int build_k_tables(mpmc_ctx *c) {
+	const int kmax = c->opts.ewald_kmax;
+	const double alpha = c->ewald_alpha, ea = c->polar_ewald_alpha;
+	std::vector<double4> kvec, kw;
+	std::vector<double> wen;
+	int l[3];
+	for (l[0] = 0; l[0] <= kmax; l[0]++)
+		for (l[1] = (!l[0] ? 0 : -kmax); l[1] <= kmax; l[1]++)
+			for (l[2] = ((!l[0] && !l[1]) ? 1 : -kmax); l[2] <= kmax; l[2]++) {
+				if (l[0] * l[0] + l[1] * l[1] + l[2] * l[2] > kmax * kmax) continue;
+				double k[3];
+				for (int p = 0; p < 3; p++) {
+					k[p] = 0;
+					for (int q = 0; q < 3; q++) k[p] += 2.0 * kPi * c->box.r[3 * p + q] * l[q];
+				}
+				const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+				kvec.push_back(make_double4(k[0], k[1], k[2], k2));
+				wen.push_back(std::exp(-k2 / (4.0 * alpha * alpha)) / k2);
+				const double g = std::exp(-k2 / (4.0 * ea * ea));
+				kw.push_back(make_double4(k[0] / k2 * g, k[1] / k2 * g, k[2] / k2 * g, 0.0));
+			}
+	const int K = (int)kvec.size();
+	if (K > c->cap_K) {
+		dev_free(c, &c->d_kvec, (size_t)c->cap_K);
+		dev_free(c, &c->d_kw, (size_t)c->cap_K);
+		dev_free(c, &c->d_sf, (size_t)c->cap_K);
+		dev_free(c, &c->d_w_en, (size_t)c->cap_K);
+		c->cap_K = 0;
+		int rc;
+		if ((rc = dev_alloc(c, &c->d_kvec, (size_t)K)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_kw, (size_t)K)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_sf, (size_t)K)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_w_en, (size_t)K)) != MPMC_OK) return rc;
+		c->cap_K = K;
+	}
+	if (K > 0) {
+		HIP_TRY(c, hipMemcpy(c->d_kvec, kvec.data(), K * sizeof(double4), hipMemcpyHostToDevice));
+		HIP_TRY(c, hipMemcpy(c->d_kw, kw.data(), K * sizeof(double4), hipMemcpyHostToDevice));
+		HIP_TRY(c, hipMemcpy(c->d_w_en, wen.data(), K * sizeof(double), hipMemcpyHostToDevice));
+	}
+	c->K = K;
+	return MPMC_OK;
+}
+
+static int ensure_polar_buffers(mpmc_ctx *c) {
+	const size_t np = (size_t)c->max_pad;
+	int rc;
+	if (!c->d_e_static) {
+		if ((rc = dev_alloc(c, &c->d_e_static, 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_mu[0], 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_mu[1], 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_e_induced, 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_rrms, np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_e_recip_part, (size_t)kKSplit * 3 * np)) != MPMC_OK) return rc;
+		HIP_TRY(c, hipMemset(c->d_e_static, 0, 3 * np * sizeof(double)));
+		HIP_TRY(c, hipMemset(c->d_mu[0], 0, 3 * np * sizeof(double)));
+		HIP_TRY(c, hipMemset(c->d_mu[1], 0, 3 * np * sizeof(double)));
+		HIP_TRY(c, hipMemset(c->d_e_induced, 0, 3 * np * sizeof(double)));
+		HIP_TRY(c, hipMemset(c->d_rrms, 0, np * sizeof(double)));
+	}
+	const size_t need = (size_t)c->n_split * c->n_pad * 3;
+	if (need > c->cap_part) {
+		dev_free(c, &c->d_part, c->cap_part);
+		c->cap_part = 0;
+		if ((rc = dev_alloc(c, &c->d_part, need)) != MPMC_OK) return rc;
+		c->cap_part = need;
+	}
+	return MPMC_OK;
+}
+
+// resolve alpha defaults, rebuild k tables when box/options changed
+static int prepare(mpmc_ctx *c) {
+	if (!c->box_set) return fail(c, MPMC_ERR_BOX, "energy: no box set (mpmc_set_box)");
+	if (!c->atoms_set) return fail(c, MPMC_ERR_INVALID_DATUM, "energy: no atoms set (mpmc_set_atoms)");
+	HIP_TRY(c, hipSetDevice(c->device));
+	if (c->k_dirty) {
+		// System::update_pbc, reference src/System.cpp:871-874
+		c->ewald_alpha = (c->opts.ewald_alpha > 0) ? c->opts.ewald_alpha : 3.5 / c->box.cutoff;
+		c->polar_ewald_alpha = (c->opts.polar_ewald_alpha > 0) ? c->opts.polar_ewald_alpha : 3.5 / c->box.cutoff;
+		int rc = build_k_tables(c);
+		if (rc != MPMC_OK) return rc;
+		c->k_dirty = false;
+	}
+	return MPMC_OK;
+}
+
+static AtomsDev atoms_view(const mpmc_ctx *c) {
+	AtomsDev a;
+	a.xyzq = c->d_xyzq;
+	a.lj = c->d_lj;
+	a.mf = c->d_mf;
+	a.alpha = c->d_alpha;
+	a.eps = c->d_eps;
+	a.n = c->n;
+	a.n_pad = c->n_pad;
+	return a;
+}
+static RecipDev recip_view(const mpmc_ctx *c) {
+	RecipDev r;
+	r.kvec = c->d_kvec;
+	r.w_en = c->d_w_en;
+	r.kw = c->d_kw;
+	r.sf = c->d_sf;
+	r.K = c->K;
+	return r;
+}
+
+// which pieces of energy() to run
+enum : unsigned { RUN_PAIR = 1, RUN_PAIR_ES = 2, RUN_RECIP = 4, RUN_ATOMTERMS = 8, RUN_FIELD = 16, RUN_SOLVE = 32 };
+
+static int enqueue(mpmc_ctx *c, unsigned mask) {
+	int rc = prepare(c);
+	if (rc != MPMC_OK) return rc;
+	const AtomsDev at = atoms_view(c);
+	const RecipDev rcp = recip_view(c);
+	const mpmc_options &o = c->opts;
+	hipStream_t st = c->stream;
+	c->run_mask = mask;
+	c->have_polar = false;
+	c->iters = 0;
+	c->failed = 0;
+
+	HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, S_COUNT * sizeof(double), st));
+	HIP_TRY(c, hipMemsetAsync(c->d_cnt, 0, C_COUNT * sizeof(long long), st));
+
+	if (mask & RUN_PAIR) {
+		ProfScope p(c, MPMC_K_PAIR);
+		PairParams pp;
+		pp.ewald_alpha = c->ewald_alpha;
+		pp.rd_lrc = o.rd_lrc;
+		pp.do_es = (mask & RUN_PAIR_ES) ? 1 : 0;
+		launch_pair_energy(st, at, c->box, pp, c->d_tile_pairs, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt);
+	}
+	const bool need_sf = (mask & RUN_RECIP) || ((mask & RUN_FIELD) && o.polar_ewald);
+	if (need_sf || (mask & RUN_ATOMTERMS)) {
+		ProfScope p(c, MPMC_K_RECIP);
+		if (need_sf) launch_recip_sf(st, at, rcp);
+		if (mask & (RUN_RECIP | RUN_ATOMTERMS))
+			launch_recip_energy(st, at, rcp, c->box, c->ewald_alpha, o.rd_lrc, (mask & RUN_RECIP) ? 1 : 0, c->d_scal);
+	}
+	if (mask & (RUN_FIELD | RUN_SOLVE)) {
+		if ((rc = ensure_polar_buffers(c)) != MPMC_OK) return rc;
+	}
+	if (mask & RUN_FIELD) {
+		ProfScope p(c, MPMC_K_FIELD);
+		if (o.polar_ewald) launch_field_recip(st, at, rcp, c->d_e_recip_part);
+		launch_field_real(st, at, c->box, o.polar_ewald, c->polar_ewald_alpha, c->n_split, c->d_part);
+		c->mu_cur = 0;
+		launch_field_finalize(st, at, c->box, o.polar_ewald, c->d_e_recip_part, c->d_part, c->n_split, o.polar_gamma, c->d_e_static,
+		                      c->d_mu[0]);
+	}
+	if (mask & RUN_SOLVE) {
+		// thole_iterative, reference src/System.Energy.cpp:3450-3543
+		const bool by_precision = (o.polar_precision != 0.0);
+		const int want_rrms = (o.polar_rrms || o.polar_precision > 0) ? 1 : 0;
+		const double allowed = by_precision ? o.polar_precision * o.polar_precision * kDebye2SKA * kDebye2SKA : 0.0;
+		int it = 0;
+		bool keep = true;
+		while (keep) {
+			it++;
+			if (it >= kMaxIterationCount && by_precision) { // divergence: mu = alpha E0, iterator_failed (:3483-3494)
+				launch_dipole_reset(st, at, c->d_e_static, c->d_mu[c->mu_cur]);
+				c->failed = 1;
+				break;
+			}
+			if (by_precision) HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
+			{
+				ProfScope p(c, MPMC_K_DIPOLE_ITER);
+				launch_dipole_iter_mf(st, at, c->box, o.polar_damp, c->d_mu[c->mu_cur], c->n_split, c->d_part);
+			}
+			{
+				ProfScope p(c, MPMC_K_REDUCE);
+				launch_dipole_update(st, at, c->d_e_static, c->d_part, c->n_split, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur], c->d_e_induced,
+				                     want_rrms, c->d_rrms, allowed, c->d_flag);
+			}
+			c->mu_cur = 1 - c->mu_cur;
+			if (by_precision) { // are_we_done_yet needs the verdict on the host
+				HIP_TRY(c, hipMemcpyAsync(c->h_flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+				HIP_TRY(c, hipStreamSynchronize(st));
+				keep = (*c->h_flag != 0);
+			} else {
+				keep = (it != o.polar_max_iter);
+			}
+		}
+		c->iters = it;
+		{
+			ProfScope p(c, MPMC_K_REDUCE);
+			launch_polar_energy(st, at, c->d_mu[c->mu_cur], c->d_e_static, want_rrms ? c->d_rrms : nullptr, c->d_scal);
+		}
+		c->have_polar = true;
+	}
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipMemcpyAsync(c->h_scal, c->d_scal, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, C_COUNT * sizeof(long long), hipMemcpyDeviceToHost, st));
+	c->pending = true;
+	return MPMC_OK;
+}
+
+static int wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
+	if (!c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_energy_wait: nothing enqueued");
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	c->pending = false;
+	prof_harvest(c);
+	if (!out) return MPMC_OK;
+	std::memset(out, 0, sizeof(*out));
+	const double *s = c->h_scal;
+	out->lj_pairs = s[S_LJ];
+	out->lrc_pair = s[S_LRC_PAIR];
+	out->lrc_self = s[S_LRC_SELF];
+	out->rd_energy = (s[S_LJ] + s[S_LRC_PAIR]) + s[S_LRC_SELF];
+	out->es_real = s[S_ES_REAL] - s[S_ES_INTRA];
+	out->es_recip = s[S_ES_RECIP];
+	out->es_self = s[S_ES_SELF];
+	out->coulombic_energy = (out->es_real + out->es_recip) + out->es_self; // coulombic() :1412
+	out->polarization_energy = s[S_POLAR];
+	out->dipole_rrms = s[S_RRMS];
+	out->energy = out->rd_energy + out->coulombic_energy + out->polarization_energy + out->vdw_energy + out->three_body_energy; // :136
+	out->N = c->N_movable;
+	out->NU = out->N * out->energy; // :162
+	out->n_pairs = (int64_t)c->n * (c->n - 1) / 2;
+	out->n_lj_in_cutoff = c->h_cnt[C_LJ_IN];
+	out->n_es_in_cutoff = c->h_cnt[C_ES_IN];
+	out->n_intra = c->h_cnt[C_INTRA];
+	out->n_rd_excluded = c->h_cnt[C_RDX];
+	out->n_es_excluded = c->h_cnt[C_ESX];
+	out->n_frozen = c->h_cnt[C_FROZEN];
+	out->polar_iterations = c->iters;
+	out->iterator_failed = c->failed;
+	return MPMC_OK;
+}
+
+static unsigned full_mask(const mpmc_ctx *c) {
+	unsigned m = RUN_PAIR | RUN_ATOMTERMS;
+	if (!c->opts.rd_only) {
+		m |= RUN_PAIR_ES | RUN_RECIP;
+		if (c->opts.polarization) m |= RUN_FIELD | RUN_SOLVE;
+	}
+	return m;
+}
+
+extern "C" int mpmc_energy_async(mpmc_ctx *c) {
+	if (!c) return MPMC_ERR_ARG;
+	return enqueue(c, full_mask(c));
+}
+extern "C" int mpmc_energy_wait(mpmc_ctx *c, mpmc_result *out) {
+	if (!c) return MPMC_ERR_ARG;
+	return wait_and_fill(c, out);
+}
+extern "C" int mpmc_energy(mpmc_ctx *c, mpmc_result *out) {
+	if (!c || !out) return MPMC_ERR_ARG;
+	int rc = enqueue(c, full_mask(c));
+	if (rc != MPMC_OK) return rc;
+	return wait_and_fill(c, out);
+}
+
+// ---- component entry points --------------------------------------------------------------------------------
+static int run_piece(mpmc_ctx *c, unsigned mask, mpmc_result *r) {
+	if (!c) return MPMC_ERR_ARG;
+	int rc = enqueue(c, mask);
+	if (rc != MPMC_OK) return rc;
+	return wait_and_fill(c, r);
+}
+extern "C" int mpmc_lj(mpmc_ctx *c, double *out) {
+	mpmc_result r;
+	int rc = run_piece(c, RUN_PAIR | RUN_ATOMTERMS, &r);
+	if (rc == MPMC_OK && out) *out = r.rd_energy;
+	return rc;
+}
+extern "C" int mpmc_coulombic_real(mpmc_ctx *c, double *out) {
+	mpmc_result r;
+	int rc = run_piece(c, RUN_PAIR | RUN_PAIR_ES, &r);
+	if (rc == MPMC_OK && out) *out = r.es_real;
+	return rc;
+}
+extern "C" int mpmc_coulombic_reciprocal(mpmc_ctx *c, double *out) {
+	mpmc_result r;
+	int rc = run_piece(c, RUN_RECIP, &r);
+	if (rc == MPMC_OK && out) *out = r.es_recip;
+	return rc;
+}
+extern "C" int mpmc_coulombic_self(mpmc_ctx *c, double *out) {
+	mpmc_result r;
+	int rc = run_piece(c, RUN_RECIP, &r);
+	if (rc == MPMC_OK && out) *out = r.es_self;
+	return rc;
+}
+extern "C" int mpmc_coulombic(mpmc_ctx *c, double *out) {
+	mpmc_result r;
+	int rc = run_piece(c, RUN_PAIR | RUN_PAIR_ES | RUN_RECIP, &r);
+	if (rc == MPMC_OK && out) *out = r.coulombic_energy;
+	return rc;
+}
+extern "C" int mpmc_polar(mpmc_ctx *c, double *out) {
+	if (!c) return MPMC_ERR_ARG;
+	if (!c->opts.polarization) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_polar: polarization is off");
+	mpmc_result r;
+	int rc = run_piece(c, RUN_FIELD | RUN_SOLVE, &r);
+	if (rc == MPMC_OK && out) *out = r.polarization_energy;
+	return rc;
+}
+extern "C" int mpmc_thole_field(mpmc_ctx *c, double *ef_static) {
+	if (!c) return MPMC_ERR_ARG;
+	mpmc_result r;
+	int rc = run_piece(c, RUN_FIELD, &r);
+	if (rc != MPMC_OK) return rc;
+	if (ef_static) HIP_TRY(c, hipMemcpy(ef_static, c->d_e_static, 3 * (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost));
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_thole_amatrix(mpmc_ctx *c, int row0, int nrows, double *a) {
+	if (!c || !a || row0 < 0 || nrows <= 0) return MPMC_ERR_ARG;
+	int rc = prepare(c);
+	if (rc != MPMC_OK) return rc;
+	if (row0 % 3 || nrows % 3 || row0 + nrows > 3 * c->n) return fail(c, MPMC_ERR_ARG, "mpmc_thole_amatrix: rows must cover whole atoms (multiples of 3) inside 3N");
+	const size_t need = (size_t)nrows * 3 * c->n;
+	if (need > c->cap_arows) {
+		dev_free(c, &c->d_arows, c->cap_arows);
+		c->cap_arows = 0;
+		if ((rc = dev_alloc(c, &c->d_arows, need)) != MPMC_OK) return rc;
+		c->cap_arows = need;
+	}
+	{
+		ProfScope p(c, MPMC_K_TENSOR);
+		launch_amatrix_rows(c->stream, atoms_view(c), c->box, c->opts.polar_damp, row0, nrows, c->d_arows);
+	}
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipMemcpyAsync(a, c->d_arows, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	prof_harvest(c);
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_get_dipoles(mpmc_ctx *c, double *mu, double *ef_static, double *ef_induced) {
+	if (!c) return MPMC_ERR_ARG;
+	if (!c->d_e_static) return fail(c, MPMC_ERR_ARG, "mpmc_get_dipoles: no polarization evaluation has run");
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	const size_t bytes = 3 * (size_t)c->n * sizeof(double);
+	if (mu) HIP_TRY(c, hipMemcpy(mu, c->d_mu[c->mu_cur], bytes, hipMemcpyDeviceToHost));
+	if (ef_static) HIP_TRY(c, hipMemcpy(ef_static, c->d_e_static, bytes, hipMemcpyDeviceToHost));
+	if (ef_induced) HIP_TRY(c, hipMemcpy(ef_induced, c->d_e_induced, bytes, hipMemcpyDeviceToHost));
+	return MPMC_OK;
+}
+
+// update_com + wrap_all, reference src/System.cpp:1347-1425 (host side: O(N), consumed by I/O only)
+extern "C" int mpmc_update_com(mpmc_ctx *c, double *com, double *wrapped_com, double *wrapped_pos, int *n_molecules) {
+	if (!c) return MPMC_ERR_ARG;
+	if (!c->atoms_set || !c->box_set) return fail(c, MPMC_ERR_ARG, "mpmc_update_com: atoms and box must be set");
+	if (c->h_mass.empty()) return fail(c, MPMC_ERR_ARG, "mpmc_update_com: mpmc_set_atoms was called without masses");
+	if (n_molecules) *n_molecules = c->n_molecules;
+	int m = 0;
+	for (int i0 = 0; i0 < c->n;) {
+		int i1 = i0;
+		while (i1 + 1 < c->n && c->h_mol[i1 + 1] == c->h_mol[i0]) i1++;
+		double cm[3] = {0, 0, 0}, mass = 0;
+		for (int i = i0; i <= i1; i++) {
+			mass += c->h_mass[i];
+			for (int p = 0; p < 3; p++) cm[p] += c->h_mass[i] * c->h_pos[3 * i + p];
+		}
+		for (int p = 0; p < 3; p++) cm[p] /= mass;
+		const bool mol_frozen = c->h_frozen[i1] != 0;
+		double w[3] = {0, 0, 0};
+		if (!mol_frozen) {
+			double d[3];
+			for (int p = 0; p < 3; p++) {
+				d[p] = 0;
+				for (int q = 0; q < 3; q++) d[p] += c->box.r[3 * q + p] * cm[q];
+				d[p] = std::rint(d[p]);
+			}
+			for (int p = 0; p < 3; p++) {
+				w[p] = 0;
+				for (int q = 0; q < 3; q++) w[p] += c->box.b[3 * q + p] * d[q];
+			}
+		}
+		if (com)
+			for (int p = 0; p < 3; p++) com[3 * m + p] = cm[p];
+		if (wrapped_com)
+			for (int p = 0; p < 3; p++) wrapped_com[3 * m + p] = w[p]; // the reference stores the lattice shift here (:1404)
+		if (wrapped_pos)
+			for (int i = i0; i <= i1; i++)
+				for (int p = 0; p < 3; p++) wrapped_pos[3 * i + p] = mol_frozen ? c->h_pos[3 * i + p] : c->h_pos[3 * i + p] - w[p];
+		m++;
+		i0 = i1 + 1;
+	}
+	return MPMC_OK;
+}
+
+// ---- path integral ---------------------------------------------------------------------------------------
+extern "C" int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sums4[4], mpmc_result *per_bead, int *any_failed) {
+	if (!beads || n_local < 0 || !sums4) return MPMC_ERR_ARG;
+	for (int b = 0; b < n_local; b++) { // every bead enqueued on its own stream before the first wait
+		int rc = mpmc_energy_async(beads[b]);
+		if (rc != MPMC_OK) return rc;
+	}
+	sums4[0] = sums4[1] = sums4[2] = sums4[3] = 0;
+	int failed = 0;
+	for (int b = 0; b < n_local; b++) {
+		mpmc_result r;
+		int rc = mpmc_energy_wait(beads[b], &r);
+		if (rc != MPMC_OK) return rc;
+		sums4[0] += r.rd_energy; // ordered accumulation, PathIntegral.cpp:791-796
+		sums4[1] += r.coulombic_energy;
+		sums4[2] += r.polarization_energy;
+		sums4[3] += r.vdw_energy;
+		failed |= r.iterator_failed;
+		if (per_bead) per_bead[b] = r;
+	}
+	if (any_failed) *any_failed = failed;
+	return MPMC_OK;
+}
+
+extern "C" double mpmc_pi_finish(const double s[4], int P, double obs4[4]) {
+	double o[4];
+	for (int k = 0; k < 4; k++) o[k] = s[k] / P; // :798-801
+	if (obs4)
+		for (int k = 0; k < 4; k++) obs4[k] = o[k];
+	return o[0] + o[1] + o[3] + o[2]; // rd + coulombic + vdw + polarization, :803-804
+}
+
+// ---- measurement -----------------------------------------------------------------------------------------
+extern "C" int mpmc_set_profiling(mpmc_ctx *c, int enabled) {
+	if (!c) return MPMC_ERR_ARG;
+	c->prof = enabled != 0;
+	return MPMC_OK;
+}
+extern "C" int mpmc_get_timings(mpmc_ctx *c, mpmc_timings *out, int reset) {
+	if (!c || !out) return MPMC_ERR_ARG;
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	prof_harvest(c);
+	*out = c->tim;
+	if (reset) std::memset(&c->tim, 0, sizeof(c->tim));
+	return MPMC_OK;
+}
+extern "C" int mpmc_synchronize(mpmc_ctx *c) {
+	if (!c) return MPMC_ERR_ARG;
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return MPMC_OK;
+}
+extern "C" int mpmc_memory_usage(mpmc_ctx *c, int64_t *total, int64_t *tensor) {
+	if (!c) return MPMC_ERR_ARG;
+	if (total) *total = c->bytes_total;
+	if (tensor) *tensor = 0;
+	return MPMC_OK;
+}

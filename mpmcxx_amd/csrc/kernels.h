@@ -1,0 +1,81 @@
+// kernels.h -- launch wrappers of the gfx950 kernels (implemented in kernels.hip), used by context.cpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pair_math.h"
+
+namespace mpmc {
+
+constexpr int kTile = 64; // one wavefront owns 64 i-atoms; j-atoms are staged in LDS 64 at a time
+constexpr int kKSplit = 8; // k-vector range split of the reciprocal field kernel
+
+// device view of one System's atoms (struct-of-arrays, padded to a multiple of kTile)
+struct AtomsDev {
+	const double4 *xyzq; // x, y, z, charge
+	const double2 *lj;   // |sigma|, sqrt(epsilon)
+	const int2 *mf;      // molecule id, AF_* flags
+	const double *alpha; // polarizability
+	const double *eps;   // epsilon (atom self-LRC term)
+	int n, n_pad;
+};
+
+// slots of the scalar result vector on the device
+enum : int {
+	S_LJ = 0, S_LRC_PAIR, S_ES_REAL, S_ES_INTRA, // pair kernel
+	S_ES_RECIP, S_ES_SELF, S_LRC_SELF,           // recip / atom kernel
+	S_POLAR, S_RRMS,                             // polarization
+	S_COUNT = 16
+};
+enum : int { C_LJ_IN = 0, C_ES_IN, C_INTRA, C_RDX, C_ESX, C_FROZEN, C_COUNT = 8 };
+
+struct PairParams {
+	double ewald_alpha;
+	int rd_lrc, do_es;
+};
+
+// pair energies over all unordered pairs: partial sums per block then a fixed-order final reduction
+void launch_pair_energy(hipStream_t st, const AtomsDev &at, const Box &bx, const PairParams &pp, const int2 *tile_pairs,
+                        int n_tile_pairs, double *block_part /*[n_tile_pairs][4]*/, int *block_cnt /*[n_tile_pairs][6]*/,
+                        double *scal, long long *cnt);
+
+// reciprocal space: structure factors for every k, then energy + O(N) atom terms
+struct RecipDev {
+	const double4 *kvec; // kx, ky, kz, k^2            [K]
+	const double *w_en;  // exp(-k^2/4a^2)/k^2         [K]
+	const double4 *kw;   // k_p/k^2 exp(-k^2/4ap^2), _ [K]
+	double4 *sf;         // SF_re, SF_im (energy: non-frozen, q != 0), C_k, S_k (field: all atoms)  [K]
+	int K;
+};
+void launch_recip_sf(hipStream_t st, const AtomsDev &at, const RecipDev &rc);
+void launch_recip_energy(hipStream_t st, const AtomsDev &at, const RecipDev &rc, const Box &bx, double ewald_alpha, int rd_lrc,
+                         int do_es, double *scal);
+
+// static field
+void launch_field_recip(hipStream_t st, const AtomsDev &at, const RecipDev &rc, double *e_recip /*[n_pad][3]*/);
+void launch_field_real(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, double polar_ewald_alpha, int n_split,
+                       double *part /*[n_split][n_pad][3]*/);
+// E0 = recip*(8 pi/V) + sum_s part ; mu0 = gamma * alpha * E0
+void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip,
+                           const double *part, int n_split, double gamma, double *e_static, double *mu);
+
+// Thole dipole iteration, matrix-free: part[s][i] = - sum_{j in split s, j != i} T_ij mu_j
+void launch_dipole_iter_mf(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, const double *mu, int n_split,
+                           double *part);
+// new_mu = alpha (E0 + F) ; optionally rrms per atom and the "broke tolerance" flag (are_we_done_yet)
+void launch_dipole_update(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, int n_split,
+                          const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom,
+                          double allowed_sqerr, int *not_done_flag);
+// iterator failure: mu = alpha * E0
+void launch_dipole_reset(hipStream_t st, const AtomsDev &at, const double *e_static, double *mu);
+void launch_polar_energy(hipStream_t st, const AtomsDev &at, const double *mu, const double *e_static, const double *rrms_atom,
+                         double *scal);
+
+// dense thole_amatrix rows (parity / DENSE solver)
+void launch_amatrix_rows(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, int row0, int nrows, double *a /*[nrows][3n]*/);
+
+// device-resident positions [count][3] -> xyzq[first .. first+count).xyz
+void launch_set_positions(hipStream_t st, const double *pos_dev, double4 *xyzq, int first, int count);
+
+} // namespace mpmc

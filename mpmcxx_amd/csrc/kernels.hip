@@ -1,0 +1,550 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the energy hot path.
+//
+// Common shape: one wavefront (64 lanes) owns 64 i-atoms in registers; j-atoms are staged 64 at a time in LDS
+// and broadcast-read by all lanes (same address per wave instruction => no bank conflicts).  All arithmetic
+// is fp64.  Every sum is reduced in a fixed order (per-lane serial -> wave shuffle tree -> per-block partial ->
+// single-block final pass), so results are bit-reproducible run to run.  No atomics on floating point.
+//
+// Compiled with -ffp-contract=off (see pair_math.h).
+#include "kernels.h"
+
+namespace mpmc {
+
+// ------------------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	return v; // valid in lane 0
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	return v;
+}
+// sum over a 256-thread block; result valid in thread 0.  `sh` must hold 4 doubles.
+__device__ __forceinline__ double block_sum_256(double v, double *sh) {
+	v = wave_sum(v);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+	__syncthreads();
+	return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// pair energies: lj() + coulombic_real()    (reference System.Energy.cpp:897-1032, 1466-1517)
+// grid: one wave per (I <= J) tile pair.
+// ------------------------------------------------------------------------------------------------------
+template <bool ORTHO>
+__global__ __launch_bounds__(64) void k_pair_energy(AtomsDev at, Box bx, PairParams pp, const int2 *__restrict__ tile_pairs,
+                                                    double *__restrict__ block_part, int *__restrict__ block_cnt) {
+	__shared__ double4 s_xyzq[kTile];
+	__shared__ double2 s_lj[kTile];
+	__shared__ int2 s_mf[kTile];
+
+	const int lane = threadIdx.x;
+	const int2 IJ = tile_pairs[blockIdx.x];
+	const int i = IJ.x * kTile + lane;
+	const int j0 = IJ.y * kTile;
+	const bool diag = (IJ.x == IJ.y);
+
+	const double4 pi = at.xyzq[i];
+	const double2 li = at.lj[i];
+	const int2 mi = at.mf[i];
+	s_xyzq[lane] = at.xyzq[j0 + lane];
+	s_lj[lane] = at.lj[j0 + lane];
+	s_mf[lane] = at.mf[j0 + lane];
+	__syncthreads();
+
+	const bool i_real = !(mi.y & AF_PAD);
+	const double rc = bx.cutoff;
+	double e_lj = 0, e_lrc = 0, e_re = 0, e_in = 0;
+	int n_lj = 0, n_es = 0, n_intra = 0, n_rdx = 0, n_esx = 0, n_fr = 0;
+
+	for (int jj = 0; jj < kTile; ++jj) {
+		const int2 mj = s_mf[jj];
+		const bool act = i_real && !(mj.y & AF_PAD) && (!diag || jj > lane);
+		if (!act) continue;
+		const double4 pj = s_xyzq[jj];
+		const double2 lj = s_lj[jj];
+		const PairFlags f = pair_flags(mi.x, mi.y, mj.x, mj.y);
+		n_intra += f.intra;
+		n_rdx += f.rd_excluded;
+		n_esx += f.es_excluded;
+		n_fr += f.frozen;
+		if (f.frozen) continue; // frozen pairs contribute to no term (:936, :1049, :1487)
+
+		const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+		double ox, oy, oz;
+		const double rimg = min_image<ORTHO>(bx, dx, dy, dz, ox, oy, oz);
+
+		double sig, eps;
+		lj_mix(mi.y, mj.y, li.x, li.y, lj.x, lj.y, sig, eps);
+		if (pp.rd_lrc && eps != 0.0 && sig != 0.0) e_lrc += lrc_term(sig, eps, rc, bx.volume);
+		if ((rimg - kSmallDR < rc) && !f.rd_excluded) {
+			e_lj += lj_term(sig, eps, rimg, f.attractive_only);
+			n_lj++;
+		}
+		if (pp.do_es) {
+			if (!((rimg > rc) || f.es_excluded)) {
+				e_re += pi.w * pj.w * erfc(pp.ewald_alpha * rimg) / rimg;
+				n_es++;
+			} else if (f.es_excluded) {
+				const double qq = pi.w * pj.w;
+				if (qq != 0.0) { // charge-to-screen term uses the plain (non-image) distance (:1504)
+					const double r = sqrt(((dx * dx) + dy * dy) + dz * dz);
+					e_in += qq * erf(pp.ewald_alpha * r) / r;
+				}
+			}
+		}
+	}
+
+	e_lj = wave_sum(e_lj);
+	e_lrc = wave_sum(e_lrc);
+	e_re = wave_sum(e_re);
+	e_in = wave_sum(e_in);
+	n_lj = wave_sum_i(n_lj);
+	n_es = wave_sum_i(n_es);
+	n_intra = wave_sum_i(n_intra);
+	n_rdx = wave_sum_i(n_rdx);
+	n_esx = wave_sum_i(n_esx);
+	n_fr = wave_sum_i(n_fr);
+	if (lane == 0) {
+		double *bp = block_part + 4 * (size_t)blockIdx.x;
+		bp[0] = e_lj;
+		bp[1] = e_lrc;
+		bp[2] = e_re;
+		bp[3] = e_in;
+		int *bc = block_cnt + 6 * (size_t)blockIdx.x;
+		bc[0] = n_lj;
+		bc[1] = n_es;
+		bc[2] = n_intra;
+		bc[3] = n_rdx;
+		bc[4] = n_esx;
+		bc[5] = n_fr;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_reduce_pairs(const double *__restrict__ block_part, const int *__restrict__ block_cnt, int nb,
+                                                      double *__restrict__ scal, long long *__restrict__ cnt) {
+	__shared__ double sh[4];
+	__shared__ long long shc[256];
+	double s[4] = {0, 0, 0, 0};
+	long long c[6] = {0, 0, 0, 0, 0, 0};
+	for (int b = threadIdx.x; b < nb; b += 256) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) s[k] += block_part[4 * (size_t)b + k];
+#pragma unroll
+		for (int k = 0; k < 6; ++k) c[k] += block_cnt[6 * (size_t)b + k];
+	}
+	for (int k = 0; k < 4; ++k) {
+		double t = block_sum_256(s[k], sh);
+		if (threadIdx.x == 0) scal[S_LJ + k] = t;
+	}
+	for (int k = 0; k < 6; ++k) {
+		__syncthreads();
+		shc[threadIdx.x] = c[k];
+		__syncthreads();
+		for (int off = 128; off > 0; off >>= 1) {
+			if (threadIdx.x < off) shc[threadIdx.x] += shc[threadIdx.x + off];
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) cnt[k] = shc[0];
+	}
+}
+
+void launch_pair_energy(hipStream_t st, const AtomsDev &at, const Box &bx, const PairParams &pp, const int2 *tile_pairs, int n_tile_pairs,
+                        double *block_part, int *block_cnt, double *scal, long long *cnt) {
+	if (bx.ortho)
+		hipLaunchKernelGGL(k_pair_energy<true>, dim3(n_tile_pairs), dim3(kTile), 0, st, at, bx, pp, tile_pairs, block_part, block_cnt);
+	else
+		hipLaunchKernelGGL(k_pair_energy<false>, dim3(n_tile_pairs), dim3(kTile), 0, st, at, bx, pp, tile_pairs, block_part, block_cnt);
+	hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, block_part, block_cnt, n_tile_pairs, scal, cnt);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// reciprocal space (reference coulombic_reciprocal :1561-1622, recip_term :2834-2896, coulombic_self :1626-1643,
+// lj_lrc_self :1072-1096)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_recip_sf(AtomsDev at, RecipDev rc) {
+	__shared__ double sh[4];
+	const double4 kv = rc.kvec[blockIdx.x];
+	double re = 0, im = 0, C = 0, S = 0;
+	for (int a = threadIdx.x; a < at.n; a += 256) {
+		const double4 p = at.xyzq[a];
+		const int fl = at.mf[a].y;
+		const double ph = ((kv.x * p.x) + kv.y * p.y) + kv.z * p.z;
+		double s, c;
+		sincos(ph, &s, &c);
+		const double qc = p.w * c, qs = p.w * s;
+		C += qc; // recip_term sums over ALL atoms (:2868-2872)
+		S += qs;
+		if (!(fl & (AF_FROZEN | AF_ZERO_Q))) { // coulombic_reciprocal skips frozen and q == 0 (:1599-1602)
+			re += qc;
+			im += qs;
+		}
+	}
+	re = block_sum_256(re, sh);
+	im = block_sum_256(im, sh);
+	C = block_sum_256(C, sh);
+	S = block_sum_256(S, sh);
+	if (threadIdx.x == 0) rc.sf[blockIdx.x] = make_double4(re, im, C, S);
+}
+
+__global__ __launch_bounds__(256) void k_recip_energy(AtomsDev at, RecipDev rc, Box bx, double ewald_alpha, int rd_lrc, int do_es,
+                                                      double *__restrict__ scal) {
+	__shared__ double sh[4];
+	double e = 0, self = 0, lrc = 0;
+	if (do_es) {
+		for (int k = threadIdx.x; k < rc.K; k += 256) {
+			const double4 sf = rc.sf[k];
+			e += rc.w_en[k] * (sf.x * sf.x + sf.y * sf.y);
+		}
+	}
+	for (int a = threadIdx.x; a < at.n; a += 256) {
+		const int fl = at.mf[a].y;
+		if (fl & AF_FROZEN) continue;
+		const double q = at.xyzq[a].w;
+		if (do_es) self -= ewald_alpha * q * q / sqrt(kPi);
+		if (rd_lrc && !(fl & AF_NULL_RD)) lrc += lrc_term(at.lj[a].x, at.eps[a], bx.cutoff, bx.volume);
+	}
+	e = block_sum_256(e, sh);
+	self = block_sum_256(self, sh);
+	lrc = block_sum_256(lrc, sh);
+	if (threadIdx.x == 0) {
+		scal[S_ES_RECIP] = e * (4.0 * kPi / bx.volume);
+		scal[S_ES_SELF] = self;
+		scal[S_LRC_SELF] = lrc;
+	}
+}
+
+void launch_recip_sf(hipStream_t st, const AtomsDev &at, const RecipDev &rc) {
+	if (rc.K > 0) hipLaunchKernelGGL(k_recip_sf, dim3(rc.K), dim3(256), 0, st, at, rc);
+}
+void launch_recip_energy(hipStream_t st, const AtomsDev &at, const RecipDev &rc, const Box &bx, double ewald_alpha, int rd_lrc, int do_es,
+                         double *scal) {
+	hipLaunchKernelGGL(k_recip_energy, dim3(1), dim3(256), 0, st, at, rc, bx, ewald_alpha, rd_lrc, do_es, scal);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// static field
+// ------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_field_recip(AtomsDev at, RecipDev rc, double *__restrict__ e_part /*[kKSplit][n_pad][3]*/) {
+	const int i = blockIdx.x * kTile + threadIdx.x;
+	const int per = (rc.K + kKSplit - 1) / kKSplit;
+	const int k0 = blockIdx.y * per, k1 = min(rc.K, k0 + per);
+	const double4 p = at.xyzq[i];
+	double ex = 0, ey = 0, ez = 0;
+	for (int k = k0; k < k1; ++k) {
+		const double4 kv = rc.kvec[k];
+		const double4 sf = rc.sf[k];
+		const double4 kw = rc.kw[k];
+		const double ph = ((kv.x * p.x) + kv.y * p.y) + kv.z * p.z;
+		double s, c;
+		sincos(ph, &s, &c);
+		const double g = s * sf.z - c * sf.w; // sin(k.r) C_k - cos(k.r) S_k  (:2877-2878)
+		ex += kw.x * g;
+		ey += kw.y * g;
+		ez += kw.z * g;
+	}
+	double *o = e_part + ((size_t)blockIdx.y * at.n_pad + i) * 3;
+	o[0] = ex;
+	o[1] = ey;
+	o[2] = ez;
+}
+
+// real-space / no-PBC static field: thread i accumulates over the j-tiles of its split (ordered pairs, so no
+// cross-lane accumulation is needed; E_i += f q_j dimg(i,j) holds for j < i as well because dimg is odd in d).
+template <bool ORTHO, bool EWALD>
+__global__ __launch_bounds__(64) void k_field_real(AtomsDev at, Box bx, double alpha_p, int tiles_per_split, double *__restrict__ part) {
+	__shared__ double4 s_xyzq[kTile];
+	__shared__ int2 s_mf[kTile];
+	const int lane = threadIdx.x;
+	const int i = blockIdx.x * kTile + lane;
+	const int nt = at.n_pad / kTile;
+	const int t0 = blockIdx.y * tiles_per_split, t1 = min(nt, t0 + tiles_per_split);
+	const double4 pi = at.xyzq[i];
+	const int2 mi = at.mf[i];
+	const bool i_real = !(mi.y & AF_PAD);
+	const double rc = bx.cutoff;
+	double ex = 0, ey = 0, ez = 0;
+	for (int t = t0; t < t1; ++t) {
+		__syncthreads();
+		s_xyzq[lane] = at.xyzq[t * kTile + lane];
+		s_mf[lane] = at.mf[t * kTile + lane];
+		__syncthreads();
+		for (int jj = 0; jj < kTile; ++jj) {
+			const int2 mj = s_mf[jj];
+			const int j = t * kTile + jj;
+			if (!i_real || (mj.y & (AF_PAD | AF_ZERO_Q)) || j == i) continue; // q_j == 0 contributes exactly 0
+			const PairFlags f = pair_flags(mi.x, mi.y, mj.x, mj.y);
+			if (f.frozen) continue; // :2915, :3311
+			if (!EWALD && f.intra) continue; // :3313
+			const double4 pj = s_xyzq[jj];
+			double ox, oy, oz;
+			const double r = min_image<ORTHO>(bx, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, ox, oy, oz);
+			double fac;
+			if (EWALD) {
+				if ((r > rc) || (r == 0.0)) continue; // :2917
+				fac = field_real_factor(r, alpha_p, f.es_excluded) * pj.w;
+			} else {
+				if (!((r - kSmallDR < rc) && (r != 0.0))) continue; // :3319
+				fac = pj.w / (r * r * r);
+			}
+			ex += fac * ox;
+			ey += fac * oy;
+			ez += fac * oz;
+		}
+	}
+	double *o = part + ((size_t)blockIdx.y * at.n_pad + i) * 3;
+	o[0] = ex;
+	o[1] = ey;
+	o[2] = ez;
+}
+
+__global__ __launch_bounds__(256) void k_field_finalize(AtomsDev at, Box bx, int polar_ewald, const double *__restrict__ e_recip_part,
+                                                        const double *__restrict__ part, int n_split, double gamma,
+                                                        double *__restrict__ e_static, double *__restrict__ mu) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= at.n_pad) return;
+	double e[3] = {0, 0, 0};
+	if (polar_ewald) {
+		for (int s = 0; s < kKSplit; ++s)
+			for (int p = 0; p < 3; ++p) e[p] += e_recip_part[((size_t)s * at.n_pad + i) * 3 + p];
+		const double sc = 8.0 * kPi / bx.volume; // :2890
+		for (int p = 0; p < 3; ++p) e[p] *= sc;
+	}
+	for (int s = 0; s < n_split; ++s)
+		for (int p = 0; p < 3; ++p) e[p] += part[((size_t)s * at.n_pad + i) * 3 + p];
+	const double a = at.alpha[i];
+	for (int p = 0; p < 3; ++p) {
+		e_static[3 * (size_t)i + p] = e[p];
+		mu[3 * (size_t)i + p] = (a * e[p]) * gamma; // init_dipoles :3553-3556
+	}
+}
+
+void launch_field_recip(hipStream_t st, const AtomsDev &at, const RecipDev &rc, double *e_recip_part) {
+	hipLaunchKernelGGL(k_field_recip, dim3(at.n_pad / kTile, kKSplit), dim3(kTile), 0, st, at, rc, e_recip_part);
+}
+
+void launch_field_real(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, double alpha_p, int n_split, double *part) {
+	const int nt = at.n_pad / kTile;
+	const int tps = (nt + n_split - 1) / n_split;
+	dim3 grid(nt, n_split), block(kTile);
+	if (polar_ewald) {
+		if (bx.ortho)
+			hipLaunchKernelGGL((k_field_real<true, true>), grid, block, 0, st, at, bx, alpha_p, tps, part);
+		else
+			hipLaunchKernelGGL((k_field_real<false, true>), grid, block, 0, st, at, bx, alpha_p, tps, part);
+	} else {
+		if (bx.ortho)
+			hipLaunchKernelGGL((k_field_real<true, false>), grid, block, 0, st, at, bx, alpha_p, tps, part);
+		else
+			hipLaunchKernelGGL((k_field_real<false, false>), grid, block, 0, st, at, bx, alpha_p, tps, part);
+	}
+}
+
+void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip_part, const double *part,
+                           int n_split, double gamma, double *e_static, double *mu) {
+	hipLaunchKernelGGL(k_field_finalize, dim3((at.n_pad + 255) / 256), dim3(256), 0, st, at, bx, polar_ewald, e_recip_part, part, n_split,
+	                   gamma, e_static, mu);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Thole dipole iteration, matrix-free (reference thole_amatrix :2661-2770 + contract_dipoles :3564-3598 fused):
+//   part[s][i] = - sum_{j in split s, j != i} ( a mu_j - b d (d . mu_j) ),  a = damp1/r^3, b = 3 damp2/r^5
+// No cutoff, no exclusions (the A matrix couples every pair).
+// ------------------------------------------------------------------------------------------------------
+template <bool ORTHO>
+__global__ __launch_bounds__(64) void k_dipole_iter_mf(AtomsDev at, Box bx, double lambda, const double *__restrict__ mu, int tiles_per_split,
+                                                       double *__restrict__ part) {
+	__shared__ double4 s_xyzq[kTile];
+	__shared__ double s_mu[kTile * 3];
+	__shared__ int s_fl[kTile];
+	const int lane = threadIdx.x;
+	const int i = blockIdx.x * kTile + lane;
+	const int nt = at.n_pad / kTile;
+	const int t0 = blockIdx.y * tiles_per_split, t1 = min(nt, t0 + tiles_per_split);
+	const double4 pi = at.xyzq[i];
+	double fx = 0, fy = 0, fz = 0;
+	for (int t = t0; t < t1; ++t) {
+		__syncthreads();
+		const int jg = t * kTile + lane;
+		s_xyzq[lane] = at.xyzq[jg];
+		s_fl[lane] = at.mf[jg].y;
+		s_mu[3 * lane + 0] = mu[3 * (size_t)jg + 0];
+		s_mu[3 * lane + 1] = mu[3 * (size_t)jg + 1];
+		s_mu[3 * lane + 2] = mu[3 * (size_t)jg + 2];
+		__syncthreads();
+		for (int jj = 0; jj < kTile; ++jj) {
+			const int j = t * kTile + jj;
+			if ((s_fl[jj] & (AF_PAD | AF_ZERO_ALPHA)) || j == i) continue; // mu_j == 0 for non-polarizable sites
+			const double4 pj = s_xyzq[jj];
+			double ox, oy, oz;
+			const double r = min_image<ORTHO>(bx, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, ox, oy, oz);
+			double a, b;
+			thole_ab(r, lambda, a, b);
+			const double mx = s_mu[3 * jj], my = s_mu[3 * jj + 1], mz = s_mu[3 * jj + 2];
+			const double t3 = b * (((ox * mx) + oy * my) + oz * mz);
+			fx -= a * mx - t3 * ox;
+			fy -= a * my - t3 * oy;
+			fz -= a * mz - t3 * oz;
+		}
+	}
+	double *o = part + ((size_t)blockIdx.y * at.n_pad + i) * 3;
+	o[0] = fx;
+	o[1] = fy;
+	o[2] = fz;
+}
+
+void launch_dipole_iter_mf(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, const double *mu, int n_split, double *part) {
+	const int nt = at.n_pad / kTile;
+	const int tps = (nt + n_split - 1) / n_split;
+	dim3 grid(nt, n_split), block(kTile);
+	if (bx.ortho)
+		hipLaunchKernelGGL(k_dipole_iter_mf<true>, grid, block, 0, st, at, bx, polar_damp, mu, tps, part);
+	else
+		hipLaunchKernelGGL(k_dipole_iter_mf<false>, grid, block, 0, st, at, bx, polar_damp, mu, tps, part);
+}
+
+// contract_dipoles tail :3586-3593, calc_dipole_rrms :3147-3177, are_we_done_yet :3227-3236
+__global__ __launch_bounds__(256) void k_dipole_update(AtomsDev at, const double *__restrict__ e_static, const double *__restrict__ part,
+                                                       int n_split, const double *__restrict__ mu_old, double *__restrict__ mu_new,
+                                                       double *__restrict__ e_induced, int want_rrms, double *__restrict__ rrms_atom,
+                                                       double allowed_sqerr, int *__restrict__ not_done_flag) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= at.n_pad) return;
+	const double a = at.alpha[i];
+	const bool live = (i < at.n) && (a != 0.0);
+	double f[3] = {0, 0, 0}, nm[3] = {0, 0, 0};
+	if (live) {
+		for (int s = 0; s < n_split; ++s)
+			for (int p = 0; p < 3; ++p) f[p] += part[((size_t)s * at.n_pad + i) * 3 + p];
+		for (int p = 0; p < 3; ++p) nm[p] = a * (e_static[3 * (size_t)i + p] + f[p]);
+	}
+	bool broke = false;
+	double acc = 0, nn = 0;
+	for (int p = 0; p < 3; ++p) {
+		const double d = nm[p] - mu_old[3 * (size_t)i + p];
+		acc += d * d;
+		nn += nm[p] * nm[p];
+		if (d * d > allowed_sqerr) broke = true;
+		mu_new[3 * (size_t)i + p] = nm[p];
+		e_induced[3 * (size_t)i + p] = f[p];
+	}
+	if (want_rrms) {
+		double r = sqrt(acc / nn);
+		if (!isfinite(r)) r = 0.0;
+		rrms_atom[i] = (i < at.n) ? r : 0.0;
+	}
+	if (allowed_sqerr > 0.0 && broke && i < at.n) atomicOr(not_done_flag, 1);
+}
+
+__global__ __launch_bounds__(256) void k_dipole_reset(AtomsDev at, const double *__restrict__ e_static, double *__restrict__ mu) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= at.n_pad) return;
+	const double a = at.alpha[i];
+	for (int p = 0; p < 3; ++p) mu[3 * (size_t)i + p] = a * e_static[3 * (size_t)i + p]; // :3486
+}
+
+__global__ __launch_bounds__(256) void k_polar_energy(AtomsDev at, const double *__restrict__ mu, const double *__restrict__ e_static,
+                                                      const double *__restrict__ rrms_atom, double *__restrict__ scal) {
+	__shared__ double sh[4];
+	double u = 0, rr = 0;
+	for (int i = threadIdx.x; i < at.n; i += 256) {
+		const size_t b = 3 * (size_t)i;
+		u += ((mu[b] * e_static[b]) + mu[b + 1] * e_static[b + 1]) + mu[b + 2] * e_static[b + 2];
+		if (rrms_atom) {
+			const double r = rrms_atom[i];
+			if (isfinite(r)) rr += r;
+		}
+	}
+	u = block_sum_256(u, sh);
+	rr = block_sum_256(rr, sh);
+	if (threadIdx.x == 0) {
+		scal[S_POLAR] = -0.5 * u;       // :2618
+		scal[S_RRMS] = rr / (double)at.n; // get_dipole_rrms :2656
+	}
+}
+
+void launch_dipole_update(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, int n_split, const double *mu_old,
+                          double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr, int *not_done_flag) {
+	hipLaunchKernelGGL(k_dipole_update, dim3((at.n_pad + 255) / 256), dim3(256), 0, st, at, e_static, part, n_split, mu_old, mu_new, e_induced,
+	                   want_rrms, rrms_atom, allowed_sqerr, not_done_flag);
+}
+void launch_dipole_reset(hipStream_t st, const AtomsDev &at, const double *e_static, double *mu) {
+	hipLaunchKernelGGL(k_dipole_reset, dim3((at.n_pad + 255) / 256), dim3(256), 0, st, at, e_static, mu);
+}
+void launch_polar_energy(hipStream_t st, const AtomsDev &at, const double *mu, const double *e_static, const double *rrms_atom, double *scal) {
+	hipLaunchKernelGGL(k_polar_energy, dim3(1), dim3(256), 0, st, at, mu, e_static, rrms_atom, scal);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// dense thole_amatrix rows (reference :2661-2770).  One thread per (row atom, column atom) 3x3 block.
+// ------------------------------------------------------------------------------------------------------
+template <bool ORTHO>
+__global__ __launch_bounds__(256) void k_amatrix_rows(AtomsDev at, Box bx, double lambda, int atom0, int natoms_rows, double *__restrict__ a) {
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	const int ir = blockIdx.y; // row atom index relative to atom0
+	if (j >= at.n || ir >= natoms_rows) return;
+	const int i = atom0 + ir;
+	const size_t ld = 3 * (size_t)at.n;
+	double *blk = a + (3 * (size_t)ir) * ld + 3 * (size_t)j;
+	if (i == j) {
+		const double al = at.alpha[i];
+		for (int p = 0; p < 3; ++p)
+			for (int q = 0; q < 3; ++q) blk[p * ld + q] = (p == q) ? ((al != 0.0) ? 1.0 / al : kMaxValue) : 0.0;
+		return;
+	}
+	const int lo = min(i, j), hi = max(i, j); // the reference fills the (lo,hi) block and COPIES it to (hi,lo) (:2762-2764)
+	const double4 pl = at.xyzq[lo], ph = at.xyzq[hi];
+	double d[3];
+	const double r = min_image<ORTHO>(bx, pl.x - ph.x, pl.y - ph.y, pl.z - ph.z, d[0], d[1], d[2]);
+	double ir3, ir5;
+	if (r == 0.0)
+		ir3 = ir5 = kMaxValue;
+	else {
+		const double inv = 1.0 / r;
+		ir3 = inv * inv * inv;
+		ir5 = ir3 * inv * inv;
+	}
+	const double r2 = r * r, l2 = lambda * lambda, l3 = l2 * lambda;
+	const double explr = exp(-lambda * r);
+	const double damp1 = 1.0 - explr * (0.5 * l2 * r2 + lambda * r + 1.0);
+	const double damp2 = damp1 - explr * (l3 * r2 * r / 6.0);
+	for (int p = 0; p < 3; ++p)
+		for (int q = 0; q < 3; ++q) {
+			double v = -3.0 * d[p] * d[q] * damp2 * ir5;
+			if (p == q) v += damp1 * ir3;
+			blk[p * ld + q] = v;
+		}
+}
+
+void launch_amatrix_rows(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, int row0, int nrows, double *a) {
+	const int atom0 = row0 / 3, nat = nrows / 3;
+	dim3 grid((at.n + 255) / 256, nat), block(256);
+	if (bx.ortho)
+		hipLaunchKernelGGL(k_amatrix_rows<true>, grid, block, 0, st, at, bx, polar_damp, atom0, nat, a);
+	else
+		hipLaunchKernelGGL(k_amatrix_rows<false>, grid, block, 0, st, at, bx, polar_damp, atom0, nat, a);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// positions that already live in device memory ([n][3] fp64) -> xyzq.xyz (charge kept)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_set_positions(const double *__restrict__ pos, double4 *__restrict__ xyzq, int first, int count) {
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	if (t >= count) return;
+	double4 v = xyzq[first + t];
+	v.x = pos[3 * (size_t)t + 0];
+	v.y = pos[3 * (size_t)t + 1];
+	v.z = pos[3 * (size_t)t + 2];
+	xyzq[first + t] = v;
+}
+void launch_set_positions(hipStream_t st, const double *pos_dev, double4 *xyzq, int first, int count) {
+	if (count > 0) hipLaunchKernelGGL(k_set_positions, dim3((count + 255) / 256), dim3(256), 0, st, pos_dev, xyzq, first, count);
+}
+
+} // namespace mpmc

@@ -1,0 +1,335 @@
+"""ctypes binding of the C ABI (include/mpmc_energy.h) -- host-side mirror of the reference's energy surface.
+
+`System` mirrors the part of the reference's `System` class that the energy hot path exposes
+(reference src/System.h:314-402): ``energy()``, ``lj()``, ``coulombic()``, ``coulombic_real()``,
+``coulombic_reciprocal()``, ``coulombic_self()``, ``polar()``, ``thole_field()``, ``thole_amatrix()`` and the
+``observables`` it fills; errors surface as ``MpmcError(code)`` with the reference's integer error codes
+(src/constants.h:108-147), the Python spelling of the reference's ``throw <int>``.
+
+There is no CPU fallback: if the HIP library is missing or no device is present this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# status codes (include/mpmc_energy.h)
+MPMC_OK = 0
+ERR_UNSUPPORTED = 4004
+ERR_INVALID_SETTING = 4000
+ERR_NO_DEVICE = -1
+DAMPING = {"off": 0, "linear": 1, "exponential": 2, None: 2}
+SOLVER = {"auto": 0, "matrix_free": 1, "compact": 2, "dense": 3}
+K_NAMES = ["pair", "recip", "field", "tensor", "dipole_iter", "reduce"]
+
+
+class MpmcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mpmc error {code}: {msg}")
+        self.code = code
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("rd_only", C.c_int32), ("rd_lrc", C.c_int32), ("polarization", C.c_int32), ("polar_iterative", C.c_int32),
+        ("polar_ewald", C.c_int32), ("polar_max_iter", C.c_int32), ("polar_gs", C.c_int32), ("polar_rrms", C.c_int32),
+        ("damp_type", C.c_int32), ("ewald_kmax", C.c_int32), ("solver", C.c_int32), ("reserved0", C.c_int32),
+        ("polar_precision", C.c_double), ("polar_gamma", C.c_double), ("polar_damp", C.c_double),
+        ("ewald_alpha", C.c_double), ("polar_ewald_alpha", C.c_double), ("unsupported_flags", C.c_uint64),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("energy", C.c_double), ("rd_energy", C.c_double), ("coulombic_energy", C.c_double), ("polarization_energy", C.c_double),
+        ("vdw_energy", C.c_double), ("three_body_energy", C.c_double), ("kinetic_energy", C.c_double),
+        ("es_real", C.c_double), ("es_recip", C.c_double), ("es_self", C.c_double),
+        ("lj_pairs", C.c_double), ("lrc_pair", C.c_double), ("lrc_self", C.c_double),
+        ("dipole_rrms", C.c_double), ("N", C.c_double), ("NU", C.c_double),
+        ("n_pairs", C.c_int64), ("n_lj_in_cutoff", C.c_int64), ("n_es_in_cutoff", C.c_int64), ("n_intra", C.c_int64),
+        ("n_rd_excluded", C.c_int64), ("n_es_excluded", C.c_int64), ("n_frozen", C.c_int64),
+        ("polar_iterations", C.c_int32), ("iterator_failed", C.c_int32),
+    ]
+
+    def as_dict(self) -> Dict[str, float]:
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int64 * 6)]
+
+
+_lib = None
+
+
+def lib():
+    """load (building if needed) mpmcxx_amd/libmpmc_energy.so; raises if it cannot be produced."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        path = _build.build_library()
+    L = C.CDLL(path)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    L.mpmc_abi_version.restype = C.c_int
+    L.mpmc_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.mpmc_last_error.argtypes = [vp]
+    L.mpmc_last_error.restype = C.c_char_p
+    L.mpmc_pbc_compute.argtypes = [dp, dp, dp, dp]
+    L.mpmc_default_options.argtypes = [C.POINTER(Options)]
+    L.mpmc_default_options.restype = None
+    L.mpmc_ctx_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.mpmc_ctx_destroy.argtypes = [vp]
+    L.mpmc_set_box.argtypes = [vp, dp, dp, C.c_double, C.c_double]
+    L.mpmc_set_options.argtypes = [vp, C.POINTER(Options)]
+    L.mpmc_set_atoms.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, ip, ip, ip, dp]
+    L.mpmc_update_positions.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.mpmc_set_positions_device.argtypes = [vp, vp]
+    L.mpmc_energy.argtypes = [vp, C.POINTER(Result)]
+    L.mpmc_energy_async.argtypes = [vp]
+    L.mpmc_energy_wait.argtypes = [vp, C.POINTER(Result)]
+    for name in ("mpmc_lj", "mpmc_coulombic", "mpmc_coulombic_real", "mpmc_coulombic_reciprocal", "mpmc_coulombic_self", "mpmc_polar"):
+        getattr(L, name).argtypes = [vp, dp]
+    L.mpmc_thole_field.argtypes = [vp, dp]
+    L.mpmc_thole_amatrix.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.mpmc_get_dipoles.argtypes = [vp, dp, dp, dp]
+    L.mpmc_update_com.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_int)]
+    L.mpmc_pi_potential_local.argtypes = [C.POINTER(vp), C.c_int, dp, C.POINTER(Result), C.POINTER(C.c_int)]
+    L.mpmc_pi_finish.argtypes = [dp, C.c_int, dp]
+    L.mpmc_pi_finish.restype = C.c_double
+    L.mpmc_set_profiling.argtypes = [vp, C.c_int]
+    L.mpmc_get_timings.argtypes = [vp, C.POINTER(Timings), C.c_int]
+    L.mpmc_synchronize.argtypes = [vp]
+    L.mpmc_memory_usage.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    _lib = L
+    return L
+
+
+def _dp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib().mpmc_device_count(C.byref(n))
+    return n.value
+
+
+def pbc_compute(basis: np.ndarray):
+    """PeriodicBoundary::update: returns (reciprocal(3,3), volume, cutoff)."""
+    b = np.ascontiguousarray(basis, dtype=np.float64).reshape(9)
+    R = np.zeros(9)
+    vol, cut = C.c_double(), C.c_double()
+    rc = lib().mpmc_pbc_compute(_dp(b), _dp(R), C.byref(vol), C.byref(cut))
+    if rc != MPMC_OK:
+        raise MpmcError(rc, "invalid box")
+    return R.reshape(3, 3), vol.value, cut.value
+
+
+def make_options(opts: Dict[str, object]) -> Options:
+    o = Options()
+    lib().mpmc_default_options(C.byref(o))
+    for k in ("rd_only", "rd_lrc", "polarization", "polar_iterative", "polar_ewald", "polar_max_iter", "polar_gs", "polar_rrms", "ewald_kmax"):
+        if k in opts and opts[k] is not None:
+            setattr(o, k, int(opts[k]))
+    for k in ("polar_precision", "polar_gamma", "polar_damp"):
+        if k in opts and opts[k] is not None:
+            setattr(o, k, float(opts[k]))
+    for k in ("ewald_alpha", "polar_ewald_alpha"):
+        v = opts.get(k)
+        setattr(o, k, float(v) if v is not None else 0.0)
+    dt = opts.get("damp_type")
+    o.damp_type = DAMPING[dt] if not isinstance(dt, int) else dt
+    sv = opts.get("solver", "auto")
+    o.solver = SOLVER[sv] if not isinstance(sv, int) else sv
+    o.unsupported_flags = int(opts.get("unsupported_flags", 0))
+    return o
+
+
+class System:
+    """Device-resident state of one box (one reference `System` / one PI bead)."""
+
+    def __init__(self, atoms: Dict[str, np.ndarray], basis: np.ndarray, options: Dict[str, object], device: int = 0,
+                 max_atoms: Optional[int] = None):
+        L = lib()
+        self._L = L
+        self._h = C.c_void_p()
+        n = int(np.asarray(atoms["pos"]).shape[0])
+        rc = L.mpmc_ctx_create(int(device), int(max_atoms or n), C.byref(self._h))
+        if rc != MPMC_OK:
+            raise MpmcError(rc, (L.mpmc_last_error(None) or b"").decode())
+        self.n = n
+        self.observables: Dict[str, float] = {}
+        self.set_box(basis)
+        self.set_options(options)
+        self.set_atoms(atoms)
+
+    # -- plumbing -------------------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != MPMC_OK:
+            raise MpmcError(rc, (self._L.mpmc_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.mpmc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    # -- state ------------------------------------------------------------------------------------------------
+    def set_box(self, basis: np.ndarray):
+        b = np.ascontiguousarray(basis, dtype=np.float64).reshape(9)
+        self._check(self._L.mpmc_set_box(self._h, _dp(b), None, 0.0, 0.0))
+        self.basis = b.reshape(3, 3).copy()
+
+    def set_options(self, options: Dict[str, object]):
+        self._opts = make_options(options)
+        self._check(self._L.mpmc_set_options(self._h, C.byref(self._opts)))
+        self.options = dict(options)
+
+    def set_atoms(self, atoms: Dict[str, np.ndarray]):
+        f = lambda k: np.ascontiguousarray(atoms[k], dtype=np.float64)
+        g = lambda k: np.ascontiguousarray(atoms[k], dtype=np.int32)
+        pos = f("pos").reshape(-1)
+        n = pos.size // 3
+        disp = g("has_disp") if "has_disp" in atoms else None
+        mass = f("mass") if "mass" in atoms else None
+        self._check(self._L.mpmc_set_atoms(self._h, n, _dp(pos), _dp(f("charge")), _dp(f("polarizability")), _dp(f("epsilon")),
+                                           _dp(f("sigma")), _ip(g("mol_id")), _ip(g("frozen")), _ip(disp), _dp(mass)))
+        self.n = n
+
+    def update_positions(self, first: int, pos: np.ndarray):
+        p = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1)
+        self._check(self._L.mpmc_update_positions(self._h, int(first), p.size // 3, _dp(p)))
+
+    def set_positions_device(self, data_ptr: int):
+        self._check(self._L.mpmc_set_positions_device(self._h, C.c_void_p(data_ptr)))
+
+    # -- double System::energy() (reference src/System.Energy.cpp:19) ---------------------------------------------
+    def energy(self) -> float:
+        r = Result()
+        self._check(self._L.mpmc_energy(self._h, C.byref(r)))
+        self.observables = r.as_dict()
+        return r.energy
+
+    def energy_async(self):
+        self._check(self._L.mpmc_energy_async(self._h))
+
+    def energy_wait(self) -> float:
+        r = Result()
+        self._check(self._L.mpmc_energy_wait(self._h, C.byref(r)))
+        self.observables = r.as_dict()
+        return r.energy
+
+    def _scalar(self, fn) -> float:
+        v = C.c_double()
+        self._check(fn(self._h, C.byref(v)))
+        return v.value
+
+    def lj(self) -> float:
+        return self._scalar(self._L.mpmc_lj)
+
+    def coulombic(self) -> float:
+        return self._scalar(self._L.mpmc_coulombic)
+
+    def coulombic_real(self) -> float:
+        return self._scalar(self._L.mpmc_coulombic_real)
+
+    def coulombic_reciprocal(self) -> float:
+        return self._scalar(self._L.mpmc_coulombic_reciprocal)
+
+    def coulombic_self(self) -> float:
+        return self._scalar(self._L.mpmc_coulombic_self)
+
+    def polar(self) -> float:
+        return self._scalar(self._L.mpmc_polar)
+
+    def thole_field(self) -> np.ndarray:
+        E = np.zeros((self.n, 3))
+        self._check(self._L.mpmc_thole_field(self._h, _dp(E)))
+        return E
+
+    def thole_amatrix(self, row0: int = 0, nrows: Optional[int] = None) -> np.ndarray:
+        nrows = 3 * self.n - row0 if nrows is None else nrows
+        A = np.zeros((nrows, 3 * self.n))
+        self._check(self._L.mpmc_thole_amatrix(self._h, int(row0), int(nrows), _dp(A)))
+        return A
+
+    def dipoles(self):
+        mu, E, F = np.zeros((self.n, 3)), np.zeros((self.n, 3)), np.zeros((self.n, 3))
+        self._check(self._L.mpmc_get_dipoles(self._h, _dp(mu), _dp(E), _dp(F)))
+        return mu, E, F
+
+    def update_com(self):
+        nm = C.c_int(0)
+        com = np.zeros((self.n, 3))
+        wcom = np.zeros((self.n, 3))
+        wpos = np.zeros((self.n, 3))
+        self._check(self._L.mpmc_update_com(self._h, _dp(com), _dp(wcom), _dp(wpos), C.byref(nm)))
+        return com[: nm.value], wcom[: nm.value], wpos
+
+    # -- measurement --------------------------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self._check(self._L.mpmc_set_profiling(self._h, 1 if on else 0))
+
+    def timings(self, reset: bool = False) -> Dict[str, Dict[str, float]]:
+        t = Timings()
+        self._check(self._L.mpmc_get_timings(self._h, C.byref(t), 1 if reset else 0))
+        return {K_NAMES[i]: {"ms": t.ms[i], "launches": int(t.launches[i])} for i in range(6)}
+
+    def synchronize(self):
+        self._check(self._L.mpmc_synchronize(self._h))
+
+    def memory_usage(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._L.mpmc_memory_usage(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+def pi_potential_local(beads: Sequence[System]):
+    """local leg of SimulationControl::PI_calculate_potential (reference PathIntegral.cpp:752-805):
+    returns (sums4 = ordered sums of {rd, coulombic, polarization, vdw} over this rank's beads, per-bead results, failed)."""
+    L = lib()
+    n = len(beads)
+    arr = (C.c_void_p * max(n, 1))(*[b.handle for b in beads])
+    sums = np.zeros(4)
+    res = (Result * max(n, 1))()
+    failed = C.c_int(0)
+    rc = L.mpmc_pi_potential_local(arr, n, _dp(sums), res, C.byref(failed))
+    if rc != MPMC_OK:
+        msg = b""
+        for b in beads:
+            msg = L.mpmc_last_error(b.handle) or msg
+        raise MpmcError(rc, msg.decode())
+    per = [res[i].as_dict() for i in range(n)]
+    for b, r in zip(beads, per):
+        b.observables = r
+    return sums, per, bool(failed.value)
+
+
+def pi_finish(sums4_global: np.ndarray, P: int):
+    s = np.ascontiguousarray(sums4_global, dtype=np.float64)
+    obs = np.zeros(4)
+    v = lib().mpmc_pi_finish(_dp(s), int(P), _dp(obs))
+    return v, obs

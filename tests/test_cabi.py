@@ -1,0 +1,71 @@
+"""CPU: the C-ABI library builds (hipcc cross-compiles gfx950), loads, and exports every symbol that
+include/mpmc_energy.h declares.  No compute calls here (there is no GPU in this container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import util
+from mpmcxx_amd import build as mbuild
+from mpmcxx_amd import energy
+
+
+def declared_symbols():
+    hdr = open(os.path.join(util.ROOT, "include", "mpmc_energy.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpmc_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = mbuild.build_library()
+    assert os.path.exists(path)
+    L = ctypes.CDLL(path)
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+    assert L.mpmc_abi_version() == 1
+
+
+def test_code_object_is_gfx950():
+    data = open(mbuild.build_library(), "rb").read()
+    assert b"gfx950" in data
+    for kern in (b"k_pair_energy", b"k_recip_sf", b"k_field_real", b"k_dipole_iter_mf"):
+        assert kern in data, kern
+
+
+def test_struct_layouts_match_header():
+    # sizes the C side compiled with (guards the ctypes mirrors in mpmcxx_amd/energy.py)
+    assert ctypes.sizeof(energy.Options) == 12 * 4 + 5 * 8 + 8
+    assert ctypes.sizeof(energy.Result) == 16 * 8 + 7 * 8 + 2 * 4
+    assert ctypes.sizeof(energy.Timings) == 6 * 8 + 6 * 8
+
+
+def test_pbc_compute_matches_reference_values():
+    # host helper (PeriodicBoundary::update) -- golden values come from the reference harness
+    for name in ("ion216_polar", "ion216_triclinic", "ar2"):
+        g = util.golden(name)
+        R, vol, cut = energy.pbc_compute(np.array(g["basis"]).reshape(3, 3))
+        assert vol == g["volume"] and cut == g["cutoff"]
+        assert np.array_equal(R.reshape(-1), np.array(g["reciprocal_basis"]))
+
+
+def test_no_cpu_fallback_without_device():
+    if energy.device_count() > 0:
+        pytest.skip("a GPU is present")
+    atoms, basis, opts = util.load_fixture("ar2")
+    with pytest.raises(energy.MpmcError) as ei:
+        energy.System(atoms, basis, opts)
+    assert ei.value.code == energy.ERR_NO_DEVICE
+    assert "no CPU path" in str(ei.value)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(util.ROOT, "mpmcxx_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "mpmc_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
