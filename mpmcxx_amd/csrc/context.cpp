@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -71,6 +72,12 @@ struct mpmc_ctx {
 	// dense A rows scratch
 	double *d_arows = nullptr;
 	size_t cap_arows = 0;
+	// compact Thole tensor store: (a,b) per unordered pair, tile-pair major, 64*64 double2 per tile pair
+	double2 *d_ab = nullptr;
+	size_t cap_ab = 0; // in double2 elements
+	int solver_used = MPMC_SOLVER_MATRIX_FREE;
+	bool use_dpp = true;   // lane rotation by v_mov_b32_dpp wave_rol:1 (verified at create), else ds_bpermute
+	bool legacy = false;   // MPMC_LEGACY_KERNELS=1: first-generation split kernels (A/B comparisons only)
 
 	Box box{};
 	bool box_set = false, atoms_set = false, opts_set = false, k_dirty = true;
@@ -220,6 +227,54 @@ extern "C" void mpmc_default_options(mpmc_options *o) {
 	o->solver = MPMC_SOLVER_AUTO;
 }
 
+// largest double t >= 0 with pred(t) true, for a predicate that is true below and false above some point near rc^2
+template <typename Pred>
+static double bisect_threshold(double rc, Pred pred) {
+	double lo = rc * rc * (1.0 - 1e-6), hi = rc * rc * (1.0 + 1e-6) + 1e-300;
+	if (!pred(lo) || pred(hi)) return pred(hi) ? hi : -1.0; // degenerate box; callers validated rc > 0
+	uint64_t a, b;
+	std::memcpy(&a, &lo, 8);
+	std::memcpy(&b, &hi, 8);
+	while (b - a > 1) { // positive doubles order like their bit patterns
+		uint64_t m = a + (b - a) / 2;
+		double x;
+		std::memcpy(&x, &m, 8);
+		if (pred(x)) a = m;
+		else b = m;
+	}
+	double out;
+	std::memcpy(&out, &a, 8);
+	return out;
+}
+
+// per-device result of the lane-rotation self-test (0 unknown, 1 dpp ok, 2 dpp wrong -> ds_bpermute)
+static int g_rot_mode[64] = {0};
+static int rot_selftest(mpmc_ctx *c) {
+	if (c->device < 64 && g_rot_mode[c->device]) {
+		c->use_dpp = (g_rot_mode[c->device] == 1);
+		return MPMC_OK;
+	}
+	int *d = nullptr, h[128];
+	HIP_TRY(c, hipMalloc((void **)&d, 128 * sizeof(int)));
+	launch_rot_selftest(c->stream, d, d + 64);
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	(void)hipFree(d);
+	bool dpp_ok = true, perm_ok = true;
+	for (int l = 0; l < 64; l++) {
+		if (h[l] != ((l + 1) & 63)) dpp_ok = false;
+		if (h[64 + l] != ((l + 1) & 63)) perm_ok = false;
+	}
+	if (!perm_ok) {
+		c->err = "lane-rotation self-test failed (ds_bpermute)";
+		return MPMC_ERR_INTERNAL;
+	}
+	c->use_dpp = dpp_ok;
+	if (c->device < 64) g_rot_mode[c->device] = dpp_ok ? 1 : 2;
+	return MPMC_OK;
+}
+
 // ---- lifetime --------------------------------------------------------------------------------------------
 extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	if (!out || max_atoms <= 0) return fail(nullptr, MPMC_ERR_ARG, "mpmc_ctx_create: bad argument");
@@ -255,11 +310,14 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_scal, S_COUNT * sizeof(double)) != hipSuccess) rc = MPMC_ERR_HIP;
 	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_cnt, C_COUNT * sizeof(long long)) != hipSuccess) rc = MPMC_ERR_HIP;
 	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_flag, sizeof(int)) != hipSuccess) rc = MPMC_ERR_HIP;
+	if (rc == MPMC_OK) rc = rot_selftest(c);
 	if (rc != MPMC_OK) {
 		g_create_error = "mpmc_ctx_create: device allocation failed: " + c->err;
 		mpmc_ctx_destroy(c);
 		return rc;
 	}
+	if (const char *e = std::getenv("MPMC_LEGACY_KERNELS")) c->legacy = (e[0] == '1');
+	if (const char *e = std::getenv("MPMC_NO_DPP")) if (e[0] == '1') c->use_dpp = false;
 	*out = c;
 	return MPMC_OK;
 }
@@ -272,7 +330,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows};
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (c->h_scal) (void)hipHostFree(c->h_scal);
@@ -297,6 +355,9 @@ extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *re
 	std::memcpy(c->box.r, R, sizeof(R));
 	c->box.volume = vol;
 	c->box.cutoff = cut;
+	// squared-distance forms of the reference's cutoff predicates (see pair_math.h Box)
+	c->box.t_lj = bisect_threshold(cut, [cut](double t) { return std::sqrt(t) - kSmallDR < cut; });
+	c->box.t_es = bisect_threshold(cut, [cut](double t) { return !(std::sqrt(t) > cut); });
 	c->box.ortho = 1;
 	for (int i = 0; i < 3; i++)
 		for (int j = 0; j < 3; j++)
@@ -324,8 +385,8 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 			return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: polar_max_iter must be >= 1 when polar_precision is 0 (the reference never terminates)");
 		if (o->polar_precision < 0.0) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: polar_precision < 0");
 		if (o->solver < MPMC_SOLVER_AUTO || o->solver > MPMC_SOLVER_DENSE) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: bad solver");
-		if (o->solver == MPMC_SOLVER_COMPACT || o->solver == MPMC_SOLVER_DENSE)
-			return fail(c, MPMC_ERR_UNSUPPORTED, "mpmc_set_options: stored-tensor solvers are not built in this version; use AUTO or MATRIX_FREE");
+		if (o->solver == MPMC_SOLVER_DENSE)
+			return fail(c, MPMC_ERR_UNSUPPORTED, "mpmc_set_options: the dense 3N x 3N solver is not built; mpmc_thole_amatrix gives the dense matrix, COMPACT stores the same tensors in 16 B/pair");
 	}
 	if (o->ewald_kmax < 0 || o->ewald_kmax > 64) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: ewald_kmax out of range");
 	c->opts = *o;
@@ -532,13 +593,41 @@ static int ensure_polar_buffers(mpmc_ctx *c) {
 		HIP_TRY(c, hipMemset(c->d_e_induced, 0, 3 * np * sizeof(double)));
 		HIP_TRY(c, hipMemset(c->d_rrms, 0, np * sizeof(double)));
 	}
-	const size_t need = (size_t)c->n_split * c->n_pad * 3;
+	// per-atom partial slots: one per source tile (symmetric kernels) -- also covers the n_split <= n_tiles slots
+	// of the first-generation row kernels
+	const size_t need = (size_t)c->n_tiles * c->n_pad * 3;
 	if (need > c->cap_part) {
 		dev_free(c, &c->d_part, c->cap_part);
 		c->cap_part = 0;
 		if ((rc = dev_alloc(c, &c->d_part, need)) != MPMC_OK) return rc;
 		c->cap_part = need;
 	}
+	return MPMC_OK;
+}
+
+// decide how the dipole iteration runs and (COMPACT) make room for the tensor store
+static int resolve_solver(mpmc_ctx *c) {
+	const size_t need = (size_t)c->n_tile_pairs * (kTile * kTile); // double2 elements, 16 B each
+	int want = c->opts.solver;
+	if (c->legacy) want = MPMC_SOLVER_MATRIX_FREE;
+	if (want == MPMC_SOLVER_AUTO) {
+		size_t budget_mb = 4096;
+		if (const char *e = std::getenv("MPMC_TENSOR_BUDGET_MB")) budget_mb = (size_t)std::strtoull(e, nullptr, 10);
+		want = (need * sizeof(double2) <= budget_mb * (size_t)1048576) ? MPMC_SOLVER_COMPACT : MPMC_SOLVER_MATRIX_FREE;
+	}
+	if (want == MPMC_SOLVER_COMPACT && need > c->cap_ab) {
+		dev_free(c, &c->d_ab, c->cap_ab);
+		c->cap_ab = 0;
+		int rc = dev_alloc(c, &c->d_ab, need);
+		if (rc != MPMC_OK) {
+			if (c->opts.solver == MPMC_SOLVER_COMPACT) return rc; // explicitly requested: report
+			(void)hipGetLastError();
+			want = MPMC_SOLVER_MATRIX_FREE; // AUTO: fall back to recomputing the tensors (still the HIP path)
+		} else {
+			c->cap_ab = need;
+		}
+	}
+	c->solver_used = want;
 	return MPMC_OK;
 }
 
@@ -597,14 +686,40 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 	HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, S_COUNT * sizeof(double), st));
 	HIP_TRY(c, hipMemsetAsync(c->d_cnt, 0, C_COUNT * sizeof(long long), st));
 
-	if (mask & RUN_PAIR) {
-		ProfScope p(c, MPMC_K_PAIR);
-		PairParams pp;
-		pp.ewald_alpha = c->ewald_alpha;
-		pp.rd_lrc = o.rd_lrc;
-		pp.do_es = (mask & RUN_PAIR_ES) ? 1 : 0;
-		launch_pair_energy(st, at, c->box, pp, c->d_tile_pairs, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt);
+	if (mask & (RUN_FIELD | RUN_SOLVE)) {
+		if ((rc = ensure_polar_buffers(c)) != MPMC_OK) return rc;
+		if ((rc = resolve_solver(c)) != MPMC_OK) return rc;
 	}
+	const bool compact = (mask & RUN_SOLVE) && c->solver_used == MPMC_SOLVER_COMPACT;
+	const int field_slots = c->legacy ? c->n_split : c->n_tiles;
+
+	// ---- pairwise pass ------------------------------------------------------------------------------------
+	if (c->legacy) {
+		if (mask & RUN_PAIR) {
+			ProfScope p(c, MPMC_K_PAIR);
+			PairParams pp;
+			pp.ewald_alpha = c->ewald_alpha;
+			pp.rd_lrc = o.rd_lrc;
+			pp.do_es = (mask & RUN_PAIR_ES) ? 1 : 0;
+			launch_pair_energy(st, at, c->box, pp, c->d_tile_pairs, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt);
+		}
+	} else if (mask & (RUN_PAIR | RUN_FIELD)) {
+		// one symmetric pass: energies + counts, static-field partials, Thole tensor store
+		ProfScope p(c, MPMC_K_PAIR);
+		FusedParams fp;
+		fp.ewald_alpha = c->ewald_alpha;
+		fp.polar_ewald_alpha = c->polar_ewald_alpha;
+		fp.polar_damp = o.polar_damp;
+		fp.rd_lrc = o.rd_lrc;
+		fp.do_es = ((mask & RUN_PAIR_ES) || (mask & RUN_FIELD)) ? 1 : 0;
+		fp.do_field = (mask & RUN_FIELD) ? (o.polar_ewald ? 1 : 2) : 0;
+		fp.do_thole = compact ? 1 : 0;
+		launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
+		                  compact ? c->d_ab : nullptr);
+		if (mask & RUN_PAIR) launch_reduce_pairs(st, c->d_block_part, c->d_block_cnt, c->n_tile_pairs, c->d_scal, c->d_cnt);
+	}
+
+	// ---- reciprocal space + O(N) atom terms ------------------------------------------------------------------
 	const bool need_sf = (mask & RUN_RECIP) || ((mask & RUN_FIELD) && o.polar_ewald);
 	if (need_sf || (mask & RUN_ATOMTERMS)) {
 		ProfScope p(c, MPMC_K_RECIP);
@@ -612,22 +727,23 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		if (mask & (RUN_RECIP | RUN_ATOMTERMS))
 			launch_recip_energy(st, at, rcp, c->box, c->ewald_alpha, o.rd_lrc, (mask & RUN_RECIP) ? 1 : 0, c->d_scal);
 	}
-	if (mask & (RUN_FIELD | RUN_SOLVE)) {
-		if ((rc = ensure_polar_buffers(c)) != MPMC_OK) return rc;
-	}
+
+	// ---- static field ---------------------------------------------------------------------------------------
 	if (mask & RUN_FIELD) {
 		ProfScope p(c, MPMC_K_FIELD);
 		if (o.polar_ewald) launch_field_recip(st, at, rcp, c->d_e_recip_part);
-		launch_field_real(st, at, c->box, o.polar_ewald, c->polar_ewald_alpha, c->n_split, c->d_part);
+		if (c->legacy) launch_field_real(st, at, c->box, o.polar_ewald, c->polar_ewald_alpha, c->n_split, c->d_part);
 		c->mu_cur = 0;
-		launch_field_finalize(st, at, c->box, o.polar_ewald, c->d_e_recip_part, c->d_part, c->n_split, o.polar_gamma, c->d_e_static,
+		launch_field_finalize(st, at, c->box, o.polar_ewald, c->d_e_recip_part, c->d_part, field_slots, o.polar_gamma, c->d_e_static,
 		                      c->d_mu[0]);
 	}
+
+	// ---- thole_iterative, reference src/System.Energy.cpp:3450-3543 ------------------------------------------------
 	if (mask & RUN_SOLVE) {
-		// thole_iterative, reference src/System.Energy.cpp:3450-3543
 		const bool by_precision = (o.polar_precision != 0.0);
 		const int want_rrms = (o.polar_rrms || o.polar_precision > 0) ? 1 : 0;
 		const double allowed = by_precision ? o.polar_precision * o.polar_precision * kDebye2SKA * kDebye2SKA : 0.0;
+		const int iter_slots = compact ? c->n_tiles : c->n_split;
 		int it = 0;
 		bool keep = true;
 		while (keep) {
@@ -640,11 +756,14 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 			if (by_precision) HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
 			{
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
-				launch_dipole_iter_mf(st, at, c->box, o.polar_damp, c->d_mu[c->mu_cur], c->n_split, c->d_part);
+				if (compact)
+					launch_dipole_iter_compact(st, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->n_tile_pairs, c->d_ab, c->d_part);
+				else
+					launch_dipole_iter_mf(st, at, c->box, o.polar_damp, c->d_mu[c->mu_cur], c->n_split, c->d_part);
 			}
 			{
 				ProfScope p(c, MPMC_K_REDUCE);
-				launch_dipole_update(st, at, c->d_e_static, c->d_part, c->n_split, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur], c->d_e_induced,
+				launch_dipole_update(st, at, c->d_e_static, c->d_part, iter_slots, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur], c->d_e_induced,
 				                     want_rrms, c->d_rrms, allowed, c->d_flag);
 			}
 			c->mu_cur = 1 - c->mu_cur;
@@ -916,6 +1035,6 @@ extern "C" int mpmc_synchronize(mpmc_ctx *c) {
 extern "C" int mpmc_memory_usage(mpmc_ctx *c, int64_t *total, int64_t *tensor) {
 	if (!c) return MPMC_ERR_ARG;
 	if (total) *total = c->bytes_total;
-	if (tensor) *tensor = 0;
+	if (tensor) *tensor = (c->solver_used == MPMC_SOLVER_COMPACT) ? (int64_t)(c->cap_ab * sizeof(double2)) : 0;
 	return MPMC_OK;
 }

@@ -75,6 +75,25 @@ void launch_polar_energy(hipStream_t st, const AtomsDev &at, const double *mu, c
 // dense thole_amatrix rows (parity / DENSE solver)
 void launch_amatrix_rows(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, int row0, int nrows, double *a /*[nrows][3n]*/);
 
+// ---- symmetric production kernels (kernels_sym.hip) -------------------------------------------------------
+struct FusedParams {
+	double ewald_alpha, polar_ewald_alpha, polar_damp;
+	int rd_lrc;
+	int do_es;    // electrostatics on
+	int do_field; // 0 none, 1 Ewald real_term, 2 thole_field_nopbc
+	int do_thole; // write the (a,b) tensor store
+};
+// every unordered pair once: energies + counts (block partials), static-field partials fpart[nt][n_pad][3],
+// Thole store ab[n_tile_pairs][64*64] (double2 = 16 B per pair)
+void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
+                       int n_tile_pairs, double *block_part, int *block_cnt, double *fpart, double2 *ab);
+void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt);
+// one Jacobi contraction streaming the store: part[nt][n_pad][3]
+void launch_dipole_iter_compact(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+                                int n_tile_pairs, const double2 *ab, double *part);
+// lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
+void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm);
+
 // device-resident positions [count][3] -> xyzq[first .. first+count).xyz
 void launch_set_positions(hipStream_t st, const double *pos_dev, double4 *xyzq, int first, int count);
 

@@ -163,6 +163,10 @@ void launch_pair_energy(hipStream_t st, const AtomsDev &at, const Box &bx, const
 	hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, block_part, block_cnt, n_tile_pairs, scal, cnt);
 }
 
+void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt) {
+	hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, block_part, block_cnt, nb, scal, cnt);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // reciprocal space (reference coulombic_reciprocal :1561-1622, recip_term :2834-2896, coulombic_self :1626-1643,
 // lj_lrc_self :1072-1096)
@@ -304,11 +308,40 @@ __global__ __launch_bounds__(64) void k_field_real(AtomsDev at, Box bx, double a
 	o[2] = ez;
 }
 
-__global__ __launch_bounds__(256) void k_field_finalize(AtomsDev at, Box bx, int polar_ewald, const double *__restrict__ e_recip_part,
+// sum of the per-source-tile partial slots of 64 atoms: 8 groups of 64 threads stride over the slots, then a fixed-order
+// fold through LDS (bit-reproducible).  Result valid in the threads with g == 0.
+constexpr int kSlotGroups = 8;
+__device__ __forceinline__ void slot_sum_64(const double *__restrict__ part, int n_slots, int n_pad, int i, int a, int g,
+                                            double (*sh)[kTile][3], double out[3]) {
+	double f[3] = {0, 0, 0};
+	for (int t = g; t < n_slots; t += kSlotGroups) {
+		const double *q = part + ((size_t)t * n_pad + i) * 3;
+		f[0] += q[0];
+		f[1] += q[1];
+		f[2] += q[2];
+	}
+	sh[g][a][0] = f[0];
+	sh[g][a][1] = f[1];
+	sh[g][a][2] = f[2];
+	__syncthreads();
+	if (g == 0) {
+		for (int p = 0; p < 3; ++p) {
+			double v = sh[0][a][p];
+			for (int k = 1; k < kSlotGroups; ++k) v += sh[k][a][p];
+			out[p] = v;
+		}
+	}
+}
+
+__global__ __launch_bounds__(512) void k_field_finalize(AtomsDev at, Box bx, int polar_ewald, const double *__restrict__ e_recip_part,
                                                         const double *__restrict__ part, int n_split, double gamma,
                                                         double *__restrict__ e_static, double *__restrict__ mu) {
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= at.n_pad) return;
+	__shared__ double sh[kSlotGroups][kTile][3];
+	const int a = threadIdx.x & 63, g = threadIdx.x >> 6;
+	const int i = blockIdx.x * kTile + a;
+	double real[3];
+	slot_sum_64(part, n_split, at.n_pad, i, a, g, sh, real);
+	if (g != 0) return;
 	double e[3] = {0, 0, 0};
 	if (polar_ewald) {
 		for (int s = 0; s < kKSplit; ++s)
@@ -316,12 +349,11 @@ __global__ __launch_bounds__(256) void k_field_finalize(AtomsDev at, Box bx, int
 		const double sc = 8.0 * kPi / bx.volume; // :2890
 		for (int p = 0; p < 3; ++p) e[p] *= sc;
 	}
-	for (int s = 0; s < n_split; ++s)
-		for (int p = 0; p < 3; ++p) e[p] += part[((size_t)s * at.n_pad + i) * 3 + p];
-	const double a = at.alpha[i];
+	for (int p = 0; p < 3; ++p) e[p] += real[p]; // real_term is added after the reciprocal part was scaled
+	const double al = at.alpha[i];
 	for (int p = 0; p < 3; ++p) {
 		e_static[3 * (size_t)i + p] = e[p];
-		mu[3 * (size_t)i + p] = (a * e[p]) * gamma; // init_dipoles :3553-3556
+		mu[3 * (size_t)i + p] = (al * e[p]) * gamma; // init_dipoles :3553-3556
 	}
 }
 
@@ -348,7 +380,7 @@ void launch_field_real(hipStream_t st, const AtomsDev &at, const Box &bx, int po
 
 void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip_part, const double *part,
                            int n_split, double gamma, double *e_static, double *mu) {
-	hipLaunchKernelGGL(k_field_finalize, dim3((at.n_pad + 255) / 256), dim3(256), 0, st, at, bx, polar_ewald, e_recip_part, part, n_split,
+	hipLaunchKernelGGL(k_field_finalize, dim3(at.n_pad / kTile), dim3(kTile * kSlotGroups), 0, st, at, bx, polar_ewald, e_recip_part, part, n_split,
 	                   gamma, e_static, mu);
 }
 
@@ -410,19 +442,24 @@ void launch_dipole_iter_mf(hipStream_t st, const AtomsDev &at, const Box &bx, do
 }
 
 // contract_dipoles tail :3586-3593, calc_dipole_rrms :3147-3177, are_we_done_yet :3227-3236
-__global__ __launch_bounds__(256) void k_dipole_update(AtomsDev at, const double *__restrict__ e_static, const double *__restrict__ part,
+__global__ __launch_bounds__(512) void k_dipole_update(AtomsDev at, const double *__restrict__ e_static, const double *__restrict__ part,
                                                        int n_split, const double *__restrict__ mu_old, double *__restrict__ mu_new,
                                                        double *__restrict__ e_induced, int want_rrms, double *__restrict__ rrms_atom,
                                                        double allowed_sqerr, int *__restrict__ not_done_flag) {
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= at.n_pad) return;
-	const double a = at.alpha[i];
-	const bool live = (i < at.n) && (a != 0.0);
+	__shared__ double sh[kSlotGroups][kTile][3];
+	const int a = threadIdx.x & 63, g = threadIdx.x >> 6;
+	const int i = blockIdx.x * kTile + a;
+	double fsum[3];
+	slot_sum_64(part, n_split, at.n_pad, i, a, g, sh, fsum);
+	if (g != 0) return;
+	const double al = at.alpha[i];
+	const bool live = (i < at.n) && (al != 0.0);
 	double f[3] = {0, 0, 0}, nm[3] = {0, 0, 0};
 	if (live) {
-		for (int s = 0; s < n_split; ++s)
-			for (int p = 0; p < 3; ++p) f[p] += part[((size_t)s * at.n_pad + i) * 3 + p];
-		for (int p = 0; p < 3; ++p) nm[p] = a * (e_static[3 * (size_t)i + p] + f[p]);
+		for (int p = 0; p < 3; ++p) {
+			f[p] = fsum[p];
+			nm[p] = al * (e_static[3 * (size_t)i + p] + f[p]);
+		}
 	}
 	bool broke = false;
 	double acc = 0, nn = 0;
@@ -471,8 +508,8 @@ __global__ __launch_bounds__(256) void k_polar_energy(AtomsDev at, const double 
 
 void launch_dipole_update(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, int n_split, const double *mu_old,
                           double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr, int *not_done_flag) {
-	hipLaunchKernelGGL(k_dipole_update, dim3((at.n_pad + 255) / 256), dim3(256), 0, st, at, e_static, part, n_split, mu_old, mu_new, e_induced,
-	                   want_rrms, rrms_atom, allowed_sqerr, not_done_flag);
+	hipLaunchKernelGGL(k_dipole_update, dim3(at.n_pad / kTile), dim3(kTile * kSlotGroups), 0, st, at, e_static, part, n_split, mu_old, mu_new,
+	                   e_induced, want_rrms, rrms_atom, allowed_sqerr, not_done_flag);
 }
 void launch_dipole_reset(hipStream_t st, const AtomsDev &at, const double *e_static, double *mu) {
 	hipLaunchKernelGGL(k_dipole_reset, dim3((at.n_pad + 255) / 256), dim3(256), 0, st, at, e_static, mu);

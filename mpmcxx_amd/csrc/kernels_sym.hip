@@ -1,0 +1,461 @@
+// kernels_sym.hip -- the symmetric ("each unordered pair once") gfx950 kernels of the production path.
+//
+//   k_pair_fused          ONE pass over all N(N-1)/2 pairs does everything position dependent that is pairwise:
+//                         lj() + pair LRC, coulombic_real() (erfc and intramolecular erf term), the real-space / no-PBC
+//                         static field (real_term / thole_field_nopbc, both atoms of the pair), the in-cutoff pair
+//                         counts, and the Thole tensor store (a = d1/r^3, b = 3 d2/r^5 per pair, 16 B) that the
+//                         dipole iterations stream afterwards.
+//   k_dipole_iter_compact one Jacobi contraction  F = -(A - diag) mu  streaming that store: 16 B per unordered pair,
+//                         each pair's tensor applied to both of its atoms.  HBM-bound by construction.
+//
+// Wave-level schedule (both kernels): one wavefront per (I <= J) tile pair of 64 x 64 atoms.  Lane l owns i-atom
+// I*64+l in registers.  The j-atoms sit in LDS; at step s lane l pairs with j = (l + s) & 63, so the 64 lanes touch 64
+// DIFFERENT j-atoms in every step: the per-atom vector accumulators of the j-side travel in registers and are
+// rotated by one lane per step (v_mov_b32_dpp wave_rol:1), never reduced across lanes and never sent through
+// atomics.  Diagonal tiles use s = 1..32 (s = 32: lanes 0..31 only) which enumerates each pair once.
+// Per-atom partial results go to slot [source tile][atom] of a partial buffer that is completely overwritten by
+// every launch and summed in tile order by the follow-up kernel => bit-reproducible.
+#include <algorithm>
+#include <cstdlib>
+
+#include "erfcx_coeffs.h"
+#include "kernels.h"
+
+namespace mpmc {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	return v;
+}
+
+// lane l receives the value held by lane (l+1) & 63
+template <bool DPP>
+__device__ __forceinline__ double rot_from_next(double v, int src_lane_x4) {
+	int lo = __double2loint(v), hi = __double2hiint(v);
+	if (DPP) {
+		lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+		hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
+	} else {
+		lo = __builtin_amdgcn_ds_bpermute(src_lane_x4, lo);
+		hi = __builtin_amdgcn_ds_bpermute(src_lane_x4, hi);
+	}
+	return __hiloint2double(hi, lo);
+}
+
+// the tensor store is read exactly once per launch: stream it past the caches (global_load ... nt).
+// Measured on MI355X (10k atoms): 0.159 ms vs 0.170 ms per launch with default-policy loads.
+template <bool NT>
+__device__ __forceinline__ double2 ld_stream(const double2 *p) {
+	if (NT) {
+		double2 v;
+		v.x = __builtin_nontemporal_load(&p->x);
+		v.y = __builtin_nontemporal_load(&p->y);
+		return v;
+	}
+	return *p;
+}
+
+// first step of an off-diagonal tile walk: 16 different chunk offsets spread over consecutive blocks
+__device__ __forceinline__ int stagger_start(int block) { return ((block * 5) & 15) * 4; }
+
+// self-test of the rotation primitive: out[l] = lane id received by lane l (expected (l+1)&63)
+__global__ void k_rot_selftest(int *out_dpp, int *out_perm) {
+	const int lane = threadIdx.x;
+	const int src4 = ((lane + 1) & 63) * 4;
+	out_dpp[lane] = (int)rot_from_next<true>((double)lane, src4);
+	out_perm[lane] = (int)rot_from_next<false>((double)lane, src4);
+}
+void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm) {
+	hipLaunchKernelGGL(k_rot_selftest, dim3(1), dim3(64), 0, st, out_dpp, out_perm);
+}
+
+// erfc(x) = exp(-x^2) * erfcx(x) for every x >= 0; (1+2x) erfcx(x) is the degree-20 polynomial of tools/fit_erfcx.py in
+// t = (x-K)/(x+K) (rel. err < 1e-14), so there is no range branch and no libm erfc/erf in the kernel.
+// Also returns e = exp(-x^2), which the Ewald field term needs anyway.
+__device__ __forceinline__ double erfc_and_gauss(double x, double &e) {
+	e = exp(-x * x);
+	constexpr double c[MPMC_ERFCX_DEG + 1] = {MPMC_ERFCX_COEFFS};
+	const double d1 = x + MPMC_ERFCX_K, d2 = fma(2.0, x, 1.0);
+	const double den = d1 * d2;
+	double inv = __builtin_amdgcn_rcp(den);
+	inv = fma(fma(-den, inv, 1.0), inv, inv);
+	inv = fma(fma(-den, inv, 1.0), inv, inv);
+	const double t = (x - MPMC_ERFCX_K) * (d2 * inv); // (x-K)/(x+K)
+	double p = c[MPMC_ERFCX_DEG];
+#pragma unroll
+	for (int k = MPMC_ERFCX_DEG - 1; k >= 0; --k) p = fma(p, t, c[k]);
+	return e * (p * (d1 * inv)); // p / (1+2x)
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fused symmetric pair kernel
+//   ES    : electrostatics on (coulombic_real)
+//   FIELD : 0 none, 1 Ewald real_term (:2900-2940), 2 thole_field_nopbc (:3300-3333)
+//   THOLE : write the (a,b) tensor store
+// ------------------------------------------------------------------------------------------------------
+template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP>
+__global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedParams fp, const int2 *__restrict__ tile_pairs,
+                                                   double *__restrict__ block_part, int *__restrict__ block_cnt,
+                                                   double *__restrict__ fpart /*[nt][n_pad][3]*/, double2 *__restrict__ ab) {
+	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_q[kTile], s_sig[kTile], s_sqe[kTile];
+	__shared__ int s_mol[kTile], s_fl[kTile];
+	__shared__ double s_g[3 * kTile];
+
+	const int lane = threadIdx.x;
+	const int2 IJ = tile_pairs[blockIdx.x];
+	const bool diag = (IJ.x == IJ.y);
+	const int i = IJ.x * kTile + lane;
+	const int j0 = IJ.y * kTile;
+	const int src4 = ((lane + 1) & 63) * 4;
+
+	const double4 pi = at.xyzq[i];
+	const double2 li = at.lj[i];
+	const int2 mi = at.mf[i];
+	{
+		const double4 pj = at.xyzq[j0 + lane];
+		const double2 lj = at.lj[j0 + lane];
+		const int2 mj = at.mf[j0 + lane];
+		s_x[lane] = pj.x;
+		s_y[lane] = pj.y;
+		s_z[lane] = pj.z;
+		s_q[lane] = pj.w;
+		s_sig[lane] = lj.x;
+		s_sqe[lane] = lj.y;
+		s_mol[lane] = mj.x;
+		s_fl[lane] = mj.y;
+	}
+	__syncthreads();
+
+	const bool i_real = !(mi.y & AF_PAD);
+	const double rc = bx.cutoff;
+	const bool same_alpha = (fp.polar_ewald_alpha == fp.ewald_alpha);
+	const double lam = fp.polar_damp, lam2 = lam * lam, lam3 = lam2 * lam;
+	double e_lj = 0, e_lrc = 0, e_re = 0, e_in = 0;
+	int n_lj = 0, n_es = 0, n_intra = 0, n_rdx = 0, n_esx = 0, n_fr = 0;
+	double eix = 0, eiy = 0, eiz = 0; // field on my i-atom
+	double gx = 0, gy = 0, gz = 0;    // field on the j-atom currently paired with this lane (rotates)
+
+	// step order: diagonal tiles s = 1..32; off-diagonal tiles walk all 64 steps starting at a per-block offset
+	// (multiple of 4) so that concurrently running waves do not hit the same HBM channels in lock step
+	const int s_first = diag ? 1 : stagger_start(blockIdx.x), n_steps = diag ? 32 : 64;
+	double2 *ab_tile = THOLE ? ab + (size_t)blockIdx.x * (kTile * kTile) : nullptr;
+
+	for (int k = 0; k < n_steps; ++k) {
+		const int s = diag ? (s_first + k) : ((s_first + k) & 63);
+		const bool last = (k == n_steps - 1);
+		const int jl = (lane + s) & 63;
+		const int flj = s_fl[jl];
+		const bool act = i_real && !(flj & AF_PAD) && (!diag || s < 32 || lane < 32);
+		double ta = 0.0, tb = 0.0;
+		if (act) {
+			const int molj = s_mol[jl];
+			const PairFlags f = pair_flags(mi.x, mi.y, molj, flj);
+			n_intra += f.intra;
+			n_rdx += f.rd_excluded;
+			n_esx += f.es_excluded;
+			n_fr += f.frozen;
+			const double qj = s_q[jl];
+			const double dx = pi.x - s_x[jl], dy = pi.y - s_y[jl], dz = pi.z - s_z[jl];
+			double ox, oy, oz;
+			const double ri2 = min_image_sq<ORTHO>(bx, dx, dy, dz, ox, oy, oz);
+			const double ir = fast_rsqrt(ri2); // 1/rimg   (inf/NaN when ri2 == 0: coincident atoms => non-finite energy, as in the reference)
+			const double r = ri2 * ir;
+			const bool in_lj = (ri2 <= bx.t_lj); // rimg - 1e-12 < rc
+			const bool in_es = (ri2 <= bx.t_es); // !(rimg > rc)
+
+			if (THOLE) { // thole_amatrix couples every pair: no cutoff, no exclusions, frozen included (:2694-2767)
+				double ir3, ir5;
+				if (ri2 == 0.0) {
+					ir3 = ir5 = kMaxValue;
+				} else {
+					ir3 = ir * ir * ir;
+					ir5 = ir3 * ir * ir;
+				}
+				const double rr = (ri2 == 0.0) ? 0.0 : r;
+				const double explr = exp(-lam * rr);
+				const double damp1 = 1.0 - explr * (0.5 * lam2 * ri2 + lam * rr + 1.0);
+				const double damp2 = damp1 - explr * (lam3 * ri2 * rr / 6.0);
+				ta = damp1 * ir3;
+				tb = 3.0 * damp2 * ir5;
+			}
+
+			if (!f.frozen) {
+				double sig, eps;
+				lj_mix(mi.y, flj, li.x, li.y, s_sig[jl], s_sqe[jl], sig, eps);
+				if (fp.rd_lrc && eps != 0.0 && sig != 0.0) e_lrc += lrc_term(sig, eps, rc, bx.volume);
+				if (in_lj && !f.rd_excluded) {
+					const double sr = sig * ir;
+					double s6 = sr * sr * sr;
+					s6 *= s6;
+					const double t12 = f.attractive_only ? 0.0 : s6 * s6;
+					e_lj += 4.0 * eps * (t12 - s6);
+					n_lj++;
+				}
+				if (ES) {
+					const double qq = pi.w * qj;
+					double erfc_a = 0.0, gauss_a = 0.0;
+					const bool es_pair = in_es && !f.es_excluded;
+					const bool fld_pair = (FIELD == 1) && in_es && (ri2 != 0.0) && !(pi.w == 0.0 && qj == 0.0);
+					if (es_pair || (fld_pair && same_alpha && !f.es_excluded)) erfc_a = erfc_and_gauss(fp.ewald_alpha * r, gauss_a);
+					if (es_pair) {
+						e_re += qq * erfc_a * ir;
+						n_es++;
+					} else if (f.es_excluded && qq != 0.0) { // charge-to-screen term, plain (non-image) distance (:1503-1504)
+						const double r02 = ((dx * dx) + dy * dy) + dz * dz;
+						const double ir0 = fast_rsqrt(r02);
+						double g0;
+						e_in += qq * (1.0 - erfc_and_gauss(fp.ewald_alpha * (r02 * ir0), g0)) * ir0; // erf = 1 - erfc
+					}
+					if (FIELD == 1 && fld_pair) { // real_term :2916-2934
+						const double ap = fp.polar_ewald_alpha;
+						double fac;
+						if (f.es_excluded) { // erf form (:2921); erf = 1 - erfc from the same polynomial
+							double ga;
+							const double ec = erfc_and_gauss(ap * r, ga);
+							fac = (2.0 * ap * kOneOverSqrtPi * ga * r - (1.0 - ec)) * (ir * ir * ir);
+						} else {
+							double ec = erfc_a, ga = gauss_a;
+							if (!same_alpha) ec = erfc_and_gauss(ap * r, ga);
+							fac = (2.0 * ap * kOneOverSqrtPi * ga * r + ec) * (ir * ir * ir);
+						}
+						const double fj = fac * qj, fi = fac * pi.w;
+						eix += fj * ox;
+						eiy += fj * oy;
+						eiz += fj * oz;
+						gx -= fi * ox;
+						gy -= fi * oy;
+						gz -= fi * oz;
+					}
+					if (FIELD == 2 && !f.intra && in_lj && ri2 != 0.0) { // thole_field_nopbc :3311-3326
+						const double ir3 = ir * ir * ir;
+						const double fj = qj * ir3, fi = pi.w * ir3;
+						eix += fj * ox;
+						eiy += fj * oy;
+						eiz += fj * oz;
+						gx -= fi * ox;
+						gy -= fi * oy;
+						gz -= fi * oz;
+					}
+				}
+			}
+		}
+		if (THOLE) ab_tile[s * kTile + lane] = make_double2(ta, tb);
+		if (FIELD != 0 && !last) {
+			gx = rot_from_next<DPP>(gx, src4);
+			gy = rot_from_next<DPP>(gy, src4);
+			gz = rot_from_next<DPP>(gz, src4);
+		}
+	}
+
+	if (FIELD != 0) {
+		const int jl_last = (lane + s_first + n_steps - 1) & 63; // the j-atom whose accumulator this lane ended up holding
+		const int nt_pad3 = at.n_pad * 3;
+		if (diag) { // both sides belong to the same 64 atoms: fold through LDS, one slot [I][I-atoms]
+			s_g[3 * jl_last + 0] = gx;
+			s_g[3 * jl_last + 1] = gy;
+			s_g[3 * jl_last + 2] = gz;
+			__syncthreads();
+			double *o = fpart + (size_t)IJ.x * nt_pad3 + 3 * (size_t)i;
+			o[0] = eix + s_g[3 * lane + 0];
+			o[1] = eiy + s_g[3 * lane + 1];
+			o[2] = eiz + s_g[3 * lane + 2];
+		} else {
+			double *oi = fpart + (size_t)IJ.y * nt_pad3 + 3 * (size_t)i; // i-atoms, contribution of tile J
+			oi[0] = eix;
+			oi[1] = eiy;
+			oi[2] = eiz;
+			double *oj = fpart + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + jl_last); // j-atoms, contribution of tile I
+			oj[0] = gx;
+			oj[1] = gy;
+			oj[2] = gz;
+		}
+	}
+
+	e_lj = wave_sum(e_lj);
+	e_lrc = wave_sum(e_lrc);
+	e_re = wave_sum(e_re);
+	e_in = wave_sum(e_in);
+	n_lj = wave_sum_i(n_lj);
+	n_es = wave_sum_i(n_es);
+	n_intra = wave_sum_i(n_intra);
+	n_rdx = wave_sum_i(n_rdx);
+	n_esx = wave_sum_i(n_esx);
+	n_fr = wave_sum_i(n_fr);
+	if (lane == 0) {
+		double *bp = block_part + 4 * (size_t)blockIdx.x;
+		bp[0] = e_lj;
+		bp[1] = e_lrc;
+		bp[2] = e_re;
+		bp[3] = e_in;
+		int *bc = block_cnt + 6 * (size_t)blockIdx.x;
+		bc[0] = n_lj;
+		bc[1] = n_es;
+		bc[2] = n_intra;
+		bc[3] = n_rdx;
+		bc[4] = n_esx;
+		bc[5] = n_fr;
+	}
+}
+
+template <bool ORTHO, bool ES, int FIELD, bool THOLE>
+static void launch_fused_t(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, int ntp,
+                           double *bpart, int *bcnt, double *fpart, double2 *ab) {
+	if (dpp)
+		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, bpart, bcnt, fpart, ab);
+	else
+		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, bpart, bcnt, fpart, ab);
+}
+
+template <bool ORTHO>
+static void launch_fused_o(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, int ntp,
+                           double *bpart, int *bcnt, double *fpart, double2 *ab) {
+	const bool thole = fp.do_thole && ab;
+	if (!fp.do_es)
+		launch_fused_t<ORTHO, false, 0, false>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
+	else if (fp.do_field == 0)
+		launch_fused_t<ORTHO, true, 0, false>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
+	else if (fp.do_field == 1) {
+		if (thole) launch_fused_t<ORTHO, true, 1, true>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
+		else launch_fused_t<ORTHO, true, 1, false>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
+	} else {
+		if (thole) launch_fused_t<ORTHO, true, 2, true>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
+		else launch_fused_t<ORTHO, true, 2, false>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
+	}
+}
+
+void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
+                       int n_tile_pairs, double *block_part, int *block_cnt, double *fpart, double2 *ab) {
+	if (bx.ortho) launch_fused_o<true>(st, dpp, at, bx, fp, tile_pairs, n_tile_pairs, block_part, block_cnt, fpart, ab);
+	else launch_fused_o<false>(st, dpp, at, bx, fp, tile_pairs, n_tile_pairs, block_part, block_cnt, fpart, ab);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Jacobi contraction streaming the compact tensor store (reference contract_dipoles :3564-3598 over the A matrix of
+// thole_amatrix :2661-2770):  for the pair (i,j):  F_i -= a mu_j - b d (d.mu_j),   F_j -= a mu_i - b d (d.mu_i)
+// Entries of masked pairs were stored as (0,0), so the loop carries no predicates at all.
+// ------------------------------------------------------------------------------------------------------
+template <bool ORTHO, bool DPP>
+__global__ __launch_bounds__(64) void k_dipole_iter_compact(AtomsDev at, Box bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
+                                                            int n_tile_pairs, const double2 *__restrict__ ab,
+                                                            double *__restrict__ part /*[nt][n_pad][3]*/) {
+	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_mx[kTile], s_my[kTile], s_mz[kTile];
+	__shared__ double s_g[3 * kTile];
+	const int lane = threadIdx.x;
+	// one tile pair per block, or (persistent launch, gridDim < n_tile_pairs) a strided walk over them
+	for (int tp = blockIdx.x; tp < n_tile_pairs; tp += gridDim.x) {
+	__syncthreads(); // the previous tile pair's LDS reads are done before its image is overwritten
+	const int2 IJ = tile_pairs[tp];
+	const bool diag = (IJ.x == IJ.y);
+	const int i = IJ.x * kTile + lane;
+	const int j0 = IJ.y * kTile;
+	const int src4 = ((lane + 1) & 63) * 4;
+
+	const double4 pi = at.xyzq[i];
+	const double mix = mu[3 * (size_t)i], miy = mu[3 * (size_t)i + 1], miz = mu[3 * (size_t)i + 2];
+	{
+		const double4 pj = at.xyzq[j0 + lane];
+		s_x[lane] = pj.x;
+		s_y[lane] = pj.y;
+		s_z[lane] = pj.z;
+		s_mx[lane] = mu[3 * (size_t)(j0 + lane)];
+		s_my[lane] = mu[3 * (size_t)(j0 + lane) + 1];
+		s_mz[lane] = mu[3 * (size_t)(j0 + lane) + 2];
+	}
+	__syncthreads();
+
+	const double2 *__restrict__ abt = ab + (size_t)tp * (kTile * kTile) + lane;
+	double fx = 0, fy = 0, fz = 0, gx = 0, gy = 0, gz = 0;
+	// 64 steps (off-diagonal, staggered start) or 32 steps (diagonal, s = 1..32): always whole chunks of 4
+	const int s_first = diag ? 1 : stagger_start(tp), n_steps = diag ? 32 : 64;
+	// software pipeline: the (a,b) of the NEXT 4 steps are in flight while the current 4 are applied
+	double2 cur[4], nxt[4];
+#pragma unroll
+	for (int u = 0; u < 4; ++u) cur[u] = ld_stream<true>(abt + (diag ? (s_first + u) : ((s_first + u) & 63)) * kTile);
+	for (int kc = 0; kc < n_steps; kc += 4) {
+		const bool more = (kc + 4 < n_steps);
+		if (more) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int sn = diag ? (s_first + kc + 4 + u) : ((s_first + kc + 4 + u) & 63);
+				nxt[u] = ld_stream<true>(abt + sn * kTile);
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int s = diag ? (s_first + kc + u) : ((s_first + kc + u) & 63);
+			const int jl = (lane + s) & 63;
+			const double2 t = cur[u];
+			// displacement as VALUES only (no predicate here): the image index is the reference's rint(R d), the
+			// back-projection may be fused
+			const double dx = pi.x - s_x[jl], dy = pi.y - s_y[jl], dz = pi.z - s_z[jl];
+			double ox, oy, oz;
+			if (ORTHO) {
+				ox = fma(-bx.b[0], rint(bx.r[0] * dx), dx);
+				oy = fma(-bx.b[4], rint(bx.r[4] * dy), dy);
+				oz = fma(-bx.b[8], rint(bx.r[8] * dz), dz);
+			} else {
+				(void)min_image_sq<false>(bx, dx, dy, dz, ox, oy, oz);
+			}
+			const double mjx = s_mx[jl], mjy = s_my[jl], mjz = s_mz[jl];
+			const double dj = t.y * fma(oz, mjz, fma(oy, mjy, ox * mjx));
+			const double di = t.y * fma(oz, miz, fma(oy, miy, ox * mix));
+			fx = fma(-t.x, mjx, fma(dj, ox, fx));
+			fy = fma(-t.x, mjy, fma(dj, oy, fy));
+			fz = fma(-t.x, mjz, fma(dj, oz, fz));
+			gx = fma(-t.x, mix, fma(di, ox, gx));
+			gy = fma(-t.x, miy, fma(di, oy, gy));
+			gz = fma(-t.x, miz, fma(di, oz, gz));
+			if (kc + u != n_steps - 1) {
+				gx = rot_from_next<DPP>(gx, src4);
+				gy = rot_from_next<DPP>(gy, src4);
+				gz = rot_from_next<DPP>(gz, src4);
+			}
+		}
+		if (more) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+		}
+	}
+	const int jl_last = (lane + s_first + n_steps - 1) & 63;
+	const int nt_pad3 = at.n_pad * 3;
+	if (diag) {
+		s_g[3 * jl_last + 0] = gx;
+		s_g[3 * jl_last + 1] = gy;
+		s_g[3 * jl_last + 2] = gz;
+		__syncthreads();
+		double *o = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)i;
+		o[0] = fx + s_g[3 * lane + 0];
+		o[1] = fy + s_g[3 * lane + 1];
+		o[2] = fz + s_g[3 * lane + 2];
+	} else {
+		double *oi = part + (size_t)IJ.y * nt_pad3 + 3 * (size_t)i;
+		oi[0] = fx;
+		oi[1] = fy;
+		oi[2] = fz;
+		double *oj = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + jl_last);
+		oj[0] = gx;
+		oj[1] = gy;
+		oj[2] = gz;
+	}
+	} // tile pairs
+}
+
+void launch_dipole_iter_compact(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+                                int n_tile_pairs, const double2 *ab, double *part) {
+	dim3 grid(n_tile_pairs), block(kTile);
+	if (bx.ortho) {
+		if (dpp) hipLaunchKernelGGL((k_dipole_iter_compact<true, true>), grid, block, 0, st, at, bx, mu, tile_pairs, n_tile_pairs, ab, part);
+		else hipLaunchKernelGGL((k_dipole_iter_compact<true, false>), grid, block, 0, st, at, bx, mu, tile_pairs, n_tile_pairs, ab, part);
+	} else {
+		if (dpp) hipLaunchKernelGGL((k_dipole_iter_compact<false, true>), grid, block, 0, st, at, bx, mu, tile_pairs, n_tile_pairs, ab, part);
+		else hipLaunchKernelGGL((k_dipole_iter_compact<false, false>), grid, block, 0, st, at, bx, mu, tile_pairs, n_tile_pairs, ab, part);
+	}
+}
+
+} // namespace mpmc

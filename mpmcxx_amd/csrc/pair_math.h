@@ -45,6 +45,11 @@ struct Box {
 	double b[9];   // pbc.basis[q][p]           row-major
 	double r[9];   // pbc.reciprocal_basis[q][p] row-major
 	double volume, cutoff;
+	// squared-distance forms of the reference's cutoff predicates, found on the host by bisection over doubles
+	// with a correctly rounded sqrt, so the device never needs an exactly rounded sqrt to decide inclusion:
+	//   ri2 <= t_lj   <=>   sqrt(ri2) - 1e-12 < cutoff      (lj :934, thole_field_nopbc :3319)
+	//   ri2 <= t_es   <=>   !(sqrt(ri2) > cutoff)           (coulombic_real :1490, real_term :2917)
+	double t_lj, t_es;
 	int ortho;     // 1 when basis (and therefore reciprocal) is diagonal
 };
 
@@ -80,6 +85,45 @@ MPMC_HD double min_image(const Box &bx, double dx, double dy, double dz, double 
 	}
 	ox = ex; oy = ey; oz = ez;
 	return ri;
+}
+
+// same displacement, squared length only (no sqrt): the inclusion predicates are applied on ri2 (Box::t_lj/t_es)
+template <bool ORTHO>
+MPMC_HD double min_image_sq(const Box &bx, double dx, double dy, double dz, double &ox, double &oy, double &oz) {
+	double ix, iy, iz, tx, ty, tz;
+	if (ORTHO) {
+		ix = rint(bx.r[0] * dx);
+		iy = rint(bx.r[4] * dy);
+		iz = rint(bx.r[8] * dz);
+		tx = bx.b[0] * ix;
+		ty = bx.b[4] * iy;
+		tz = bx.b[8] * iz;
+	} else {
+		ix = rint(((bx.r[0] * dx) + bx.r[3] * dy) + bx.r[6] * dz);
+		iy = rint(((bx.r[1] * dx) + bx.r[4] * dy) + bx.r[7] * dz);
+		iz = rint(((bx.r[2] * dx) + bx.r[5] * dy) + bx.r[8] * dz);
+		tx = ((bx.b[0] * ix) + bx.b[3] * iy) + bx.b[6] * iz;
+		ty = ((bx.b[1] * ix) + bx.b[4] * iy) + bx.b[7] * iz;
+		tz = ((bx.b[2] * ix) + bx.b[5] * iy) + bx.b[8] * iz;
+	}
+	ox = dx - tx;
+	oy = dy - ty;
+	oz = dz - tz;
+	return ((ox * ox) + oy * oy) + oz * oz;
+}
+
+// 1/sqrt(x) to ~1 ulp: hardware seed (v_rsq_f64, ~2^-23) + two Newton steps.  Values only, never predicates.
+MPMC_HD double fast_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	double y = __builtin_amdgcn_rsq(x);
+	double e = fma(-(x * y), y, 1.0);
+	y = fma(0.5 * y, e, y);
+	e = fma(-(x * y), y, 1.0);
+	y = fma(0.5 * y, e, y);
+	return y;
+#else
+	return 1.0 / sqrt(x);
+#endif
 }
 
 // ---- pair_exclusions, reference System.cpp:1035-1197 (Lorentz-Berthelot branch) --------------------------
