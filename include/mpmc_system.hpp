@@ -1,0 +1,315 @@
+// include/mpmc_system.hpp -- C++ host facade over the C ABI (include/mpmc_energy.h).
+//
+// The reference is compiled C++ whose energy path is a set of `System` member functions; this header gives host
+// C++ code the same surface -- same member names, argument meaning, side effects and error behaviour -- so that a
+// Monte Carlo accept/reject loop written against the reference's `System` reads the same against this one:
+//
+//   reference (src/System.h)                         here (namespace mpmc)
+//   -----------------------------------------------  ---------------------------------------------------------
+//   double System::energy()               :315        double System::energy()
+//   lj / coulombic / coulombic_real / _reciprocal /   same names, same return values
+//     _self / polar / thole_field         :346-402
+//   observables_t *observables            :94-113     observables_t *observables (same field names)
+//   nodestats->polarization_iterations    :151-185    nodestats->polarization_iterations
+//   int iterator_failed                   :680        int iterator_failed
+//   PeriodicBoundary pbc (+ update_pbc)               PeriodicBoundary pbc, update_pbc()
+//   option fields rd_only, rd_lrc, polarization, polar_* , ewald_* (:510-831)   same names
+//   errors: `throw <int>` (src/constants.h:108-147)   `throw <int>` with the same codes
+//   SimulationControl::PI_calculate_potential()       PathIntegralEnsemble::PI_calculate_potential()
+//     (src/SimulationControl.PathIntegral.cpp:752)
+//
+// Data model: flat vectors instead of Molecule -> Atom linked lists (the flattening is what the adapter of
+// INTEGRATION.md does for the real reference objects).  Header-only; link with -lmpmc_energy.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "mpmc_energy.h"
+
+namespace mpmc {
+
+enum { DAMPING_OFF = 0, DAMPING_LINEAR = 1, DAMPING_EXPONENTIAL = 2 }; // reference constants.h:66-70
+
+// reference src/PeriodicBoundary.h
+class PeriodicBoundary {
+public:
+	double cutoff = 0, volume = 0;
+	double basis[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+	double reciprocal_basis[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+	void update() { // PeriodicBoundary::update, src/PeriodicBoundary.cpp:31-35
+		int rc = mpmc_pbc_compute(&basis[0][0], &reciprocal_basis[0][0], &volume, &cutoff);
+		if (rc != MPMC_OK) throw (int)MPMC_ERR_BOX;
+	}
+};
+
+// reference src/System.h:94-113
+struct observables_t {
+	double energy = 0, coulombic_energy = 0, rd_energy = 0, polarization_energy = 0, vdw_energy = 0, three_body_energy = 0,
+	       dipole_rrms = 0, kinetic_energy = 0, temperature = 0, volume = 0, N = 0, NU = 0, spin_ratio = 0, frozen_mass = 0, total_mass = 0;
+	double potential() const { return coulombic_energy + rd_energy + polarization_energy + vdw_energy + three_body_energy; }
+};
+struct nodestats_t {
+	double polarization_iterations = 0;
+};
+
+// one row of the flattened atom list (reference src/Atom.h:21-56, the fields the path reads / writes)
+struct Atom {
+	double pos[3] = {0, 0, 0};
+	double mass = 0, charge = 0, polarizability = 0, epsilon = 0, sigma = 0;
+	double c6 = 0, c8 = 0, c10 = 0;
+	int frozen = 0;
+	int molecule = 0; // index of the owning molecule (consecutive atoms with equal index form one Molecule)
+	// written by energy():
+	double mu[3] = {0, 0, 0}, ef_static[3] = {0, 0, 0}, ef_induced[3] = {0, 0, 0};
+};
+
+class System {
+public:
+	// ---- options, reference names and defaults (src/System.h:510-831) ----
+	int rd_only = 0, rd_lrc = 1;
+	int polarization = 0, polar_iterative = 0, polar_ewald = 0, polar_max_iter = 10, polar_gs = 0, polar_rrms = 0;
+	int damp_type = DAMPING_EXPONENTIAL;
+	int ewald_kmax = 7;
+	double polar_precision = 0, polar_gamma = 1.0, polar_damp = 0;
+	double ewald_alpha = 0.5, polar_ewald_alpha = 0.5;
+	int ewald_alpha_set = 0, polar_ewald_alpha_set = 0;
+	uint64_t unsupported_flags = 0; // MPMC_FLAG_*: reference switches outside the hot path that are ON
+	int solver = MPMC_SOLVER_AUTO;
+	int device = 0;
+
+	// ---- state ----
+	PeriodicBoundary pbc;
+	std::vector<Atom> atoms;
+	int natoms = 0;
+	int iterator_failed = 0;
+	double last_volume = 0;
+	observables_t *observables = &obs_;
+	nodestats_t *nodestats = &stats_;
+	mpmc_result last_result{};
+
+	System() = default;
+	System(const System &) = delete;
+	System &operator=(const System &) = delete;
+	~System() {
+		if (ctx_) mpmc_ctx_destroy(ctx_);
+	}
+
+	// System::update_pbc, src/System.cpp:859-876
+	void update_pbc() {
+		pbc.update();
+		if (ewald_alpha_set != 1) ewald_alpha = 3.5 / pbc.cutoff;
+		if (polar_ewald_alpha_set != 1) polar_ewald_alpha = 3.5 / pbc.cutoff;
+		box_dirty_ = true;
+	}
+	int countNatoms() const { return (int)atoms.size(); }
+
+	// call after changing atom parameters or the number of atoms (positions alone: move_atoms)
+	void atoms_changed() { atoms_dirty_ = true; }
+	// after a Monte Carlo move that displaced atoms [first, first+count)
+	void move_atoms(int first, int count) {
+		if (atoms_dirty_ || !ctx_) return; // a full upload is pending anyway
+		std::vector<double> p(3 * (size_t)count);
+		for (int k = 0; k < count; k++)
+			for (int d = 0; d < 3; d++) p[3 * k + d] = atoms[first + k].pos[d];
+		check(mpmc_update_positions(ctx_, first, count, p.data()), "mpmc_update_positions");
+	}
+
+	// ---- double System::energy(), src/System.Energy.cpp:19-171 ----
+	double energy() {
+		sync_state();
+		mpmc_result r;
+		check(mpmc_energy(ctx_, &r), "mpmc_energy");
+		absorb(r);
+		return r.energy;
+	}
+	void energy_async() {
+		sync_state();
+		check(mpmc_energy_async(ctx_), "mpmc_energy_async");
+	}
+	double energy_wait() {
+		mpmc_result r;
+		check(mpmc_energy_wait(ctx_, &r), "mpmc_energy_wait");
+		absorb(r);
+		return r.energy;
+	}
+
+	double lj() { return piece(mpmc_lj); }
+	double coulombic() { return piece(mpmc_coulombic); }
+	double coulombic_real() { return piece(mpmc_coulombic_real); }
+	double coulombic_reciprocal() { return piece(mpmc_coulombic_reciprocal); }
+	double coulombic_self() { return piece(mpmc_coulombic_self); }
+	double polar() {
+		double v = piece(mpmc_polar);
+		fetch_dipoles();
+		return v;
+	}
+	void thole_field() {
+		sync_state();
+		std::vector<double> e(3 * atoms.size());
+		check(mpmc_thole_field(ctx_, e.data()), "mpmc_thole_field");
+		for (size_t i = 0; i < atoms.size(); i++)
+			for (int p = 0; p < 3; p++) atoms[i].ef_static[p] = e[3 * i + p];
+	}
+	// rows [row0, row0+nrows) of the dense 3N x 3N matrix of System::thole_amatrix (row-major nrows x 3N)
+	std::vector<double> thole_amatrix(int row0, int nrows) {
+		sync_state();
+		std::vector<double> a((size_t)nrows * 3 * atoms.size());
+		check(mpmc_thole_amatrix(ctx_, row0, nrows, a.data()), "mpmc_thole_amatrix");
+		return a;
+	}
+
+	mpmc_ctx *context() {
+		sync_state();
+		return ctx_;
+	}
+
+private:
+	observables_t obs_;
+	nodestats_t stats_;
+	mpmc_ctx *ctx_ = nullptr;
+	int capacity_ = 0;
+	bool atoms_dirty_ = true, box_dirty_ = true;
+
+	void check(int rc, const char *what) {
+		if (rc == MPMC_OK) return;
+		last_error_ = std::string(what) + ": " + (ctx_ ? mpmc_last_error(ctx_) : mpmc_last_error(nullptr));
+		throw (rc > 0 ? rc : (int)MPMC_ERR_INTERNAL); // reference convention: throw <int>
+	}
+
+	void sync_state() {
+		natoms = countNatoms();
+		const int n = natoms;
+		if (!ctx_ || capacity_ < n) {
+			if (ctx_) mpmc_ctx_destroy(ctx_);
+			ctx_ = nullptr;
+			capacity_ = n + n / 4 + 64;
+			check(mpmc_ctx_create(device, capacity_, &ctx_), "mpmc_ctx_create");
+			atoms_dirty_ = box_dirty_ = true;
+		}
+		if (box_dirty_) {
+			check(mpmc_set_box(ctx_, &pbc.basis[0][0], &pbc.reciprocal_basis[0][0], pbc.volume, pbc.cutoff), "mpmc_set_box");
+			box_dirty_ = false;
+		}
+		mpmc_options o;
+		mpmc_default_options(&o);
+		o.rd_only = rd_only;
+		o.rd_lrc = rd_lrc;
+		o.polarization = polarization;
+		o.polar_iterative = polar_iterative;
+		o.polar_ewald = polar_ewald;
+		o.polar_max_iter = polar_max_iter;
+		o.polar_gs = polar_gs;
+		o.polar_rrms = polar_rrms;
+		o.damp_type = damp_type;
+		o.ewald_kmax = ewald_kmax;
+		o.solver = solver;
+		o.polar_precision = polar_precision;
+		o.polar_gamma = polar_gamma;
+		o.polar_damp = polar_damp;
+		o.ewald_alpha = ewald_alpha;
+		o.polar_ewald_alpha = polar_ewald_alpha;
+		o.unsupported_flags = unsupported_flags | ((polarization && !polar_iterative) ? MPMC_FLAG_POLAR_MATRIX_INVERSION : 0);
+		check(mpmc_set_options(ctx_, &o), "mpmc_set_options");
+		if (atoms_dirty_) {
+			std::vector<double> pos(3 * (size_t)n), q(n), al(n), ep(n), sg(n), ms(n);
+			std::vector<int32_t> mol(n), fr(n), dp(n);
+			for (int i = 0; i < n; i++) {
+				const Atom &a = atoms[i];
+				for (int p = 0; p < 3; p++) pos[3 * i + p] = a.pos[p];
+				q[i] = a.charge;
+				al[i] = a.polarizability;
+				ep[i] = a.epsilon;
+				sg[i] = a.sigma;
+				ms[i] = a.mass;
+				mol[i] = a.molecule;
+				fr[i] = a.frozen;
+				dp[i] = (a.c6 != 0.0 || a.c8 != 0.0 || a.c10 != 0.0) ? 1 : 0;
+			}
+			check(mpmc_set_atoms(ctx_, n, pos.data(), q.data(), al.data(), ep.data(), sg.data(), mol.data(), fr.data(), dp.data(), ms.data()),
+			      "mpmc_set_atoms");
+			atoms_dirty_ = false;
+		}
+	}
+
+	void fetch_dipoles() {
+		const size_t n = atoms.size();
+		std::vector<double> mu(3 * n), e0(3 * n), ei(3 * n);
+		check(mpmc_get_dipoles(ctx_, mu.data(), e0.data(), ei.data()), "mpmc_get_dipoles");
+		for (size_t i = 0; i < n; i++)
+			for (int p = 0; p < 3; p++) {
+				atoms[i].mu[p] = mu[3 * i + p];
+				atoms[i].ef_static[p] = e0[3 * i + p];
+				atoms[i].ef_induced[p] = ei[3 * i + p];
+			}
+	}
+
+	void absorb(const mpmc_result &r) {
+		last_result = r;
+		obs_.energy = r.energy;
+		obs_.coulombic_energy = r.coulombic_energy;
+		obs_.rd_energy = r.rd_energy;
+		obs_.polarization_energy = r.polarization_energy;
+		obs_.vdw_energy = r.vdw_energy;
+		obs_.three_body_energy = r.three_body_energy;
+		obs_.dipole_rrms = r.dipole_rrms;
+		obs_.N = r.N;
+		obs_.NU = r.NU;
+		stats_.polarization_iterations = (double)r.polar_iterations;
+		iterator_failed = r.iterator_failed;
+		last_volume = pbc.volume;
+		if (polarization && !rd_only) fetch_dipoles();
+	}
+
+	double piece(int (*fn)(mpmc_ctx *, double *)) {
+		sync_state();
+		double v = 0;
+		check(fn(ctx_, &v), "component");
+		return v;
+	}
+
+public:
+	std::string last_error_;
+};
+
+// SimulationControl's multi-System part for ensemble pi_nvt (src/SimulationControl.h:60, PathIntegral.cpp:752-805).
+// `systems` holds the beads owned by THIS process; `nSys` is the Trotter number P over all processes.
+// The cross-process exchange of 4 doubles per bead (MPI_Allgather x4 in the reference) is delegated to
+// `allgather`: it receives this process's per-bead values (n_local x 4, local order) and must return all P x 4
+// values in bead order.  With one process it may be left empty.
+class PathIntegralEnsemble {
+public:
+	std::vector<System *> systems;
+	int nSys = 0;
+	observables_t sys_observables; // the aggregate "sys.observables" of the reference
+	std::function<std::vector<double>(const std::vector<double> &)> allgather;
+
+	double PI_calculate_potential() {
+		const int n_local = (int)systems.size();
+		for (System *s : systems) s->energy_async(); // every bead enqueued on its own stream before the first wait
+		std::vector<double> mine(4 * (size_t)n_local);
+		for (int b = 0; b < n_local; b++) {
+			systems[b]->energy_wait();
+			const observables_t *o = systems[b]->observables;
+			mine[4 * b + 0] = o->rd_energy;
+			mine[4 * b + 1] = o->coulombic_energy;
+			mine[4 * b + 2] = o->polarization_energy;
+			mine[4 * b + 3] = o->vdw_energy;
+		}
+		const std::vector<double> all = allgather ? allgather(mine) : mine;
+		const int P = nSys ? nSys : n_local;
+		double acc[4] = {0, 0, 0, 0};
+		for (int s = 0; s < P; s++) // ordered sum, :791-796
+			for (int k = 0; k < 4; k++) acc[k] += all[4 * (size_t)s + k];
+		for (int k = 0; k < 4; k++) acc[k] /= P; // :798-801
+		sys_observables.rd_energy = acc[0];
+		sys_observables.coulombic_energy = acc[1];
+		sys_observables.polarization_energy = acc[2];
+		sys_observables.vdw_energy = acc[3];
+		return acc[0] + acc[1] + acc[3] + acc[2]; // :803-804
+	}
+};
+
+} // namespace mpmc
