@@ -583,3 +583,171 @@ double orc_pi_aggregate(int P, const double *rd, const double *es, const double 
 	for (int c = 0; c < 4; c++) o[c] /= P;
 	return o[0] + o[1] + o[3] + o[2]; /* rd + coulombic + vdw + polarization (:803-804) */
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * CPU-baseline timing on a BOUNDED SAMPLE of one evaluation (bench.py cpu_baseline leg only).
+ * Every O(N^2) stage of energy() is executed for the rows i = 0, stride, 2*stride, ... only, with exactly the
+ * per-pair arithmetic of the full functions above, timed, and scaled by that stage's exact work ratio
+ * (pairs in the full loop / pairs executed).  The O(K*N) reciprocal stages and the O(N) terms run in full.
+ * out_sec[0..6] = estimated seconds of one FULL evaluation per stage:
+ *   0 lj+lrc, 1 coulombic_real, 2 coulombic_reciprocal(+self), 3 thole_amatrix, 4 thole_field (recip+real),
+ *   5 thole_iterative (polar_max_iter dense contractions), 6 total.
+ * Returns the wall seconds actually spent.
+ * ------------------------------------------------------------------------------------------- */
+#include <time.h>
+static double now_sec(void) {
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+double orc_time_sample(const orc_system *s, int stride, double out_sec[7]) {
+	const int n = s->n;
+	const double t_begin = now_sec();
+	volatile double sink = 0;
+	double pairs_full = 0.5 * (double)n * (double)(n - 1), pairs_done = 0;
+	int rows = 0;
+	for (int i = 0; i < n; i += stride) {
+		pairs_done += (double)(n - 1 - i);
+		rows++;
+	}
+	if (pairs_done <= 0) pairs_done = 1;
+	const double tri_scale = pairs_full / pairs_done; /* triangular (i<j) loops */
+	const double row_scale = (double)n / (double)rows; /* full-row loops        */
+	for (int k = 0; k < 7; k++) out_sec[k] = 0;
+
+	/* 0: lj() rows */
+	double t0 = now_sec();
+	{
+		double potential = 0, cutoff = s->cutoff;
+		for (int i = 0; i < n; i += stride)
+			for (int j = i + 1; j < n; j++) {
+				pair_par pp;
+				double dimg[3], r;
+				pair_params(s, i, j, &pp);
+				double rimg = 0;
+				if (!pp.frozen || s->polarization) rimg = orc_minimum_image(s, i, j, dimg, &r);
+				double lrc = 0, rd = 0;
+				if (s->rd_lrc && pp.epsilon != 0 && pp.sigma != 0 && !pp.frozen) lrc = lrc_term(pp.sigma, pp.epsilon, cutoff, s->volume);
+				if ((rimg - ORC_SMALL_DR < cutoff) && !pp.rd_excluded && !pp.frozen) {
+					double sor = fabs(pp.sigma) / rimg;
+					double sor6 = sor * sor * sor;
+					sor6 *= sor6;
+					double sor12 = sor6 * sor6;
+					rd += 4.0 * pp.epsilon * ((pp.attractive_only ? 0 : sor12) - sor6);
+				}
+				potential += rd + lrc;
+			}
+		sink += potential;
+	}
+	out_sec[0] = (now_sec() - t0) * tri_scale;
+
+	if (!s->rd_only) {
+		/* 1: coulombic_real rows */
+		t0 = now_sec();
+		{
+			double alpha = s->ewald_alpha, potential = 0;
+			for (int i = 0; i < n; i += stride)
+				for (int j = i + 1; j < n; j++) {
+					pair_par pp;
+					double dimg[3], rr = 0;
+					pair_params(s, i, j, &pp);
+					double es_real = 0, es_self_intra = 0;
+					if (!pp.frozen) {
+						double r = orc_minimum_image(s, i, j, dimg, &rr);
+						if (!((r > s->cutoff) || pp.es_excluded)) es_real = s->charge[i] * s->charge[j] * erfc(alpha * r) / r;
+						else if (pp.es_excluded) es_self_intra = s->charge[i] * s->charge[j] * erf(alpha * rr) / rr;
+					}
+					potential += es_real - es_self_intra;
+				}
+			sink += potential;
+		}
+		out_sec[1] = (now_sec() - t0) * tri_scale;
+
+		/* 2: reciprocal + self, in full */
+		t0 = now_sec();
+		sink += orc_coulombic_reciprocal(s) + orc_coulombic_self(s);
+		out_sec[2] = now_sec() - t0;
+
+		if (s->polarization) {
+			double *E = (double *)calloc(3 * (size_t)n, sizeof(double));
+			double *mu = (double *)calloc(3 * (size_t)n, sizeof(double));
+			double *rowbuf = (double *)calloc(9 * (size_t)n, sizeof(double)); /* one atom's 3 dense rows */
+
+			/* 4: thole_field: reciprocal part in full, real part on sampled rows */
+			t0 = now_sec();
+			if (s->polar_ewald) field_recip(s, E);
+			double t_recip = now_sec() - t0;
+			t0 = now_sec();
+			for (int i = 0; i < n; i += stride)
+				for (int j = i + 1; j < n; j++) {
+					pair_par pp;
+					double d[3], rr;
+					pair_params(s, i, j, &pp);
+					if (pp.frozen) continue;
+					double r = orc_minimum_image(s, i, j, d, &rr);
+					double factor;
+					if (s->polar_ewald) {
+						if ((r > s->cutoff) || (r == 0.0)) continue;
+						double a = s->polar_ewald_alpha, r2 = r * r;
+						if (pp.es_excluded) factor = (2.0 * a * ORC_ONE_OVER_SQRT_PI * exp(-a * a * r2) * r - erf(a * r)) / (r * r2);
+						else factor = (2.0 * a * ORC_ONE_OVER_SQRT_PI * exp(-a * a * r2) * r + erfc(a * r)) / (r2 * r);
+					} else {
+						if (pp.intra || !((r - ORC_SMALL_DR < s->cutoff) && (r != 0.))) continue;
+						factor = 1.0 / (r * r * r);
+					}
+					for (int p = 0; p < 3; p++) {
+						E[3 * i + p] += factor * s->charge[j] * d[p];
+						E[3 * j + p] -= factor * s->charge[i] * d[p];
+					}
+				}
+			out_sec[4] = t_recip + (now_sec() - t0) * tri_scale;
+			for (int i = 0; i < 3 * n; i++) mu[i] = s->polarizability[i / 3] * E[i];
+
+			/* 3 + 5: thole_amatrix rows of the sampled atoms, then polar_max_iter dense contractions that stream those
+			 * rows from memory iteration by iteration (as the reference streams its 3N x 3N matrix) */
+			free(rowbuf);
+			rowbuf = (double *)calloc((size_t)rows * 9 * (size_t)n, sizeof(double));
+			double t_build = 0, t_contract = 0;
+			t0 = now_sec();
+			{
+				int k = 0;
+				for (int i = 0; i < n; i += stride, k++) {
+					double *rb = rowbuf + (size_t)k * 9 * n;
+					for (int j = 0; j < n; j++) {
+						double T[9];
+						if (j == i) continue;
+						tensor_upper(s, i < j ? i : j, i < j ? j : i, T);
+						for (int p = 0; p < 3; p++)
+							for (int q = 0; q < 3; q++) rb[(size_t)p * 3 * n + 3 * j + q] = T[3 * p + q];
+					}
+				}
+			}
+			t_build = now_sec() - t0;
+			t0 = now_sec();
+			for (int it = 0; it < s->polar_max_iter; it++) {
+				int k = 0;
+				for (int i = 0; i < n; i += stride, k++) {
+					const double *rb = rowbuf + (size_t)k * 9 * n;
+					double f[3] = {0, 0, 0};
+					for (int j = 0; j < n; j++)
+						if (j != i)
+							for (int p = 0; p < 3; p++) {
+								const double *row = rb + (size_t)p * 3 * n + 3 * j;
+								f[p] -= row[0] * mu[3 * j] + row[1] * mu[3 * j + 1] + row[2] * mu[3 * j + 2];
+							}
+					sink += f[0] + f[1] + f[2];
+				}
+			}
+			t_contract = now_sec() - t0;
+			out_sec[3] = t_build * row_scale * 0.5; /* the full build fills each (i<j) block once and mirrors it */
+			out_sec[5] = t_contract * row_scale;
+			free(E);
+			free(mu);
+			free(rowbuf);
+		}
+	}
+	for (int k = 0; k < 6; k++) out_sec[6] += out_sec[k];
+	(void)sink;
+	return now_sec() - t_begin;
+}

@@ -71,6 +71,10 @@ double orc_polar(const orc_system *s, orc_result *out, double *ef_static, double
  * ordered sum over beads s=0..P-1, divided by P.  out4 = {rd, coulombic, polarization, vdw}; returns V */
 double orc_pi_aggregate(int P, const double *rd, const double *es, const double *pol, const double *vdw, double out4[4]);
 
+/* bench.py cpu_baseline leg: time every stage of ONE evaluation on the rows i = 0, stride, 2 stride, ... and
+ * scale each stage by its exact work ratio; out_sec[6] = estimated seconds of one full evaluation. */
+double orc_time_sample(const orc_system *s, int stride, double out_sec[7]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,8 @@ def lib():
         L.orc_thole_amatrix_block.restype = None
         L.orc_minimum_image.argtypes = [C.POINTER(OrcSystem), C.c_int, C.c_int, dp, dp]
         L.orc_minimum_image.restype = C.c_double
+        L.orc_time_sample.argtypes = [C.POINTER(OrcSystem), C.c_int, dp]
+        L.orc_time_sample.restype = C.c_double
         L.orc_pi_aggregate.argtypes = [C.c_int, dp, dp, dp, dp, dp]
         L.orc_pi_aggregate.restype = C.c_double
         _lib = L
@@ -173,6 +175,12 @@ class OracleSystem:
         if want_atoms:
             out.update(ef_static=E, mu=mu, ef_induced=F)
         return out
+
+    def time_sample(self, stride: int):
+        """(estimated seconds per stage of one full evaluation [7], wall seconds spent)"""
+        out = np.zeros(7)
+        wall = lib().orc_time_sample(C.byref(self.s), int(stride), _dp(out))
+        return out, wall
 
     def thole_field(self):
         E = np.zeros((self.n, 3))
