@@ -39,6 +39,13 @@ struct mpmc_ctx {
 	std::vector<double> h_pos, h_q, h_alpha, h_eps, h_sigma, h_mass;
 	std::vector<int32_t> h_mol, h_frozen, h_disp;
 
+	// spatial order: device slot k holds original atom perm[k]; slot_of[i] is the slot of original atom i.
+	// Atoms are sorted (nested x / y / z bisection of the wrapped fractional coordinates) so that each tile of 64
+	// consecutive slots is spatially compact; every result that leaves the library is returned in ORIGINAL order.
+	std::vector<int32_t> perm, slot_of;
+	int32_t *d_slot_of = nullptr, *d_perm = nullptr;
+	bool atoms_dirty = true; // host mirror newer than the device arrays (full upload pending)
+
 	// device atom arrays
 	double4 *d_xyzq = nullptr;
 	double2 *d_lj = nullptr;
@@ -304,6 +311,8 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	A(dev_alloc(c, &c->d_mf, P));
 	A(dev_alloc(c, &c->d_alpha, P));
 	A(dev_alloc(c, &c->d_eps, P));
+	A(dev_alloc(c, &c->d_slot_of, P));
+	A(dev_alloc(c, &c->d_perm, P));
 	A(dev_alloc(c, &c->d_scal, (size_t)S_COUNT));
 	A(dev_alloc(c, &c->d_cnt, (size_t)C_COUNT));
 	A(dev_alloc(c, &c->d_flag, (size_t)1));
@@ -330,7 +339,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab};
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (c->h_scal) (void)hipHostFree(c->h_scal);
@@ -364,6 +373,7 @@ extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *re
 			if (i != j && (basis[3 * i + j] != 0.0 || R[3 * i + j] != 0.0)) c->box.ortho = 0;
 	c->box_set = true;
 	c->k_dirty = true;
+	c->atoms_dirty = true; // the spatial order depends on the cell
 	return MPMC_OK;
 }
 
@@ -396,16 +406,59 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 }
 
 // ---- atoms -----------------------------------------------------------------------------------------------
+// nested bisection sort of the wrapped fractional coordinates: nx slabs in x, ny strips in y per slab, z order inside a
+// strip; consecutive groups of 64 slots (tiles) are then roughly cubic cells.  Pure host code, O(N log N).
+static void compute_spatial_order(mpmc_ctx *c) {
+	const int n = c->n;
+	c->perm.resize(n);
+	c->slot_of.resize(n);
+	for (int i = 0; i < n; i++) c->perm[i] = i;
+	bool enable = c->box_set && n > 2 * kTile;
+	if (const char *e = std::getenv("MPMC_NO_SORT")) if (e[0] == '1') enable = false;
+	if (enable) {
+		std::vector<double> f(3 * (size_t)n);
+		for (int i = 0; i < n; i++)
+			for (int p = 0; p < 3; p++) {
+				double v = 0;
+				for (int q = 0; q < 3; q++) v += c->box.r[3 * q + p] * c->h_pos[3 * i + q];
+				v -= std::floor(v);
+				f[3 * (size_t)i + p] = v;
+			}
+		const int T = (n + kTile - 1) / kTile;
+		const int nx = std::max(1, (int)std::lround(std::cbrt((double)T)));
+		const int tiles_per_slab = (T + nx - 1) / nx;
+		const int ny = std::max(1, (int)std::lround(std::sqrt((double)tiles_per_slab)));
+		const int tiles_per_strip = (tiles_per_slab + ny - 1) / ny;
+		auto by = [&](int dim) { return [&f, dim](int a, int b) { return f[3 * (size_t)a + dim] < f[3 * (size_t)b + dim] || (f[3 * (size_t)a + dim] == f[3 * (size_t)b + dim] && a < b); }; };
+		std::sort(c->perm.begin(), c->perm.end(), by(0));
+		const int slab = tiles_per_slab * kTile, strip = tiles_per_strip * kTile;
+		for (int s0 = 0; s0 < n; s0 += slab) {
+			const int s1 = std::min(n, s0 + slab);
+			std::sort(c->perm.begin() + s0, c->perm.begin() + s1, by(1));
+			for (int t0 = s0; t0 < s1; t0 += strip) {
+				const int t1 = std::min(s1, t0 + strip);
+				std::sort(c->perm.begin() + t0, c->perm.begin() + t1, by(2));
+			}
+		}
+	}
+	for (int k = 0; k < n; k++) c->slot_of[c->perm[k]] = k;
+}
+
 static int upload_atoms(mpmc_ctx *c) {
+	compute_spatial_order(c);
 	const int n = c->n, np = c->n_pad;
 	std::vector<double4> xyzq(np);
 	std::vector<double2> lj(np);
 	std::vector<int2> mf(np);
 	std::vector<double> al(np, 0.0), ep(np, 0.0);
-	for (int i = 0; i < np; i++) {
-		if (i < n) {
-			xyzq[i] = make_double4(c->h_pos[3 * i], c->h_pos[3 * i + 1], c->h_pos[3 * i + 2], c->h_q[i]);
-			lj[i] = make_double2(std::fabs(c->h_sigma[i]), std::sqrt(c->h_eps[i]));
+	std::vector<int32_t> perm(np, -1), slot(np, -1);
+	for (int k = 0; k < np; k++) {
+		if (k < n) {
+			const int i = c->perm[k];
+			perm[k] = i;
+			slot[i] = k;
+			xyzq[k] = make_double4(c->h_pos[3 * i], c->h_pos[3 * i + 1], c->h_pos[3 * i + 2], c->h_q[i]);
+			lj[k] = make_double2(std::fabs(c->h_sigma[i]), std::sqrt(c->h_eps[i]));
 			int fl = 0;
 			if (c->h_frozen[i]) fl |= AF_FROZEN;
 			if (c->h_eps[i] == 0.0 || c->h_sigma[i] == 0.0) fl |= AF_NULL_RD;
@@ -414,13 +467,13 @@ static int upload_atoms(mpmc_ctx *c) {
 			if (c->h_sigma[i] == 0.0) fl |= AF_ZERO_SIGMA;
 			if (c->h_q[i] == 0.0) fl |= AF_ZERO_Q;
 			if (c->h_alpha[i] == 0.0) fl |= AF_ZERO_ALPHA;
-			mf[i] = make_int2(c->h_mol[i], fl);
-			al[i] = c->h_alpha[i];
-			ep[i] = c->h_eps[i];
+			mf[k] = make_int2(c->h_mol[i], fl);
+			al[k] = c->h_alpha[i];
+			ep[k] = c->h_eps[i];
 		} else {
-			xyzq[i] = make_double4(0, 0, 0, 0);
-			lj[i] = make_double2(0, 0);
-			mf[i] = make_int2(-1 - i, AF_PAD | AF_FROZEN | AF_NULL_RD | AF_ZERO_SIGMA | AF_ZERO_Q | AF_ZERO_ALPHA);
+			xyzq[k] = make_double4(0, 0, 0, 0);
+			lj[k] = make_double2(0, 0);
+			mf[k] = make_int2(-1 - k, AF_PAD | AF_FROZEN | AF_NULL_RD | AF_ZERO_SIGMA | AF_ZERO_Q | AF_ZERO_ALPHA);
 		}
 	}
 	HIP_TRY(c, hipMemcpyAsync(c->d_xyzq, xyzq.data(), np * sizeof(double4), hipMemcpyHostToDevice, c->stream));
@@ -428,7 +481,10 @@ static int upload_atoms(mpmc_ctx *c) {
 	HIP_TRY(c, hipMemcpyAsync(c->d_mf, mf.data(), np * sizeof(int2), hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(c, hipMemcpyAsync(c->d_alpha, al.data(), np * sizeof(double), hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(c, hipMemcpyAsync(c->d_eps, ep.data(), np * sizeof(double), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_perm, perm.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_slot_of, slot.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream)); // staging vectors die here
+	c->atoms_dirty = false;
 	return MPMC_OK;
 }
 
@@ -470,8 +526,8 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 		}
 	}
 
-	int rc = upload_atoms(c);
-	if (rc != MPMC_OK) return rc;
+	int rc = MPMC_OK;
+	c->atoms_dirty = true; // uploaded (in spatial order) by the next evaluation, when the box is known too
 
 	// upper-triangular tile-pair schedule of the pair kernel
 	const int nt = c->n_tiles;
@@ -505,17 +561,26 @@ extern "C" int mpmc_update_positions(mpmc_ctx *c, int first, int count, const do
 	if (!c->atoms_set || first + count > c->n) return fail(c, MPMC_ERR_ARG, "mpmc_update_positions: range outside the atom list");
 	if (count == 0) return MPMC_OK;
 	HIP_TRY(c, hipSetDevice(c->device));
-	std::vector<double4> tmp(count);
 	for (int t = 0; t < count; t++) {
-		const int i = first + t;
 		if (!std::isfinite(pos[3 * t]) || !std::isfinite(pos[3 * t + 1]) || !std::isfinite(pos[3 * t + 2]))
 			return fail(c, MPMC_ERR_INVALID_DATUM, "mpmc_update_positions: non-finite position");
+	}
+	for (int t = 0; t < count; t++) {
+		const int i = first + t;
 		c->h_pos[3 * i] = pos[3 * t];
 		c->h_pos[3 * i + 1] = pos[3 * t + 1];
 		c->h_pos[3 * i + 2] = pos[3 * t + 2];
-		tmp[t] = make_double4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], c->h_q[i]);
 	}
-	HIP_TRY(c, hipMemcpyAsync(c->d_xyzq + first, tmp.data(), count * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+	if (c->atoms_dirty) return MPMC_OK; // a full (re-sorted) upload is pending anyway
+	if (count > 256) { // large updates: one full re-upload (also refreshes the spatial order)
+		c->atoms_dirty = true;
+		return MPMC_OK;
+	}
+	for (int t = 0; t < count; t++) { // the moved atoms keep their slots (the order only matters for speed)
+		const int i = first + t;
+		const double4 v = make_double4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], c->h_q[i]);
+		HIP_TRY(c, hipMemcpyAsync(c->d_xyzq + c->slot_of[i], &v, sizeof(double4), hipMemcpyHostToDevice, c->stream));
+	}
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return MPMC_OK;
 }
@@ -524,7 +589,11 @@ extern "C" int mpmc_set_positions_device(mpmc_ctx *c, const double *pos_device) 
 	if (!c || !pos_device) return MPMC_ERR_ARG;
 	if (!c->atoms_set) return fail(c, MPMC_ERR_ARG, "mpmc_set_positions_device: no atoms set");
 	HIP_TRY(c, hipSetDevice(c->device));
-	launch_set_positions(c->stream, pos_device, c->d_xyzq, 0, c->n);
+	if (c->atoms_dirty) { // need the slot order first
+		int rc = upload_atoms(c);
+		if (rc != MPMC_OK) return rc;
+	}
+	launch_set_positions(c->stream, pos_device, c->d_perm, c->d_xyzq, c->n);
 	HIP_TRY(c, hipGetLastError());
 	// keep the host mirror coherent (update_com / later partial updates read it)
 	HIP_TRY(c, hipMemcpyAsync(c->h_pos.data(), pos_device, 3 * (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -636,6 +705,10 @@ static int prepare(mpmc_ctx *c) {
 	if (!c->box_set) return fail(c, MPMC_ERR_BOX, "energy: no box set (mpmc_set_box)");
 	if (!c->atoms_set) return fail(c, MPMC_ERR_INVALID_DATUM, "energy: no atoms set (mpmc_set_atoms)");
 	HIP_TRY(c, hipSetDevice(c->device));
+	if (c->atoms_dirty) {
+		int rc = upload_atoms(c);
+		if (rc != MPMC_OK) return rc;
+	}
 	if (c->k_dirty) {
 		// System::update_pbc, reference src/System.cpp:871-874
 		c->ewald_alpha = (c->opts.ewald_alpha > 0) ? c->opts.ewald_alpha : 3.5 / c->box.cutoff;
@@ -892,12 +965,25 @@ extern "C" int mpmc_polar(mpmc_ctx *c, double *out) {
 	if (rc == MPMC_OK && out) *out = r.polarization_energy;
 	return rc;
 }
+// device per-atom vectors are in slot order; everything handed to the caller is in original atom order
+static int fetch_atoms3(mpmc_ctx *c, const double *d_src, double *out) {
+	std::vector<double> tmp(3 * (size_t)c->n);
+	HIP_TRY(c, hipMemcpy(tmp.data(), d_src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+	for (int k = 0; k < c->n; k++) {
+		const int i = c->perm[k];
+		out[3 * (size_t)i] = tmp[3 * (size_t)k];
+		out[3 * (size_t)i + 1] = tmp[3 * (size_t)k + 1];
+		out[3 * (size_t)i + 2] = tmp[3 * (size_t)k + 2];
+	}
+	return MPMC_OK;
+}
+
 extern "C" int mpmc_thole_field(mpmc_ctx *c, double *ef_static) {
 	if (!c) return MPMC_ERR_ARG;
 	mpmc_result r;
 	int rc = run_piece(c, RUN_FIELD, &r);
 	if (rc != MPMC_OK) return rc;
-	if (ef_static) HIP_TRY(c, hipMemcpy(ef_static, c->d_e_static, 3 * (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost));
+	if (ef_static) return fetch_atoms3(c, c->d_e_static, ef_static);
 	return MPMC_OK;
 }
 
@@ -915,7 +1001,7 @@ extern "C" int mpmc_thole_amatrix(mpmc_ctx *c, int row0, int nrows, double *a) {
 	}
 	{
 		ProfScope p(c, MPMC_K_TENSOR);
-		launch_amatrix_rows(c->stream, atoms_view(c), c->box, c->opts.polar_damp, row0, nrows, c->d_arows);
+		launch_amatrix_rows(c->stream, atoms_view(c), c->d_slot_of, c->box, c->opts.polar_damp, row0, nrows, c->d_arows);
 	}
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipMemcpyAsync(a, c->d_arows, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -929,11 +1015,11 @@ extern "C" int mpmc_get_dipoles(mpmc_ctx *c, double *mu, double *ef_static, doub
 	if (!c->d_e_static) return fail(c, MPMC_ERR_ARG, "mpmc_get_dipoles: no polarization evaluation has run");
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	const size_t bytes = 3 * (size_t)c->n * sizeof(double);
-	if (mu) HIP_TRY(c, hipMemcpy(mu, c->d_mu[c->mu_cur], bytes, hipMemcpyDeviceToHost));
-	if (ef_static) HIP_TRY(c, hipMemcpy(ef_static, c->d_e_static, bytes, hipMemcpyDeviceToHost));
-	if (ef_induced) HIP_TRY(c, hipMemcpy(ef_induced, c->d_e_induced, bytes, hipMemcpyDeviceToHost));
-	return MPMC_OK;
+	int rc = MPMC_OK;
+	if (mu && rc == MPMC_OK) rc = fetch_atoms3(c, c->d_mu[c->mu_cur], mu);
+	if (ef_static && rc == MPMC_OK) rc = fetch_atoms3(c, c->d_e_static, ef_static);
+	if (ef_induced && rc == MPMC_OK) rc = fetch_atoms3(c, c->d_e_induced, ef_induced);
+	return rc;
 }
 
 // update_com + wrap_all, reference src/System.cpp:1347-1425 (host side: O(N), consumed by I/O only)

@@ -73,7 +73,9 @@ void launch_polar_energy(hipStream_t st, const AtomsDev &at, const double *mu, c
                          double *scal);
 
 // dense thole_amatrix rows (parity / DENSE solver)
-void launch_amatrix_rows(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, int row0, int nrows, double *a /*[nrows][3n]*/);
+// rows and columns are ORIGINAL atom indices; slot_of maps them to the device order
+void launch_amatrix_rows(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, double polar_damp, int row0, int nrows,
+                         double *a /*[nrows][3n]*/);
 
 // ---- symmetric production kernels (kernels_sym.hip) -------------------------------------------------------
 struct FusedParams {
@@ -94,7 +96,7 @@ void launch_dipole_iter_compact(hipStream_t st, bool dpp, const AtomsDev &at, co
 // lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
 void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm);
 
-// device-resident positions [count][3] -> xyzq[first .. first+count).xyz
-void launch_set_positions(hipStream_t st, const double *pos_dev, double4 *xyzq, int first, int count);
+// device-resident positions [n][3] in original atom order -> xyzq[slot].xyz (perm[slot] = original index)
+void launch_set_positions(hipStream_t st, const double *pos_dev, const int *perm, double4 *xyzq, int n);
 
 } // namespace mpmc

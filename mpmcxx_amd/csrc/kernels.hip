@@ -522,7 +522,8 @@ void launch_polar_energy(hipStream_t st, const AtomsDev &at, const double *mu, c
 // dense thole_amatrix rows (reference :2661-2770).  One thread per (row atom, column atom) 3x3 block.
 // ------------------------------------------------------------------------------------------------------
 template <bool ORTHO>
-__global__ __launch_bounds__(256) void k_amatrix_rows(AtomsDev at, Box bx, double lambda, int atom0, int natoms_rows, double *__restrict__ a) {
+__global__ __launch_bounds__(256) void k_amatrix_rows(AtomsDev at, const int *__restrict__ slot_of, Box bx, double lambda, int atom0,
+                                                      int natoms_rows, double *__restrict__ a) {
 	const int j = blockIdx.x * 256 + threadIdx.x;
 	const int ir = blockIdx.y; // row atom index relative to atom0
 	if (j >= at.n || ir >= natoms_rows) return;
@@ -530,13 +531,13 @@ __global__ __launch_bounds__(256) void k_amatrix_rows(AtomsDev at, Box bx, doubl
 	const size_t ld = 3 * (size_t)at.n;
 	double *blk = a + (3 * (size_t)ir) * ld + 3 * (size_t)j;
 	if (i == j) {
-		const double al = at.alpha[i];
+		const double al = at.alpha[slot_of[i]];
 		for (int p = 0; p < 3; ++p)
 			for (int q = 0; q < 3; ++q) blk[p * ld + q] = (p == q) ? ((al != 0.0) ? 1.0 / al : kMaxValue) : 0.0;
 		return;
 	}
 	const int lo = min(i, j), hi = max(i, j); // the reference fills the (lo,hi) block and COPIES it to (hi,lo) (:2762-2764)
-	const double4 pl = at.xyzq[lo], ph = at.xyzq[hi];
+	const double4 pl = at.xyzq[slot_of[lo]], ph = at.xyzq[slot_of[hi]];
 	double d[3];
 	const double r = min_image<ORTHO>(bx, pl.x - ph.x, pl.y - ph.y, pl.z - ph.z, d[0], d[1], d[2]);
 	double ir3, ir5;
@@ -559,29 +560,30 @@ __global__ __launch_bounds__(256) void k_amatrix_rows(AtomsDev at, Box bx, doubl
 		}
 }
 
-void launch_amatrix_rows(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, int row0, int nrows, double *a) {
+void launch_amatrix_rows(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, double polar_damp, int row0, int nrows, double *a) {
 	const int atom0 = row0 / 3, nat = nrows / 3;
 	dim3 grid((at.n + 255) / 256, nat), block(256);
 	if (bx.ortho)
-		hipLaunchKernelGGL(k_amatrix_rows<true>, grid, block, 0, st, at, bx, polar_damp, atom0, nat, a);
+		hipLaunchKernelGGL(k_amatrix_rows<true>, grid, block, 0, st, at, slot_of, bx, polar_damp, atom0, nat, a);
 	else
-		hipLaunchKernelGGL(k_amatrix_rows<false>, grid, block, 0, st, at, bx, polar_damp, atom0, nat, a);
+		hipLaunchKernelGGL(k_amatrix_rows<false>, grid, block, 0, st, at, slot_of, bx, polar_damp, atom0, nat, a);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // positions that already live in device memory ([n][3] fp64) -> xyzq.xyz (charge kept)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_set_positions(const double *__restrict__ pos, double4 *__restrict__ xyzq, int first, int count) {
-	const int t = blockIdx.x * 256 + threadIdx.x;
-	if (t >= count) return;
-	double4 v = xyzq[first + t];
-	v.x = pos[3 * (size_t)t + 0];
-	v.y = pos[3 * (size_t)t + 1];
-	v.z = pos[3 * (size_t)t + 2];
-	xyzq[first + t] = v;
+__global__ __launch_bounds__(256) void k_set_positions(const double *__restrict__ pos, const int *__restrict__ perm, double4 *__restrict__ xyzq, int n) {
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= n) return;
+	const int i = perm[k];
+	double4 v = xyzq[k];
+	v.x = pos[3 * (size_t)i + 0];
+	v.y = pos[3 * (size_t)i + 1];
+	v.z = pos[3 * (size_t)i + 2];
+	xyzq[k] = v;
 }
-void launch_set_positions(hipStream_t st, const double *pos_dev, double4 *xyzq, int first, int count) {
-	if (count > 0) hipLaunchKernelGGL(k_set_positions, dim3((count + 255) / 256), dim3(256), 0, st, pos_dev, xyzq, first, count);
+void launch_set_positions(hipStream_t st, const double *pos_dev, const int *perm, double4 *xyzq, int n) {
+	if (n > 0) hipLaunchKernelGGL(k_set_positions, dim3((n + 255) / 256), dim3(256), 0, st, pos_dev, perm, xyzq, n);
 }
 
 } // namespace mpmc

@@ -183,3 +183,46 @@ def test_full_size_translation_invariance_and_image_shift():
         assert util.close(r1[k], r0[k], 1e-9), k
     S.close()
     T.close()
+
+
+def test_spatial_order_is_transparent(monkeypatch):
+    """the library sorts atoms into compact tiles internally; every output is in the caller's order and the
+    energies do not depend on the internal order beyond summation rounding."""
+    atoms, basis, opts = util.load_fixture("water64_polar")
+    S = energy.System(atoms, basis, opts)
+    e_sorted = S.energy()
+    mu_s, E_s, F_s = S.dipoles()
+    A_s = S.thole_amatrix(0, 9)
+    S.close()
+    monkeypatch.setenv("MPMC_NO_SORT", "1")
+    T = energy.System(atoms, basis, opts)
+    e_plain = T.energy()
+    mu_p, E_p, F_p = T.dipoles()
+    A_p = T.thole_amatrix(0, 9)
+    T.close()
+    assert util.close(e_sorted, e_plain, 1e-12)
+    assert util.max_rel(mu_s, mu_p) < 1e-11 and util.max_rel(E_s, E_p) < 1e-11
+    assert np.array_equal(A_s, A_p)  # the dense A entries are pure functions of the two atoms' positions
+    g = util.golden("water64_polar")
+    assert util.max_rel(mu_s.reshape(-1), g["mu"]) < util.REL_TOL
+
+
+def test_set_positions_device_matches_host_upload():
+    import torch
+
+    atoms, basis, opts = util.load_fixture("ion1000_polar")
+    S = energy.System(atoms, basis, opts)
+    e0 = S.energy()
+    rng = np.random.default_rng(3)
+    newpos = atoms["pos"] + rng.normal(scale=0.03, size=atoms["pos"].shape)
+    t = torch.tensor(newpos, dtype=torch.float64, device="cuda:0").contiguous()
+    torch.cuda.synchronize()
+    S.set_positions_device(t.data_ptr())
+    e1 = S.energy()
+    a2 = dict(atoms)
+    a2["pos"] = newpos
+    T = energy.System(a2, basis, opts)
+    e2 = T.energy()
+    assert e1 != e0 and util.close(e1, e2, 1e-12)
+    S.close()
+    T.close()
