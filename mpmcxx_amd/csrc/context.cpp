@@ -54,9 +54,12 @@ struct mpmc_ctx {
 
 	// pair kernel
 	int2 *d_tile_pairs = nullptr;
-	double *d_block_part = nullptr;
-	int *d_block_cnt = nullptr;
+	double *d_block_part = nullptr; // [ntp][2]
+	int *d_block_cnt = nullptr;     // [ntp][4] (2 used by the pair kernel, 4 by the static-count kernel)
+	int *d_cls = nullptr;           // tile-pair classes (CLS_*), recomputed every evaluation
+	double *d_tile_bounds = nullptr; // [n_tiles][6]
 	size_t cap_tile_pairs = 0;
+	long long static_cnt[4] = {0, 0, 0, 0}; // n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent)
 
 	// scalars
 	double *d_scal = nullptr;
@@ -84,7 +87,7 @@ struct mpmc_ctx {
 	size_t cap_ab = 0; // in double2 elements
 	int solver_used = MPMC_SOLVER_MATRIX_FREE;
 	bool use_dpp = true;   // lane rotation by v_mov_b32_dpp wave_rol:1 (verified at create), else ds_bpermute
-	bool legacy = false;   // MPMC_LEGACY_KERNELS=1: first-generation split kernels (A/B comparisons only)
+	bool no_classes = false; // MPMC_NO_CLASSES=1: treat every tile pair as near (A/B comparisons only)
 
 	Box box{};
 	bool box_set = false, atoms_set = false, opts_set = false, k_dirty = true;
@@ -311,6 +314,7 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	A(dev_alloc(c, &c->d_mf, P));
 	A(dev_alloc(c, &c->d_alpha, P));
 	A(dev_alloc(c, &c->d_eps, P));
+	A(dev_alloc(c, &c->d_tile_bounds, 6 * (P / kTile)));
 	A(dev_alloc(c, &c->d_slot_of, P));
 	A(dev_alloc(c, &c->d_perm, P));
 	A(dev_alloc(c, &c->d_scal, (size_t)S_COUNT));
@@ -325,7 +329,7 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 		mpmc_ctx_destroy(c);
 		return rc;
 	}
-	if (const char *e = std::getenv("MPMC_LEGACY_KERNELS")) c->legacy = (e[0] == '1');
+	if (const char *e = std::getenv("MPMC_NO_CLASSES")) c->no_classes = (e[0] == '1');
 	if (const char *e = std::getenv("MPMC_NO_DPP")) if (e[0] == '1') c->use_dpp = false;
 	*out = c;
 	return MPMC_OK;
@@ -339,7 +343,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm};
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tile_bounds};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (c->h_scal) (void)hipHostFree(c->h_scal);
@@ -483,6 +487,20 @@ static int upload_atoms(mpmc_ctx *c) {
 	HIP_TRY(c, hipMemcpyAsync(c->d_eps, ep.data(), np * sizeof(double), hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(c, hipMemcpyAsync(c->d_perm, perm.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(c, hipMemcpyAsync(c->d_slot_of, slot.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+	// position-independent pair-flag counts (diagnostics of pair_exclusions), once per upload
+	{
+		AtomsDev at;
+		at.xyzq = c->d_xyzq;
+		at.lj = c->d_lj;
+		at.mf = c->d_mf;
+		at.alpha = c->d_alpha;
+		at.eps = c->d_eps;
+		at.n = c->n;
+		at.n_pad = c->n_pad;
+		launch_static_counts(c->stream, at, c->d_tile_pairs, c->n_tile_pairs, c->d_block_cnt, c->d_cnt);
+		HIP_TRY(c, hipGetLastError());
+		HIP_TRY(c, hipMemcpyAsync(c->static_cnt, c->d_cnt, 4 * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+	}
 	HIP_TRY(c, hipStreamSynchronize(c->stream)); // staging vectors die here
 	c->atoms_dirty = false;
 	return MPMC_OK;
@@ -497,6 +515,18 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 			return fail(c, MPMC_ERR_INVALID_DATUM, "mpmc_set_atoms: non-finite position");
 		if (epsilon[i] < 0.0 || !std::isfinite(epsilon[i]) || !std::isfinite(sigma[i]) || !std::isfinite(charge[i]) || !std::isfinite(polarizability[i]))
 			return fail(c, MPMC_ERR_INVALID_DATUM, "mpmc_set_atoms: epsilon < 0 or non-finite atom parameter");
+	}
+	{ // molecules are contiguous runs of the atom list (reference System.cpp:672): an id may not reappear later
+		std::vector<int32_t> seen;
+		seen.reserve(64);
+		std::vector<int32_t> ids(mol_id, mol_id + n);
+		std::vector<int32_t> firsts;
+		for (int i = 0; i < n; i++)
+			if (i == 0 || mol_id[i] != mol_id[i - 1]) firsts.push_back(mol_id[i]);
+		std::vector<int32_t> sorted = firsts;
+		std::sort(sorted.begin(), sorted.end());
+		if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+			return fail(c, MPMC_ERR_INVALID_DATUM, "mpmc_set_atoms: atoms of one molecule (equal mol_id) must be contiguous");
 	}
 	HIP_TRY(c, hipSetDevice(c->device));
 	c->n = n;
@@ -534,12 +564,15 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 	const size_t ntp = (size_t)nt * (nt + 1) / 2;
 	if (ntp > c->cap_tile_pairs) {
 		dev_free(c, &c->d_tile_pairs, c->cap_tile_pairs);
-		dev_free(c, &c->d_block_part, 4 * c->cap_tile_pairs);
-		dev_free(c, &c->d_block_cnt, 6 * c->cap_tile_pairs);
+		dev_free(c, &c->d_block_part, 2 * c->cap_tile_pairs);
+		dev_free(c, &c->d_block_cnt, 4 * c->cap_tile_pairs);
+		dev_free(c, &c->d_cls, c->cap_tile_pairs);
 		c->cap_tile_pairs = 0;
 		if ((rc = dev_alloc(c, &c->d_tile_pairs, ntp)) != MPMC_OK) return rc;
-		if ((rc = dev_alloc(c, &c->d_block_part, 4 * ntp)) != MPMC_OK) return rc;
-		if ((rc = dev_alloc(c, &c->d_block_cnt, 6 * ntp)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_block_part, 2 * ntp)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_block_cnt, 4 * ntp)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_cls, ntp)) != MPMC_OK) return rc;
+		HIP_TRY(c, hipMemset(c->d_cls, 0, ntp * sizeof(int)));
 		c->cap_tile_pairs = ntp;
 	}
 	std::vector<int2> tp;
@@ -663,7 +696,7 @@ static int ensure_polar_buffers(mpmc_ctx *c) {
 		HIP_TRY(c, hipMemset(c->d_rrms, 0, np * sizeof(double)));
 	}
 	// per-atom partial slots: one per source tile (symmetric kernels) -- also covers the n_split <= n_tiles slots
-	// of the first-generation row kernels
+	// of the matrix-free row kernel
 	const size_t need = (size_t)c->n_tiles * c->n_pad * 3;
 	if (need > c->cap_part) {
 		dev_free(c, &c->d_part, c->cap_part);
@@ -678,7 +711,6 @@ static int ensure_polar_buffers(mpmc_ctx *c) {
 static int resolve_solver(mpmc_ctx *c) {
 	const size_t need = (size_t)c->n_tile_pairs * (kTile * kTile); // double2 elements, 16 B each
 	int want = c->opts.solver;
-	if (c->legacy) want = MPMC_SOLVER_MATRIX_FREE;
 	if (want == MPMC_SOLVER_AUTO) {
 		size_t budget_mb = 4096;
 		if (const char *e = std::getenv("MPMC_TENSOR_BUDGET_MB")) budget_mb = (size_t)std::strtoull(e, nullptr, 10);
@@ -764,21 +796,14 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		if ((rc = resolve_solver(c)) != MPMC_OK) return rc;
 	}
 	const bool compact = (mask & RUN_SOLVE) && c->solver_used == MPMC_SOLVER_COMPACT;
-	const int field_slots = c->legacy ? c->n_split : c->n_tiles;
 
-	// ---- pairwise pass ------------------------------------------------------------------------------------
-	if (c->legacy) {
-		if (mask & RUN_PAIR) {
-			ProfScope p(c, MPMC_K_PAIR);
-			PairParams pp;
-			pp.ewald_alpha = c->ewald_alpha;
-			pp.rd_lrc = o.rd_lrc;
-			pp.do_es = (mask & RUN_PAIR_ES) ? 1 : 0;
-			launch_pair_energy(st, at, c->box, pp, c->d_tile_pairs, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt);
-		}
-	} else if (mask & (RUN_PAIR | RUN_FIELD)) {
-		// one symmetric pass: energies + counts, static-field partials, Thole tensor store
+	// ---- pairwise pass: one symmetric sweep (energies + counts, static-field partials, Thole tensor store) ----------
+	if (mask & (RUN_PAIR | RUN_FIELD)) {
 		ProfScope p(c, MPMC_K_PAIR);
+		// tile-pair classes from this configuration's tile bounding boxes (orthorhombic cells; all "near" otherwise)
+		if (c->no_classes) HIP_TRY(c, hipMemsetAsync(c->d_cls, 0, (size_t)c->n_tile_pairs * sizeof(int), st));
+		else launch_tile_classes(st, at, c->box, c->d_tile_pairs, c->n_tile_pairs, (o.polarization && !o.rd_only) ? o.polar_damp : 0.0,
+		                         c->d_tile_bounds, c->d_cls);
 		FusedParams fp;
 		fp.ewald_alpha = c->ewald_alpha;
 		fp.polar_ewald_alpha = c->polar_ewald_alpha;
@@ -787,9 +812,12 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		fp.do_es = ((mask & RUN_PAIR_ES) || (mask & RUN_FIELD)) ? 1 : 0;
 		fp.do_field = (mask & RUN_FIELD) ? (o.polar_ewald ? 1 : 2) : 0;
 		fp.do_thole = compact ? 1 : 0;
-		launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
+		launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
 		                  compact ? c->d_ab : nullptr);
-		if (mask & RUN_PAIR) launch_reduce_pairs(st, c->d_block_part, c->d_block_cnt, c->n_tile_pairs, c->d_scal, c->d_cnt);
+		if (mask & RUN_PAIR) {
+			launch_reduce_pairs(st, c->d_block_part, c->d_block_cnt, c->n_tile_pairs, c->d_scal, c->d_cnt);
+			if (mask & RUN_PAIR_ES) launch_intra_terms(st, at, c->d_slot_of, c->ewald_alpha, c->d_scal);
+		}
 	}
 
 	// ---- reciprocal space + O(N) atom terms ------------------------------------------------------------------
@@ -798,16 +826,15 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		ProfScope p(c, MPMC_K_RECIP);
 		if (need_sf) launch_recip_sf(st, at, rcp);
 		if (mask & (RUN_RECIP | RUN_ATOMTERMS))
-			launch_recip_energy(st, at, rcp, c->box, c->ewald_alpha, o.rd_lrc, (mask & RUN_RECIP) ? 1 : 0, c->d_scal);
+			launch_atom_terms(st, at, rcp, c->box, c->ewald_alpha, (mask & RUN_ATOMTERMS) ? o.rd_lrc : 0, (mask & RUN_RECIP) ? 1 : 0, c->d_scal);
 	}
 
 	// ---- static field ---------------------------------------------------------------------------------------
 	if (mask & RUN_FIELD) {
 		ProfScope p(c, MPMC_K_FIELD);
 		if (o.polar_ewald) launch_field_recip(st, at, rcp, c->d_e_recip_part);
-		if (c->legacy) launch_field_real(st, at, c->box, o.polar_ewald, c->polar_ewald_alpha, c->n_split, c->d_part);
 		c->mu_cur = 0;
-		launch_field_finalize(st, at, c->box, o.polar_ewald, c->d_e_recip_part, c->d_part, field_slots, o.polar_gamma, c->d_e_static,
+		launch_field_finalize(st, at, c->box, o.polar_ewald, c->d_e_recip_part, c->d_part, c->n_tiles, o.polar_gamma, c->d_e_static,
 		                      c->d_mu[0]);
 	}
 
@@ -830,7 +857,8 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 			{
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
 				if (compact)
-					launch_dipole_iter_compact(st, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->n_tile_pairs, c->d_ab, c->d_part);
+					launch_dipole_iter_compact(st, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_ab,
+					                           c->d_part);
 				else
 					launch_dipole_iter_mf(st, at, c->box, o.polar_damp, c->d_mu[c->mu_cur], c->n_split, c->d_part);
 			}
@@ -887,10 +915,10 @@ static int wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 	out->n_pairs = (int64_t)c->n * (c->n - 1) / 2;
 	out->n_lj_in_cutoff = c->h_cnt[C_LJ_IN];
 	out->n_es_in_cutoff = c->h_cnt[C_ES_IN];
-	out->n_intra = c->h_cnt[C_INTRA];
-	out->n_rd_excluded = c->h_cnt[C_RDX];
-	out->n_es_excluded = c->h_cnt[C_ESX];
-	out->n_frozen = c->h_cnt[C_FROZEN];
+	out->n_intra = c->static_cnt[0];
+	out->n_rd_excluded = c->static_cnt[1];
+	out->n_es_excluded = c->static_cnt[2];
+	out->n_frozen = c->static_cnt[3];
 	out->polar_iterations = c->iters;
 	out->iterator_failed = c->failed;
 	return MPMC_OK;

@@ -29,16 +29,13 @@ enum : int {
 	S_COUNT = 16
 };
 enum : int { C_LJ_IN = 0, C_ES_IN, C_INTRA, C_RDX, C_ESX, C_FROZEN, C_COUNT = 8 };
-
-struct PairParams {
-	double ewald_alpha;
-	int rd_lrc, do_es;
+// tile-pair classes written by k_classify (orthorhombic cells; 0 otherwise): lower bound of the minimum-image
+// distance between the two tiles' bounding boxes
+enum : int {
+	CLS_BEYOND_CUTOFF = 1, // > cutoff: no pair of the tile pair passes any cutoff predicate
+	CLS_THOLE_FAR = 2      // lambda*r > 40 for every pair: exponential damping is below 1e-13, T is the bare dipole tensor
 };
-
-// pair energies over all unordered pairs: partial sums per block then a fixed-order final reduction
-void launch_pair_energy(hipStream_t st, const AtomsDev &at, const Box &bx, const PairParams &pp, const int2 *tile_pairs,
-                        int n_tile_pairs, double *block_part /*[n_tile_pairs][4]*/, int *block_cnt /*[n_tile_pairs][6]*/,
-                        double *scal, long long *cnt);
+constexpr double kTholeFarX = 40.0; // exp(-40)*(40^3/6) = 4.5e-14
 
 // reciprocal space: structure factors for every k, then energy + O(N) atom terms
 struct RecipDev {
@@ -49,13 +46,13 @@ struct RecipDev {
 	int K;
 };
 void launch_recip_sf(hipStream_t st, const AtomsDev &at, const RecipDev &rc);
-void launch_recip_energy(hipStream_t st, const AtomsDev &at, const RecipDev &rc, const Box &bx, double ewald_alpha, int rd_lrc,
-                         int do_es, double *scal);
+// reciprocal energy + O(N) atom terms: coulombic_self, lj_lrc_self, and the PAIR long-range correction summed in O(N)
+// through moments of (sqrt(eps), |sigma|) (Lorentz-Berthelot makes the pair term a polynomial in sigma_i + sigma_j)
+void launch_atom_terms(hipStream_t st, const AtomsDev &at, const RecipDev &rc, const Box &bx, double ewald_alpha, int rd_lrc,
+                       int do_es, double *scal);
 
 // static field
 void launch_field_recip(hipStream_t st, const AtomsDev &at, const RecipDev &rc, double *e_recip /*[n_pad][3]*/);
-void launch_field_real(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, double polar_ewald_alpha, int n_split,
-                       double *part /*[n_split][n_pad][3]*/);
 // E0 = recip*(8 pi/V) + sum_s part ; mu0 = gamma * alpha * E0
 void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip,
                            const double *part, int n_split, double gamma, double *e_static, double *mu);
@@ -88,11 +85,19 @@ struct FusedParams {
 // every unordered pair once: energies + counts (block partials), static-field partials fpart[nt][n_pad][3],
 // Thole store ab[n_tile_pairs][64*64] (double2 = 16 B per pair)
 void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
-                       int n_tile_pairs, double *block_part, int *block_cnt, double *fpart, double2 *ab);
+                       const int *cls, int n_tile_pairs, double *block_part /*[ntp][2]*/, int *block_cnt /*[ntp][2]*/, double *fpart, double2 *ab);
 void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt);
+// position-independent pair-flag counts (n_intra, n_rd_excluded, n_es_excluded, n_frozen): once per atom upload
+void launch_static_counts(hipStream_t st, const AtomsDev &at, const int2 *tile_pairs, int n_tile_pairs, int *block_cnt /*[ntp][4]*/,
+                          long long *cnt4);
+// sum over intramolecular non-frozen pairs of q_i q_j erf(alpha r)/r with the plain (non-image) distance (:1503-1504)
+void launch_intra_terms(hipStream_t st, const AtomsDev &at, const int *slot_of, double ewald_alpha, double *scal);
+// per-tile bounding boxes (wrapped fractional coordinates) and tile-pair classes (CLS_*)
+void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, const int2 *tile_pairs, int n_tile_pairs, double polar_damp,
+                         double *tile_bounds /*[nt][6]*/, int *cls);
 // one Jacobi contraction streaming the store: part[nt][n_pad][3]
 void launch_dipole_iter_compact(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                                int n_tile_pairs, const double2 *ab, double *part);
+                                const int *cls, int n_tile_pairs, const double2 *ab, double *part);
 // lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
 void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm);
 

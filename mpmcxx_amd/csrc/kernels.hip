@@ -33,116 +33,75 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// pair energies: lj() + coulombic_real()    (reference System.Energy.cpp:897-1032, 1466-1517)
-// grid: one wave per (I <= J) tile pair.
+// fixed-order final reduction of the per-tile-pair partials of k_pair_fused: {lj, es_real} and {n_lj, n_es}
 // ------------------------------------------------------------------------------------------------------
-template <bool ORTHO>
-__global__ __launch_bounds__(64) void k_pair_energy(AtomsDev at, Box bx, PairParams pp, const int2 *__restrict__ tile_pairs,
-                                                    double *__restrict__ block_part, int *__restrict__ block_cnt) {
-	__shared__ double4 s_xyzq[kTile];
-	__shared__ double2 s_lj[kTile];
-	__shared__ int2 s_mf[kTile];
+__global__ __launch_bounds__(256) void k_reduce_pairs(const double *__restrict__ block_part, const int *__restrict__ block_cnt, int nb,
+                                                      double *__restrict__ scal, long long *__restrict__ cnt) {
+	__shared__ double sh[4];
+	__shared__ long long shc[256];
+	double s0 = 0, s1 = 0;
+	long long c0 = 0, c1 = 0;
+	for (int b = threadIdx.x; b < nb; b += 256) {
+		s0 += block_part[2 * (size_t)b];
+		s1 += block_part[2 * (size_t)b + 1];
+		c0 += block_cnt[2 * (size_t)b];
+		c1 += block_cnt[2 * (size_t)b + 1];
+	}
+	s0 = block_sum_256(s0, sh);
+	s1 = block_sum_256(s1, sh);
+	if (threadIdx.x == 0) {
+		scal[S_LJ] = s0;
+		scal[S_ES_REAL] = s1;
+	}
+	for (int k = 0; k < 2; ++k) {
+		__syncthreads();
+		shc[threadIdx.x] = k ? c1 : c0;
+		__syncthreads();
+		for (int off = 128; off > 0; off >>= 1) {
+			if (threadIdx.x < off) shc[threadIdx.x] += shc[threadIdx.x + off];
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) cnt[k ? C_ES_IN : C_LJ_IN] = shc[0];
+	}
+}
 
+// position-independent pair flags (reference pair_exclusions :1035-1067): one wave per tile pair, broadcast j loop
+__global__ __launch_bounds__(64) void k_static_counts(AtomsDev at, const int2 *__restrict__ tile_pairs, int *__restrict__ block_cnt) {
+	__shared__ int2 s_mf[kTile];
 	const int lane = threadIdx.x;
 	const int2 IJ = tile_pairs[blockIdx.x];
-	const int i = IJ.x * kTile + lane;
-	const int j0 = IJ.y * kTile;
-	const bool diag = (IJ.x == IJ.y);
-
-	const double4 pi = at.xyzq[i];
-	const double2 li = at.lj[i];
-	const int2 mi = at.mf[i];
-	s_xyzq[lane] = at.xyzq[j0 + lane];
-	s_lj[lane] = at.lj[j0 + lane];
-	s_mf[lane] = at.mf[j0 + lane];
+	const int2 mi = at.mf[IJ.x * kTile + lane];
+	s_mf[lane] = at.mf[IJ.y * kTile + lane];
 	__syncthreads();
-
-	const bool i_real = !(mi.y & AF_PAD);
-	const double rc = bx.cutoff;
-	double e_lj = 0, e_lrc = 0, e_re = 0, e_in = 0;
-	int n_lj = 0, n_es = 0, n_intra = 0, n_rdx = 0, n_esx = 0, n_fr = 0;
-
+	int n_intra = 0, n_rdx = 0, n_esx = 0, n_fr = 0;
+	const bool diag = (IJ.x == IJ.y);
 	for (int jj = 0; jj < kTile; ++jj) {
 		const int2 mj = s_mf[jj];
-		const bool act = i_real && !(mj.y & AF_PAD) && (!diag || jj > lane);
-		if (!act) continue;
-		const double4 pj = s_xyzq[jj];
-		const double2 lj = s_lj[jj];
+		if ((mi.y & AF_PAD) || (mj.y & AF_PAD) || (diag && jj <= lane)) continue;
 		const PairFlags f = pair_flags(mi.x, mi.y, mj.x, mj.y);
 		n_intra += f.intra;
 		n_rdx += f.rd_excluded;
 		n_esx += f.es_excluded;
 		n_fr += f.frozen;
-		if (f.frozen) continue; // frozen pairs contribute to no term (:936, :1049, :1487)
-
-		const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-		double ox, oy, oz;
-		const double rimg = min_image<ORTHO>(bx, dx, dy, dz, ox, oy, oz);
-
-		double sig, eps;
-		lj_mix(mi.y, mj.y, li.x, li.y, lj.x, lj.y, sig, eps);
-		if (pp.rd_lrc && eps != 0.0 && sig != 0.0) e_lrc += lrc_term(sig, eps, rc, bx.volume);
-		if ((rimg - kSmallDR < rc) && !f.rd_excluded) {
-			e_lj += lj_term(sig, eps, rimg, f.attractive_only);
-			n_lj++;
-		}
-		if (pp.do_es) {
-			if (!((rimg > rc) || f.es_excluded)) {
-				e_re += pi.w * pj.w * erfc(pp.ewald_alpha * rimg) / rimg;
-				n_es++;
-			} else if (f.es_excluded) {
-				const double qq = pi.w * pj.w;
-				if (qq != 0.0) { // charge-to-screen term uses the plain (non-image) distance (:1504)
-					const double r = sqrt(((dx * dx) + dy * dy) + dz * dz);
-					e_in += qq * erf(pp.ewald_alpha * r) / r;
-				}
-			}
-		}
 	}
-
-	e_lj = wave_sum(e_lj);
-	e_lrc = wave_sum(e_lrc);
-	e_re = wave_sum(e_re);
-	e_in = wave_sum(e_in);
-	n_lj = wave_sum_i(n_lj);
-	n_es = wave_sum_i(n_es);
 	n_intra = wave_sum_i(n_intra);
 	n_rdx = wave_sum_i(n_rdx);
 	n_esx = wave_sum_i(n_esx);
 	n_fr = wave_sum_i(n_fr);
 	if (lane == 0) {
-		double *bp = block_part + 4 * (size_t)blockIdx.x;
-		bp[0] = e_lj;
-		bp[1] = e_lrc;
-		bp[2] = e_re;
-		bp[3] = e_in;
-		int *bc = block_cnt + 6 * (size_t)blockIdx.x;
-		bc[0] = n_lj;
-		bc[1] = n_es;
-		bc[2] = n_intra;
-		bc[3] = n_rdx;
-		bc[4] = n_esx;
-		bc[5] = n_fr;
+		int *bc = block_cnt + 4 * (size_t)blockIdx.x;
+		bc[0] = n_intra;
+		bc[1] = n_rdx;
+		bc[2] = n_esx;
+		bc[3] = n_fr;
 	}
 }
-
-__global__ __launch_bounds__(256) void k_reduce_pairs(const double *__restrict__ block_part, const int *__restrict__ block_cnt, int nb,
-                                                      double *__restrict__ scal, long long *__restrict__ cnt) {
-	__shared__ double sh[4];
+__global__ __launch_bounds__(256) void k_reduce_counts4(const int *__restrict__ block_cnt, int nb, long long *__restrict__ cnt4) {
 	__shared__ long long shc[256];
-	double s[4] = {0, 0, 0, 0};
-	long long c[6] = {0, 0, 0, 0, 0, 0};
-	for (int b = threadIdx.x; b < nb; b += 256) {
-#pragma unroll
-		for (int k = 0; k < 4; ++k) s[k] += block_part[4 * (size_t)b + k];
-#pragma unroll
-		for (int k = 0; k < 6; ++k) c[k] += block_cnt[6 * (size_t)b + k];
-	}
+	long long c[4] = {0, 0, 0, 0};
+	for (int b = threadIdx.x; b < nb; b += 256)
+		for (int k = 0; k < 4; ++k) c[k] += block_cnt[4 * (size_t)b + k];
 	for (int k = 0; k < 4; ++k) {
-		double t = block_sum_256(s[k], sh);
-		if (threadIdx.x == 0) scal[S_LJ + k] = t;
-	}
-	for (int k = 0; k < 6; ++k) {
 		__syncthreads();
 		shc[threadIdx.x] = c[k];
 		__syncthreads();
@@ -150,17 +109,12 @@ __global__ __launch_bounds__(256) void k_reduce_pairs(const double *__restrict__
 			if (threadIdx.x < off) shc[threadIdx.x] += shc[threadIdx.x + off];
 			__syncthreads();
 		}
-		if (threadIdx.x == 0) cnt[k] = shc[0];
+		if (threadIdx.x == 0) cnt4[k] = shc[0];
 	}
 }
-
-void launch_pair_energy(hipStream_t st, const AtomsDev &at, const Box &bx, const PairParams &pp, const int2 *tile_pairs, int n_tile_pairs,
-                        double *block_part, int *block_cnt, double *scal, long long *cnt) {
-	if (bx.ortho)
-		hipLaunchKernelGGL(k_pair_energy<true>, dim3(n_tile_pairs), dim3(kTile), 0, st, at, bx, pp, tile_pairs, block_part, block_cnt);
-	else
-		hipLaunchKernelGGL(k_pair_energy<false>, dim3(n_tile_pairs), dim3(kTile), 0, st, at, bx, pp, tile_pairs, block_part, block_cnt);
-	hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, block_part, block_cnt, n_tile_pairs, scal, cnt);
+void launch_static_counts(hipStream_t st, const AtomsDev &at, const int2 *tile_pairs, int n_tile_pairs, int *block_cnt, long long *cnt4) {
+	hipLaunchKernelGGL(k_static_counts, dim3(n_tile_pairs), dim3(kTile), 0, st, at, tile_pairs, block_cnt);
+	hipLaunchKernelGGL(k_reduce_counts4, dim3(1), dim3(256), 0, st, block_cnt, n_tile_pairs, cnt4);
 }
 
 void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt) {
@@ -196,10 +150,22 @@ __global__ __launch_bounds__(256) void k_recip_sf(AtomsDev at, RecipDev rc) {
 	if (threadIdx.x == 0) rc.sf[blockIdx.x] = make_double4(re, im, C, S);
 }
 
-__global__ __launch_bounds__(256) void k_recip_energy(AtomsDev at, RecipDev rc, Box bx, double ewald_alpha, int rd_lrc, int do_es,
-                                                      double *__restrict__ scal) {
+// binomial coefficients C(6,k), C(12,k)
+__device__ const double kBinom6[7] = {1, 6, 15, 20, 15, 6, 1};
+__device__ const double kBinom12[13] = {1, 12, 66, 220, 495, 792, 924, 792, 495, 220, 66, 12, 1};
+
+// Reciprocal energy, coulombic_self, lj_lrc_self and the pair LRC.
+// Pair LRC (reference lj_lrc_corr :1036-1069, summed over ALL non-frozen pairs with eps_ij, sigma_ij != 0):
+//   g_ij = (16 pi / 3V) eps_ij (sig_ij^12 / (3 rc^9) - sig_ij^6 / rc^3),  eps_ij = sqrt(eps_i) sqrt(eps_j),  sig_ij = (s_i + s_j)/2
+//   sum_{i<j} sqe_i sqe_j (s_i+s_j)^m = 1/2 [ sum_k C(m,k) M_k M_{m-k} - sum_i sqe_i^2 (2 s_i)^m ],   M_k = sum_i sqe_i s_i^k
+// over the atoms with eps != 0, sigma > 0 (sigma == 0 or < 0 gives sig_ij or eps_ij = 0), minus the same sum over the
+// frozen subset (frozen-frozen pairs are excluded, :1049).  O(N) instead of O(N^2), position independent.
+__global__ __launch_bounds__(256) void k_atom_terms(AtomsDev at, RecipDev rc, Box bx, double ewald_alpha, int rd_lrc, int do_es,
+                                                    double *__restrict__ scal) {
 	__shared__ double sh[4];
 	double e = 0, self = 0, lrc = 0;
+	double m[13], mf[13], d6 = 0, d12 = 0, df6 = 0, df12 = 0;
+	for (int k = 0; k < 13; ++k) m[k] = mf[k] = 0;
 	if (do_es) {
 		for (int k = threadIdx.x; k < rc.K; k += 256) {
 			const double4 sf = rc.sf[k];
@@ -208,15 +174,53 @@ __global__ __launch_bounds__(256) void k_recip_energy(AtomsDev at, RecipDev rc, 
 	}
 	for (int a = threadIdx.x; a < at.n; a += 256) {
 		const int fl = at.mf[a].y;
+		const double2 l = at.lj[a];
+		if (rd_lrc && !(fl & (AF_NULL_RD | AF_NEG_SIGMA))) {
+			double pw = l.y;
+			const bool fr = (fl & AF_FROZEN) != 0;
+			for (int k = 0; k < 13; ++k) {
+				m[k] += pw;
+				if (fr) mf[k] += pw;
+				pw *= l.x;
+			}
+			const double t2 = 2.0 * l.x, t6 = (t2 * t2 * t2) * (t2 * t2 * t2), e2 = l.y * l.y;
+			d6 += e2 * t6;
+			d12 += e2 * t6 * t6;
+			if (fr) {
+				df6 += e2 * t6;
+				df12 += e2 * t6 * t6;
+			}
+		}
 		if (fl & AF_FROZEN) continue;
 		const double q = at.xyzq[a].w;
 		if (do_es) self -= ewald_alpha * q * q / sqrt(kPi);
-		if (rd_lrc && !(fl & AF_NULL_RD)) lrc += lrc_term(at.lj[a].x, at.eps[a], bx.cutoff, bx.volume);
+		if (rd_lrc && !(fl & AF_NULL_RD)) lrc += lrc_term(l.x, at.eps[a], bx.cutoff, bx.volume);
 	}
 	e = block_sum_256(e, sh);
 	self = block_sum_256(self, sh);
 	lrc = block_sum_256(lrc, sh);
+	for (int k = 0; k < 13; ++k) {
+		m[k] = block_sum_256(m[k], sh);
+		mf[k] = block_sum_256(mf[k], sh);
+	}
+	d6 = block_sum_256(d6, sh);
+	d12 = block_sum_256(d12, sh);
+	df6 = block_sum_256(df6, sh);
+	df12 = block_sum_256(df12, sh);
 	if (threadIdx.x == 0) {
+		double s6 = 0, s12 = 0, f6 = 0, f12 = 0;
+		for (int k = 0; k <= 6; ++k) {
+			s6 += kBinom6[k] * m[k] * m[6 - k];
+			f6 += kBinom6[k] * mf[k] * mf[6 - k];
+		}
+		for (int k = 0; k <= 12; ++k) {
+			s12 += kBinom12[k] * m[k] * m[12 - k];
+			f12 += kBinom12[k] * mf[k] * mf[12 - k];
+		}
+		const double p6 = (0.5 * (s6 - d6) - 0.5 * (f6 - df6)) / 64.0;       // sum_{pairs} eps_ij sig_ij^6
+		const double p12 = (0.5 * (s12 - d12) - 0.5 * (f12 - df12)) / 4096.0; // sum_{pairs} eps_ij sig_ij^12
+		const double rc3 = bx.cutoff * bx.cutoff * bx.cutoff, rc9 = rc3 * rc3 * rc3;
+		scal[S_LRC_PAIR] = rd_lrc ? (16.0 / 3.0) * kPi * (p12 / (3.0 * rc9) - p6 / rc3) / bx.volume : 0.0;
 		scal[S_ES_RECIP] = e * (4.0 * kPi / bx.volume);
 		scal[S_ES_SELF] = self;
 		scal[S_LRC_SELF] = lrc;
@@ -226,9 +230,9 @@ __global__ __launch_bounds__(256) void k_recip_energy(AtomsDev at, RecipDev rc, 
 void launch_recip_sf(hipStream_t st, const AtomsDev &at, const RecipDev &rc) {
 	if (rc.K > 0) hipLaunchKernelGGL(k_recip_sf, dim3(rc.K), dim3(256), 0, st, at, rc);
 }
-void launch_recip_energy(hipStream_t st, const AtomsDev &at, const RecipDev &rc, const Box &bx, double ewald_alpha, int rd_lrc, int do_es,
-                         double *scal) {
-	hipLaunchKernelGGL(k_recip_energy, dim3(1), dim3(256), 0, st, at, rc, bx, ewald_alpha, rd_lrc, do_es, scal);
+void launch_atom_terms(hipStream_t st, const AtomsDev &at, const RecipDev &rc, const Box &bx, double ewald_alpha, int rd_lrc, int do_es,
+                       double *scal) {
+	hipLaunchKernelGGL(k_atom_terms, dim3(1), dim3(256), 0, st, at, rc, bx, ewald_alpha, rd_lrc, do_es, scal);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -254,55 +258,6 @@ __global__ __launch_bounds__(64) void k_field_recip(AtomsDev at, RecipDev rc, do
 		ez += kw.z * g;
 	}
 	double *o = e_part + ((size_t)blockIdx.y * at.n_pad + i) * 3;
-	o[0] = ex;
-	o[1] = ey;
-	o[2] = ez;
-}
-
-// real-space / no-PBC static field: thread i accumulates over the j-tiles of its split (ordered pairs, so no
-// cross-lane accumulation is needed; E_i += f q_j dimg(i,j) holds for j < i as well because dimg is odd in d).
-template <bool ORTHO, bool EWALD>
-__global__ __launch_bounds__(64) void k_field_real(AtomsDev at, Box bx, double alpha_p, int tiles_per_split, double *__restrict__ part) {
-	__shared__ double4 s_xyzq[kTile];
-	__shared__ int2 s_mf[kTile];
-	const int lane = threadIdx.x;
-	const int i = blockIdx.x * kTile + lane;
-	const int nt = at.n_pad / kTile;
-	const int t0 = blockIdx.y * tiles_per_split, t1 = min(nt, t0 + tiles_per_split);
-	const double4 pi = at.xyzq[i];
-	const int2 mi = at.mf[i];
-	const bool i_real = !(mi.y & AF_PAD);
-	const double rc = bx.cutoff;
-	double ex = 0, ey = 0, ez = 0;
-	for (int t = t0; t < t1; ++t) {
-		__syncthreads();
-		s_xyzq[lane] = at.xyzq[t * kTile + lane];
-		s_mf[lane] = at.mf[t * kTile + lane];
-		__syncthreads();
-		for (int jj = 0; jj < kTile; ++jj) {
-			const int2 mj = s_mf[jj];
-			const int j = t * kTile + jj;
-			if (!i_real || (mj.y & (AF_PAD | AF_ZERO_Q)) || j == i) continue; // q_j == 0 contributes exactly 0
-			const PairFlags f = pair_flags(mi.x, mi.y, mj.x, mj.y);
-			if (f.frozen) continue; // :2915, :3311
-			if (!EWALD && f.intra) continue; // :3313
-			const double4 pj = s_xyzq[jj];
-			double ox, oy, oz;
-			const double r = min_image<ORTHO>(bx, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, ox, oy, oz);
-			double fac;
-			if (EWALD) {
-				if ((r > rc) || (r == 0.0)) continue; // :2917
-				fac = field_real_factor(r, alpha_p, f.es_excluded) * pj.w;
-			} else {
-				if (!((r - kSmallDR < rc) && (r != 0.0))) continue; // :3319
-				fac = pj.w / (r * r * r);
-			}
-			ex += fac * ox;
-			ey += fac * oy;
-			ez += fac * oz;
-		}
-	}
-	double *o = part + ((size_t)blockIdx.y * at.n_pad + i) * 3;
 	o[0] = ex;
 	o[1] = ey;
 	o[2] = ez;
@@ -359,23 +314,6 @@ __global__ __launch_bounds__(512) void k_field_finalize(AtomsDev at, Box bx, int
 
 void launch_field_recip(hipStream_t st, const AtomsDev &at, const RecipDev &rc, double *e_recip_part) {
 	hipLaunchKernelGGL(k_field_recip, dim3(at.n_pad / kTile, kKSplit), dim3(kTile), 0, st, at, rc, e_recip_part);
-}
-
-void launch_field_real(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, double alpha_p, int n_split, double *part) {
-	const int nt = at.n_pad / kTile;
-	const int tps = (nt + n_split - 1) / n_split;
-	dim3 grid(nt, n_split), block(kTile);
-	if (polar_ewald) {
-		if (bx.ortho)
-			hipLaunchKernelGGL((k_field_real<true, true>), grid, block, 0, st, at, bx, alpha_p, tps, part);
-		else
-			hipLaunchKernelGGL((k_field_real<false, true>), grid, block, 0, st, at, bx, alpha_p, tps, part);
-	} else {
-		if (bx.ortho)
-			hipLaunchKernelGGL((k_field_real<true, false>), grid, block, 0, st, at, bx, alpha_p, tps, part);
-		else
-			hipLaunchKernelGGL((k_field_real<false, false>), grid, block, 0, st, at, bx, alpha_p, tps, part);
-	}
 }
 
 void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip_part, const double *part,

@@ -101,7 +101,7 @@ __device__ __forceinline__ double erfc_and_gauss(double x, double &e) {
 // ------------------------------------------------------------------------------------------------------
 template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP>
 __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedParams fp, const int2 *__restrict__ tile_pairs,
-                                                   double *__restrict__ block_part, int *__restrict__ block_cnt,
+                                                   const int *__restrict__ cls, double *__restrict__ block_part, int *__restrict__ block_cnt,
                                                    double *__restrict__ fpart /*[nt][n_pad][3]*/, double2 *__restrict__ ab) {
 	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_q[kTile], s_sig[kTile], s_sqe[kTile];
 	__shared__ int s_mol[kTile], s_fl[kTile];
@@ -113,6 +113,26 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 	const int i = IJ.x * kTile + lane;
 	const int j0 = IJ.y * kTile;
 	const int src4 = ((lane + 1) & 63) * 4;
+	// tile-pair class (wave-uniform): whole tile pair beyond the cutoff / beyond the Thole damping range
+	const int cl = cls[blockIdx.x];
+	const bool beyond = (cl & CLS_BEYOND_CUTOFF) != 0;
+	const bool store_thole = THOLE && !(cl & CLS_THOLE_FAR);
+	if (beyond && !store_thole) { // nothing position dependent to do: publish zeros so the fixed-shape reductions stay valid
+		if (FIELD != 0) {
+			const int nt_pad3 = at.n_pad * 3;
+			double *oi = fpart + (size_t)IJ.y * nt_pad3 + 3 * (size_t)i;
+			double *oj = fpart + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + lane);
+			oi[0] = oi[1] = oi[2] = 0.0;
+			oj[0] = oj[1] = oj[2] = 0.0;
+		}
+		if (lane == 0) {
+			block_part[2 * (size_t)blockIdx.x] = 0.0;
+			block_part[2 * (size_t)blockIdx.x + 1] = 0.0;
+			block_cnt[2 * (size_t)blockIdx.x] = 0;
+			block_cnt[2 * (size_t)blockIdx.x + 1] = 0;
+		}
+		return;
+	}
 
 	const double4 pi = at.xyzq[i];
 	const double2 li = at.lj[i];
@@ -133,18 +153,17 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 	__syncthreads();
 
 	const bool i_real = !(mi.y & AF_PAD);
-	const double rc = bx.cutoff;
 	const bool same_alpha = (fp.polar_ewald_alpha == fp.ewald_alpha);
 	const double lam = fp.polar_damp, lam2 = lam * lam, lam3 = lam2 * lam;
-	double e_lj = 0, e_lrc = 0, e_re = 0, e_in = 0;
-	int n_lj = 0, n_es = 0, n_intra = 0, n_rdx = 0, n_esx = 0, n_fr = 0;
+	double e_lj = 0, e_re = 0;
+	int n_lj = 0, n_es = 0;
 	double eix = 0, eiy = 0, eiz = 0; // field on my i-atom
 	double gx = 0, gy = 0, gz = 0;    // field on the j-atom currently paired with this lane (rotates)
 
 	// step order: diagonal tiles s = 1..32; off-diagonal tiles walk all 64 steps starting at a per-block offset
 	// (multiple of 4) so that concurrently running waves do not hit the same HBM channels in lock step
 	const int s_first = diag ? 1 : stagger_start(blockIdx.x), n_steps = diag ? 32 : 64;
-	double2 *ab_tile = THOLE ? ab + (size_t)blockIdx.x * (kTile * kTile) : nullptr;
+	double2 *ab_tile = store_thole ? ab + (size_t)blockIdx.x * (kTile * kTile) : nullptr;
 
 	for (int k = 0; k < n_steps; ++k) {
 		const int s = diag ? (s_first + k) : ((s_first + k) & 63);
@@ -156,10 +175,6 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 		if (act) {
 			const int molj = s_mol[jl];
 			const PairFlags f = pair_flags(mi.x, mi.y, molj, flj);
-			n_intra += f.intra;
-			n_rdx += f.rd_excluded;
-			n_esx += f.es_excluded;
-			n_fr += f.frozen;
 			const double qj = s_q[jl];
 			const double dx = pi.x - s_x[jl], dy = pi.y - s_y[jl], dz = pi.z - s_z[jl];
 			double ox, oy, oz;
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 			const bool in_lj = (ri2 <= bx.t_lj); // rimg - 1e-12 < rc
 			const bool in_es = (ri2 <= bx.t_es); // !(rimg > rc)
 
-			if (THOLE) { // thole_amatrix couples every pair: no cutoff, no exclusions, frozen included (:2694-2767)
+			if (store_thole) { // thole_amatrix couples every pair: no cutoff, no exclusions, frozen included (:2694-2767)
 				double ir3, ir5;
 				if (ri2 == 0.0) {
 					ir3 = ir5 = kMaxValue;
@@ -185,10 +200,9 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 				tb = 3.0 * damp2 * ir5;
 			}
 
-			if (!f.frozen) {
+			if (!f.frozen && !beyond) {
 				double sig, eps;
 				lj_mix(mi.y, flj, li.x, li.y, s_sig[jl], s_sqe[jl], sig, eps);
-				if (fp.rd_lrc && eps != 0.0 && sig != 0.0) e_lrc += lrc_term(sig, eps, rc, bx.volume);
 				if (in_lj && !f.rd_excluded) {
 					const double sr = sig * ir;
 					double s6 = sr * sr * sr;
@@ -206,12 +220,7 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 					if (es_pair) {
 						e_re += qq * erfc_a * ir;
 						n_es++;
-					} else if (f.es_excluded && qq != 0.0) { // charge-to-screen term, plain (non-image) distance (:1503-1504)
-						const double r02 = ((dx * dx) + dy * dy) + dz * dz;
-						const double ir0 = fast_rsqrt(r02);
-						double g0;
-						e_in += qq * (1.0 - erfc_and_gauss(fp.ewald_alpha * (r02 * ir0), g0)) * ir0; // erf = 1 - erfc
-					}
+					} // (the intramolecular charge-to-screen term, :1503-1504, is summed by k_intra_terms)
 					if (FIELD == 1 && fld_pair) { // real_term :2916-2934
 						const double ap = fp.polar_ewald_alpha;
 						double fac;
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 				}
 			}
 		}
-		if (THOLE) ab_tile[s * kTile + lane] = make_double2(ta, tb);
+		if (store_thole) ab_tile[s * kTile + lane] = make_double2(ta, tb);
 		if (FIELD != 0 && !last) {
 			gx = rot_from_next<DPP>(gx, src4);
 			gy = rot_from_next<DPP>(gy, src4);
@@ -278,61 +287,154 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 	}
 
 	e_lj = wave_sum(e_lj);
-	e_lrc = wave_sum(e_lrc);
 	e_re = wave_sum(e_re);
-	e_in = wave_sum(e_in);
 	n_lj = wave_sum_i(n_lj);
 	n_es = wave_sum_i(n_es);
-	n_intra = wave_sum_i(n_intra);
-	n_rdx = wave_sum_i(n_rdx);
-	n_esx = wave_sum_i(n_esx);
-	n_fr = wave_sum_i(n_fr);
 	if (lane == 0) {
-		double *bp = block_part + 4 * (size_t)blockIdx.x;
-		bp[0] = e_lj;
-		bp[1] = e_lrc;
-		bp[2] = e_re;
-		bp[3] = e_in;
-		int *bc = block_cnt + 6 * (size_t)blockIdx.x;
-		bc[0] = n_lj;
-		bc[1] = n_es;
-		bc[2] = n_intra;
-		bc[3] = n_rdx;
-		bc[4] = n_esx;
-		bc[5] = n_fr;
+		block_part[2 * (size_t)blockIdx.x] = e_lj;
+		block_part[2 * (size_t)blockIdx.x + 1] = e_re;
+		block_cnt[2 * (size_t)blockIdx.x] = n_lj;
+		block_cnt[2 * (size_t)blockIdx.x + 1] = n_es;
 	}
 }
 
 template <bool ORTHO, bool ES, int FIELD, bool THOLE>
-static void launch_fused_t(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, int ntp,
-                           double *bpart, int *bcnt, double *fpart, double2 *ab) {
+static void launch_fused_t(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, const int *cls,
+                           int ntp, double *bpart, int *bcnt, double *fpart, double2 *ab) {
 	if (dpp)
-		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, bpart, bcnt, fpart, ab);
+		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
 	else
-		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, bpart, bcnt, fpart, ab);
+		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
 }
 
 template <bool ORTHO>
-static void launch_fused_o(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, int ntp,
-                           double *bpart, int *bcnt, double *fpart, double2 *ab) {
+static void launch_fused_o(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, const int *cls,
+                           int ntp, double *bpart, int *bcnt, double *fpart, double2 *ab) {
 	const bool thole = fp.do_thole && ab;
 	if (!fp.do_es)
-		launch_fused_t<ORTHO, false, 0, false>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
+		launch_fused_t<ORTHO, false, 0, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
 	else if (fp.do_field == 0)
-		launch_fused_t<ORTHO, true, 0, false>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
+		launch_fused_t<ORTHO, true, 0, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
 	else if (fp.do_field == 1) {
-		if (thole) launch_fused_t<ORTHO, true, 1, true>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
-		else launch_fused_t<ORTHO, true, 1, false>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
+		if (thole) launch_fused_t<ORTHO, true, 1, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
+		else launch_fused_t<ORTHO, true, 1, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
 	} else {
-		if (thole) launch_fused_t<ORTHO, true, 2, true>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
-		else launch_fused_t<ORTHO, true, 2, false>(st, dpp, at, bx, fp, tp, ntp, bpart, bcnt, fpart, ab);
+		if (thole) launch_fused_t<ORTHO, true, 2, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
+		else launch_fused_t<ORTHO, true, 2, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
 	}
 }
 
 void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
-                       int n_tile_pairs, double *block_part, int *block_cnt, double *fpart, double2 *ab) {
-	if (bx.ortho) launch_fused_o<true>(st, dpp, at, bx, fp, tile_pairs, n_tile_pairs, block_part, block_cnt, fpart, ab);
-	else launch_fused_o<false>(st, dpp, at, bx, fp, tile_pairs, n_tile_pairs, block_part, block_cnt, fpart, ab);
+                       const int *cls, int n_tile_pairs, double *block_part, int *block_cnt, double *fpart, double2 *ab) {
+	if (bx.ortho) launch_fused_o<true>(st, dpp, at, bx, fp, tile_pairs, cls, n_tile_pairs, block_part, block_cnt, fpart, ab);
+	else launch_fused_o<false>(st, dpp, at, bx, fp, tile_pairs, cls, n_tile_pairs, block_part, block_cnt, fpart, ab);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// intramolecular charge-to-screen term of coulombic_real (:1503-1504): sum over non-frozen same-molecule pairs of
+// q_i q_j erf(alpha r)/r with the PLAIN distance, whatever the cutoff.  Molecules are contiguous runs of the original
+// atom order (validated in mpmc_set_atoms), so the sum is O(N * atoms per molecule).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_intra_terms(AtomsDev at, const int *__restrict__ slot_of, double alpha, double *__restrict__ scal) {
+	__shared__ double sh[4];
+	double acc = 0;
+	for (int i = threadIdx.x; i < at.n; i += 256) {
+		const int si = slot_of[i];
+		const int2 mi = at.mf[si];
+		const double4 pi = at.xyzq[si];
+		for (int j = i + 1; j < at.n; ++j) {
+			const int sj = slot_of[j];
+			const int2 mj = at.mf[sj];
+			if (mj.x != mi.x) break;
+			if (mi.y & mj.y & AF_FROZEN) continue;
+			const double4 pj = at.xyzq[sj];
+			const double qq = pi.w * pj.w;
+			if (qq == 0.0) continue;
+			const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+			const double r2 = ((dx * dx) + dy * dy) + dz * dz;
+			const double ir = fast_rsqrt(r2);
+			double g;
+			acc += qq * (1.0 - erfc_and_gauss(alpha * (r2 * ir), g)) * ir; // erf = 1 - erfc
+		}
+	}
+	acc = wave_sum(acc);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) scal[S_ES_INTRA] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+void launch_intra_terms(hipStream_t st, const AtomsDev &at, const int *slot_of, double ewald_alpha, double *scal) {
+	hipLaunchKernelGGL(k_intra_terms, dim3(1), dim3(256), 0, st, at, slot_of, ewald_alpha, scal);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// tile bounding boxes in wrapped fractional coordinates and tile-pair classes (orthorhombic cells only)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_tile_bounds(AtomsDev at, Box bx, double *__restrict__ tb /*[nt][6]*/) {
+	const int lane = threadIdx.x;
+	const int k = blockIdx.x * kTile + lane;
+	const double4 p = at.xyzq[k];
+	const bool real = !(at.mf[k].y & AF_PAD);
+	double lo[3], hi[3];
+	const double pos[3] = {p.x, p.y, p.z};
+	for (int d = 0; d < 3; ++d) {
+		double f = bx.r[4 * d] * pos[d]; // diagonal cell: fractional coordinate
+		f -= floor(f);
+		lo[d] = real ? f : 2.0;
+		hi[d] = real ? f : -1.0;
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		for (int d = 0; d < 3; ++d) {
+			lo[d] = fmin(lo[d], __shfl_down(lo[d], off, 64));
+			hi[d] = fmax(hi[d], __shfl_down(hi[d], off, 64));
+		}
+	if (lane == 0)
+		for (int d = 0; d < 3; ++d) {
+			tb[6 * (size_t)blockIdx.x + d] = lo[d];
+			tb[6 * (size_t)blockIdx.x + 3 + d] = hi[d];
+		}
+}
+
+__global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb, const int2 *__restrict__ tile_pairs, int ntp, Box bx,
+                                                  double thr_cut2, double thr_far2, int *__restrict__ cls) {
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	if (t >= ntp) return;
+	const int2 IJ = tile_pairs[t];
+	int c = 0;
+	if (IJ.x != IJ.y) {
+		double d2 = 0;
+		for (int d = 0; d < 3; ++d) {
+			const double a0 = tb[6 * (size_t)IJ.x + d], a1 = tb[6 * (size_t)IJ.x + 3 + d];
+			const double b0 = tb[6 * (size_t)IJ.y + d], b1 = tb[6 * (size_t)IJ.y + 3 + d];
+			double gap = 0.0; // distance between the two intervals on the unit circle
+			if (a1 < b0) gap = fmin(b0 - a1, a0 + 1.0 - b1);
+			else if (b1 < a0) gap = fmin(a0 - b1, b0 + 1.0 - a1);
+			gap = fmax(0.0, gap - 1e-12); // rounding guard: the bound must stay a LOWER bound
+			const double L = fabs(bx.b[4 * d]);
+			d2 += (L * gap) * (L * gap);
+		}
+		if (d2 > thr_cut2) c |= CLS_BEYOND_CUTOFF;
+		if (thr_far2 > 0.0 && d2 > thr_far2) c |= CLS_THOLE_FAR;
+	}
+	cls[t] = c;
+}
+
+void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, const int2 *tile_pairs, int n_tile_pairs, double polar_damp,
+                         double *tile_bounds, int *cls) {
+	if (!bx.ortho) {
+		(void)hipMemsetAsync(cls, 0, (size_t)n_tile_pairs * sizeof(int), st);
+		return;
+	}
+	const double tmax = (bx.t_lj > bx.t_es) ? bx.t_lj : bx.t_es;
+	const double thr_cut2 = tmax * (1.0 + 1e-9);
+	double thr_far2 = 0.0;
+	if (polar_damp > 0.0) {
+		const double rf = kTholeFarX / polar_damp;
+		thr_far2 = rf * rf * (1.0 + 1e-9);
+	}
+	hipLaunchKernelGGL(k_tile_bounds, dim3(at.n_pad / kTile), dim3(kTile), 0, st, at, bx, tile_bounds);
+	hipLaunchKernelGGL(k_classify, dim3((n_tile_pairs + 255) / 256), dim3(256), 0, st, tile_bounds, tile_pairs, n_tile_pairs, bx, thr_cut2,
+	                   thr_far2, cls);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -342,9 +444,9 @@ void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &
 // ------------------------------------------------------------------------------------------------------
 template <bool ORTHO, bool DPP>
 __global__ __launch_bounds__(64) void k_dipole_iter_compact(AtomsDev at, Box bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
-                                                            int n_tile_pairs, const double2 *__restrict__ ab,
+                                                            const int *__restrict__ cls, int n_tile_pairs, const double2 *__restrict__ ab,
                                                             double *__restrict__ part /*[nt][n_pad][3]*/) {
-	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_mx[kTile], s_my[kTile], s_mz[kTile];
+	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_mx[kTile], s_my[kTile], s_mz[kTile], s_v[kTile];
 	__shared__ double s_g[3 * kTile];
 	const int lane = threadIdx.x;
 	// one tile pair per block, or (persistent launch, gridDim < n_tile_pairs) a strided walk over them
@@ -366,8 +468,11 @@ __global__ __launch_bounds__(64) void k_dipole_iter_compact(AtomsDev at, Box bx,
 		s_mx[lane] = mu[3 * (size_t)(j0 + lane)];
 		s_my[lane] = mu[3 * (size_t)(j0 + lane) + 1];
 		s_mz[lane] = mu[3 * (size_t)(j0 + lane) + 2];
+		s_v[lane] = (at.mf[j0 + lane].y & AF_PAD) ? 0.0 : 1.0;
 	}
 	__syncthreads();
+	const bool far = (cls[tp] & CLS_THOLE_FAR) != 0; // wave-uniform: beyond the damping range, nothing was stored
+	const double vi = (at.mf[i].y & AF_PAD) ? 0.0 : 1.0;
 
 	const double2 *__restrict__ abt = ab + (size_t)tp * (kTile * kTile) + lane;
 	double fx = 0, fy = 0, fz = 0, gx = 0, gy = 0, gz = 0;
@@ -376,9 +481,9 @@ __global__ __launch_bounds__(64) void k_dipole_iter_compact(AtomsDev at, Box bx,
 	// software pipeline: the (a,b) of the NEXT 4 steps are in flight while the current 4 are applied
 	double2 cur[4], nxt[4];
 #pragma unroll
-	for (int u = 0; u < 4; ++u) cur[u] = ld_stream<true>(abt + (diag ? (s_first + u) : ((s_first + u) & 63)) * kTile);
+	for (int u = 0; u < 4; ++u) cur[u] = far ? make_double2(0.0, 0.0) : ld_stream<true>(abt + (diag ? (s_first + u) : ((s_first + u) & 63)) * kTile);
 	for (int kc = 0; kc < n_steps; kc += 4) {
-		const bool more = (kc + 4 < n_steps);
+		const bool more = !far && (kc + 4 < n_steps);
 		if (more) {
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
@@ -390,7 +495,7 @@ __global__ __launch_bounds__(64) void k_dipole_iter_compact(AtomsDev at, Box bx,
 		for (int u = 0; u < 4; ++u) {
 			const int s = diag ? (s_first + kc + u) : ((s_first + kc + u) & 63);
 			const int jl = (lane + s) & 63;
-			const double2 t = cur[u];
+			double2 t = cur[u];
 			// displacement as VALUES only (no predicate here): the image index is the reference's rint(R d), the
 			// back-projection may be fused
 			const double dx = pi.x - s_x[jl], dy = pi.y - s_y[jl], dz = pi.z - s_z[jl];
@@ -401,6 +506,13 @@ __global__ __launch_bounds__(64) void k_dipole_iter_compact(AtomsDev at, Box bx,
 				oz = fma(-bx.b[8], rint(bx.r[8] * dz), dz);
 			} else {
 				(void)min_image_sq<false>(bx, dx, dy, dz, ox, oy, oz);
+			}
+			if (far) { // undamped dipole tensor: a = 1/r^3, b = 3/r^5 (damping < 1e-13 beyond lambda r = 40)
+				const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
+				const double ir = fast_rsqrt(r2);
+				const double ir2 = ir * ir;
+				t.x = (vi * s_v[jl]) * (ir2 * ir);
+				t.y = 3.0 * t.x * ir2;
 			}
 			const double mjx = s_mx[jl], mjy = s_my[jl], mjz = s_mz[jl];
 			const double dj = t.y * fma(oz, mjz, fma(oy, mjy, ox * mjx));
@@ -447,14 +559,14 @@ __global__ __launch_bounds__(64) void k_dipole_iter_compact(AtomsDev at, Box bx,
 }
 
 void launch_dipole_iter_compact(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                                int n_tile_pairs, const double2 *ab, double *part) {
+                                const int *cls, int n_tile_pairs, const double2 *ab, double *part) {
 	dim3 grid(n_tile_pairs), block(kTile);
 	if (bx.ortho) {
-		if (dpp) hipLaunchKernelGGL((k_dipole_iter_compact<true, true>), grid, block, 0, st, at, bx, mu, tile_pairs, n_tile_pairs, ab, part);
-		else hipLaunchKernelGGL((k_dipole_iter_compact<true, false>), grid, block, 0, st, at, bx, mu, tile_pairs, n_tile_pairs, ab, part);
+		if (dpp) hipLaunchKernelGGL((k_dipole_iter_compact<true, true>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
+		else hipLaunchKernelGGL((k_dipole_iter_compact<true, false>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
 	} else {
-		if (dpp) hipLaunchKernelGGL((k_dipole_iter_compact<false, true>), grid, block, 0, st, at, bx, mu, tile_pairs, n_tile_pairs, ab, part);
-		else hipLaunchKernelGGL((k_dipole_iter_compact<false, false>), grid, block, 0, st, at, bx, mu, tile_pairs, n_tile_pairs, ab, part);
+		if (dpp) hipLaunchKernelGGL((k_dipole_iter_compact<false, true>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
+		else hipLaunchKernelGGL((k_dipole_iter_compact<false, false>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
 	}
 }
 
