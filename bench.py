@@ -177,43 +177,71 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # per-kernel device time from HIP events on each bead's stream
-    agg = {}
-    for s in beads:
-        for k, tv in s.timings().items():
-            a = agg.setdefault(k, {"ms": 0.0, "launches": 0})
-            a["ms"] += tv["ms"]
-            a["launches"] += tv["launches"]
+    def collect():
+        agg = {}
+        for s in beads:
+            for k, tv in s.timings(reset=True).items():
+                a = agg.setdefault(k, {"ms": 0.0, "launches": 0})
+                a["ms"] += tv["ms"]
+                a["launches"] += tv["launches"]
+        return agg
+
+    # per-kernel device time from HIP events on each bead's stream, over the timed region
+    agg = collect()
     iters = int(beads[0].observables.get("polar_iterations", 0)) if beads else 0
     mem_total, mem_tensor = beads[0].memory_usage() if beads else (0, 0)
+    tiles = beads[0].tile_stats() if beads else {"tile_pairs": 0, "thole_stored": 0, "thole_far": 0, "beyond_cutoff": 0}
+
+    # the same kernels with NOTHING else on the GPU: one extra, untimed pass, one bead at a time (HIP events again).
+    # In the timed region up to 32 beads are in flight on 32 streams, so an event pair there brackets a kernel that shares
+    # the GPU with other beads' kernels.
+    iso = None
+    if rank == 0 and args.concurrency == "async":
+        for s in beads[: min(4, len(beads))]:
+            s.energy()
+        iso = collect()
+    if world > 1:
+        dist.barrier()
+
+    n_pairs_all = n * (n - 1) // 2
+    n_pairs_stored = tiles["thole_stored"] * 4096
+    n_pairs_far = tiles["thole_far"] * 4096
+
+    def roofline_of(name, tv, label):
+        """roofline of one kernel class from its HIP-event time.  Algorithmic figures (DESIGN.md §3):
+        dipole_iter (k_dipole_iter_stream): HBM -- 16 B per stored unordered pair + 80 B per atom (positions, dipoles in, field out)
+        dipole_far  (k_dipole_iter_far)   : fp64 -- 49 flop per far-field pair (min-image 9, r^2 5, 1/r^3 & 3/r^5 11, two dots 10, two applications 14)
+        pair        (k_pair_fused)        : fp64 -- 120 flop per pair (min-image 9, r^2 5, 1/r 8, LJ 9, erfc polynomial + Gaussian 45,
+                                            Coulomb 3, field factor + both atoms 17, Thole damping + tensor 24, averaged over the in-cutoff fraction)"""
+        avg_ms = tv["ms"] / max(tv["launches"], 1)
+        sec = avg_ms * 1e-3
+        if name == "dipole_iter":
+            alg = 16.0 * n_pairs_stored + n * 80.0
+            ach = alg / sec / 1e9 if sec > 0 else 0.0
+            return {"bound": "hbm", "kernel": "k_dipole_iter_stream", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "avg_launch_ms": avg_ms, "launches": tv["launches"], "algorithmic_bytes_per_launch": alg, "measured": label}
+        flops = 49.0 * n_pairs_far if name == "dipole_far" else 120.0 * n_pairs_all
+        ach = flops / sec / 1e12 if sec > 0 else 0.0
+        return {"bound": "mfma", "kernel": "k_dipole_iter_far" if name == "dipole_far" else "k_pair_fused", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches": tv["launches"],
+                "algorithmic_flops_per_launch": flops, "measured": label,
+                "note": "fp64 compute bound: MI355X fp64 matrix (v_mfma_f64) and vector peaks are both 78.6 TFLOP/s; the kernel issues v_fma_f64"}
 
     if rank == 0:
         evals = P * args.steps
         value = evals / dt
-        it = agg.get("dipole_iter", {"ms": 0.0, "launches": 0})
-        avg_ms = it["ms"] / max(it["launches"], 1)
-        n_pairs = n * (n - 1) // 2
-        # algorithmic HBM bytes of ONE dipole-iteration launch (DESIGN.md §kernels):
-        #   COMPACT store: 16 B per unordered pair (a = d1/r^3, b = 3 d2/r^5) + atom records and mu in/out
-        #   MATRIX_FREE  : atom records (32 B) + mu (24 B) in, partial field out: nothing per pair
         solver_used = "compact" if mem_tensor > 0 else "matrix_free"
-        if solver_used == "compact":
-            alg_bytes = 16.0 * n_pairs + n * (32 + 24 + 24)
-        else:
-            alg_bytes = n * (32 + 24 + 24)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # fp64 work of the matrix-free kernel: ~90 flop-equivalent VALU ops per ordered pair (DESIGN.md)
-        flops = 90.0 * n * (n - 1)
-        roof = {"bound": "hbm", "kernel": "k_dipole_iter_" + ("compact" if solver_used == "compact" else "mf"), "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_ms": avg_ms, "launches": it["launches"], "algorithmic_bytes_per_launch": alg_bytes,
-                "concurrency": args.concurrency, "beads_per_gpu": len(beads)}
-        if solver_used == "matrix_free":
-            roof["note"] = ("matrix-free solver: the kernel is fp64-VALU-bound, its algorithmic HBM traffic is only the atom arrays; "
-                            "valu_fp64 gives the compute-side fraction")
-            roof["valu_fp64"] = {"achieved_tflops": flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                                 "frac": (flops / (avg_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if avg_ms > 0 else 0.0,
-                                 "flops_per_launch": flops}
+        label = f"HIP events over the timed region ({args.concurrency}: {len(beads)} beads in flight on this GPU)"
+        cand = [k for k in ("dipole_iter", "dipole_far", "pair") if agg.get(k, {}).get("launches")]
+        dom = max(cand, key=lambda k: agg[k]["ms"]) if cand else "dipole_iter"
+        roof = roofline_of(dom, agg.get(dom, {"ms": 0.0, "launches": 0}), label)
+        roof["share_of_device_time"] = agg[dom]["ms"] / max(sum(v["ms"] for v in agg.values()), 1e-30) if cand else 0.0
+        roof["tile_pairs"] = tiles
+        roof["other_kernels"] = {k: roofline_of(k, agg[k], label) for k in cand if k != dom}
+        if iso is not None:
+            lab2 = "HIP events, extra untimed pass with one bead at a time (kernel alone on the GPU)"
+            roof["isolated"] = {k: roofline_of(k, iso[k], lab2) for k in cand if iso.get(k, {}).get("launches")}
+            roof["isolated_kernel_ms"] = {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in iso.items() if tv["launches"]}
         cpu = cpu_baseline(args.cpu_baseline, {**atoms, "pos": bead_positions(atoms["pos"], 0)}, basis, opts, workdir) if world == 1 else None
         out = {
             "metric": "energy-evals/sec (10k-atom LJ+Ewald+polar box); 1/2/4/8-GPU scaling",

@@ -130,10 +130,11 @@ typedef struct mpmc_result {
 #define MPMC_K_PAIR 0        /* LJ + real-space Coulomb pair kernel                 */
 #define MPMC_K_RECIP 1       /* structure factors + reciprocal energy + atom terms  */
 #define MPMC_K_FIELD 2       /* static field (recip + real, or nopbc)               */
-#define MPMC_K_TENSOR 3      /* Thole tensor store build (COMPACT / DENSE solvers)  */
-#define MPMC_K_DIPOLE_ITER 4 /* one launch per Jacobi iteration                     */
-#define MPMC_K_REDUCE 5      /* final reductions / polarization energy              */
-#define MPMC_K_COUNT 6
+#define MPMC_K_TENSOR 3      /* dense thole_amatrix rows (mpmc_thole_amatrix)        */
+#define MPMC_K_DIPOLE_ITER 4 /* Jacobi contraction, stored tensors streamed (one launch per iteration; MATRIX_FREE: its kernel) */
+#define MPMC_K_REDUCE 5      /* dipole update / final reductions / polarization energy */
+#define MPMC_K_DIPOLE_FAR 6  /* Jacobi contraction, far-field tile pairs recomputed (one launch per iteration) */
+#define MPMC_K_COUNT 7
 typedef struct mpmc_timings {
 	double ms[MPMC_K_COUNT];      /* summed elapsed milliseconds                                           */
 	int64_t launches[MPMC_K_COUNT]; /* number of timed launches                                            */
@@ -208,6 +209,11 @@ int mpmc_get_timings(mpmc_ctx *ctx, mpmc_timings *out, int reset);
 int mpmc_synchronize(mpmc_ctx *ctx);
 /* bytes of device memory held by the context and by its Thole tensor store */
 int mpmc_memory_usage(mpmc_ctx *ctx, int64_t *total_bytes, int64_t *tensor_store_bytes);
+
+/* tile-pair statistics of the LAST evaluation (64 x 64 atom tiles; orthorhombic cells are classified by the
+ * minimum-image distance between tile bounding boxes): out4 = { tile pairs, pairs whose Thole tensors are stored and
+ * streamed (64 KiB each), pairs beyond the damping range (bare dipole tensor recomputed), pairs wholly beyond the cutoff } */
+int mpmc_get_tile_stats(mpmc_ctx *ctx, int64_t out4[4]);
 
 #ifdef __cplusplus
 }

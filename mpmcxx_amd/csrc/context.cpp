@@ -29,6 +29,12 @@ struct EvPair {
 struct mpmc_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	// second stream for work that is independent of the main chain inside ONE evaluation (reciprocal space next to the
+	// pair sweep; the far-field Jacobi kernel next to the streaming one); always joined back before results are used
+	hipStream_t stream2 = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	bool two_streams = true; // MPMC_ONE_STREAM=1 disables the fork/join
+	bool jacobi_hybrid = true; // one launch per Jacobi iteration over all tile pairs; MPMC_JACOBI=split: two kernels (stream / far)
 	int max_atoms = 0, max_pad = 0;
 	int n = 0, n_pad = 0, n_tiles = 0, n_tile_pairs = 0, n_split = 1;
 	int n_molecules = 0;
@@ -57,6 +63,7 @@ struct mpmc_ctx {
 	double *d_block_part = nullptr; // [ntp][2]
 	int *d_block_cnt = nullptr;     // [ntp][4] (2 used by the pair kernel, 4 by the static-count kernel)
 	int *d_cls = nullptr;           // tile-pair classes (CLS_*), recomputed every evaluation
+	int *d_lists = nullptr;         // [2 ntp] work lists of the two Jacobi kernels + [2] their lengths (at the end)
 	double *d_tile_bounds = nullptr; // [n_tiles][6]
 	size_t cap_tile_pairs = 0;
 	long long static_cnt[4] = {0, 0, 0, 0}; // n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent)
@@ -140,7 +147,7 @@ static int fail(mpmc_ctx *c, int code, const std::string &msg) {
 }
 
 // ---- profiling ------------------------------------------------------------------------------------------
-static void prof_begin(mpmc_ctx *c, int cls, int &cur) {
+static void prof_begin(mpmc_ctx *c, int cls, int &cur, hipStream_t st) {
 	cur = -1;
 	if (!c->prof) return;
 	EvPair e;
@@ -151,12 +158,12 @@ static void prof_begin(mpmc_ctx *c, int cls, int &cur) {
 		if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
 	}
 	e.cls = cls;
-	(void)hipEventRecord(e.a, c->stream);
+	(void)hipEventRecord(e.a, st);
 	c->ev_used.push_back(e);
 	cur = (int)c->ev_used.size() - 1;
 }
-static void prof_end(mpmc_ctx *c, int cur) {
-	if (cur >= 0 && cur < (int)c->ev_used.size()) (void)hipEventRecord(c->ev_used[cur].b, c->stream);
+static void prof_end(mpmc_ctx *c, int cur, hipStream_t st) {
+	if (cur >= 0 && cur < (int)c->ev_used.size()) (void)hipEventRecord(c->ev_used[cur].b, st);
 }
 static void prof_harvest(mpmc_ctx *c) { // stream must be idle
 	for (auto &e : c->ev_used) {
@@ -169,12 +176,25 @@ static void prof_harvest(mpmc_ctx *c) { // stream must be idle
 	}
 	c->ev_used.clear();
 }
-struct ProfScope {
+struct ProfScope { // HIP-event bracket on the stream the kernels are launched on
 	mpmc_ctx *c;
 	int cur;
-	ProfScope(mpmc_ctx *c_, int cls) : c(c_) { prof_begin(c, cls, cur); }
-	~ProfScope() { prof_end(c, cur); }
+	hipStream_t st;
+	ProfScope(mpmc_ctx *c_, int cls, hipStream_t st_ = nullptr) : c(c_), st(st_ ? st_ : c_->stream) { prof_begin(c, cls, cur, st); }
+	~ProfScope() { prof_end(c, cur, st); }
 };
+// side stream: starts after everything enqueued so far on the main stream / main stream waits for the side stream
+static hipStream_t fork_side(mpmc_ctx *c) {
+	if (!c->two_streams) return c->stream;
+	(void)hipEventRecord(c->ev_fork, c->stream);
+	(void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+	return c->stream2;
+}
+static void join_side(mpmc_ctx *c) {
+	if (!c->two_streams) return;
+	(void)hipEventRecord(c->ev_join, c->stream2);
+	(void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+}
 
 // ---- library --------------------------------------------------------------------------------------------
 extern "C" int mpmc_abi_version(void) { return MPMC_ABI_VERSION; }
@@ -304,10 +324,15 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	mpmc_default_options(&c->opts);
 	int rc = MPMC_OK;
 	auto A = [&](int r) { if (rc == MPMC_OK) rc = r; };
-	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
 		delete c;
 		return fail(nullptr, MPMC_ERR_HIP, "mpmc_ctx_create: hipStreamCreate failed");
 	}
+	if (const char *e = std::getenv("MPMC_ONE_STREAM")) c->two_streams = !(e[0] == '1');
+	if (const char *e = std::getenv("MPMC_JACOBI")) c->jacobi_hybrid = (e[0] != 's');
 	const size_t P = (size_t)c->max_pad;
 	A(dev_alloc(c, &c->d_xyzq, P));
 	A(dev_alloc(c, &c->d_lj, P));
@@ -338,12 +363,16 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	if (!c) return MPMC_ERR_ARG;
 	(void)hipSetDevice(c->device);
+	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	for (auto &e : c->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tile_bounds};
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tile_bounds, c->d_lists};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (c->h_scal) (void)hipHostFree(c->h_scal);
@@ -567,11 +596,13 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 		dev_free(c, &c->d_block_part, 2 * c->cap_tile_pairs);
 		dev_free(c, &c->d_block_cnt, 4 * c->cap_tile_pairs);
 		dev_free(c, &c->d_cls, c->cap_tile_pairs);
+		dev_free(c, &c->d_lists, 2 * c->cap_tile_pairs + 2);
 		c->cap_tile_pairs = 0;
 		if ((rc = dev_alloc(c, &c->d_tile_pairs, ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_block_part, 2 * ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_block_cnt, 4 * ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_cls, ntp)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_lists, 2 * ntp + 2)) != MPMC_OK) return rc;
 		HIP_TRY(c, hipMemset(c->d_cls, 0, ntp * sizeof(int)));
 		c->cap_tile_pairs = ntp;
 	}
@@ -797,6 +828,23 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 	}
 	const bool compact = (mask & RUN_SOLVE) && c->solver_used == MPMC_SOLVER_COMPACT;
 
+	// ---- reciprocal space + O(N) atom terms on the side stream, next to the pair sweep ------------------------------
+	const bool need_sf = (mask & RUN_RECIP) || ((mask & RUN_FIELD) && o.polar_ewald);
+	const bool side_work = need_sf || (mask & RUN_ATOMTERMS);
+	if (side_work) {
+		hipStream_t s2 = fork_side(c);
+		{
+			ProfScope p(c, MPMC_K_RECIP, s2);
+			if (need_sf) launch_recip_sf(s2, at, rcp);
+			if (mask & (RUN_RECIP | RUN_ATOMTERMS))
+				launch_atom_terms(s2, at, rcp, c->box, c->ewald_alpha, (mask & RUN_ATOMTERMS) ? o.rd_lrc : 0, (mask & RUN_RECIP) ? 1 : 0, c->d_scal);
+		}
+		if ((mask & RUN_FIELD) && o.polar_ewald) {
+			ProfScope p(c, MPMC_K_FIELD, s2);
+			launch_field_recip(s2, at, rcp, c->d_e_recip_part);
+		}
+	}
+
 	// ---- pairwise pass: one symmetric sweep (energies + counts, static-field partials, Thole tensor store) ----------
 	if (mask & (RUN_PAIR | RUN_FIELD)) {
 		ProfScope p(c, MPMC_K_PAIR);
@@ -812,6 +860,7 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		fp.do_es = ((mask & RUN_PAIR_ES) || (mask & RUN_FIELD)) ? 1 : 0;
 		fp.do_field = (mask & RUN_FIELD) ? (o.polar_ewald ? 1 : 2) : 0;
 		fp.do_thole = compact ? 1 : 0;
+		if (compact) launch_build_lists(st, c->d_cls, c->n_tile_pairs, c->d_lists, c->d_lists + 2 * (size_t)c->n_tile_pairs);
 		launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
 		                  compact ? c->d_ab : nullptr);
 		if (mask & RUN_PAIR) {
@@ -819,20 +868,11 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 			if (mask & RUN_PAIR_ES) launch_intra_terms(st, at, c->d_slot_of, c->ewald_alpha, c->d_scal);
 		}
 	}
-
-	// ---- reciprocal space + O(N) atom terms ------------------------------------------------------------------
-	const bool need_sf = (mask & RUN_RECIP) || ((mask & RUN_FIELD) && o.polar_ewald);
-	if (need_sf || (mask & RUN_ATOMTERMS)) {
-		ProfScope p(c, MPMC_K_RECIP);
-		if (need_sf) launch_recip_sf(st, at, rcp);
-		if (mask & (RUN_RECIP | RUN_ATOMTERMS))
-			launch_atom_terms(st, at, rcp, c->box, c->ewald_alpha, (mask & RUN_ATOMTERMS) ? o.rd_lrc : 0, (mask & RUN_RECIP) ? 1 : 0, c->d_scal);
-	}
+	if (side_work) join_side(c);
 
 	// ---- static field ---------------------------------------------------------------------------------------
 	if (mask & RUN_FIELD) {
 		ProfScope p(c, MPMC_K_FIELD);
-		if (o.polar_ewald) launch_field_recip(st, at, rcp, c->d_e_recip_part);
 		c->mu_cur = 0;
 		launch_field_finalize(st, at, c->box, o.polar_ewald, c->d_e_recip_part, c->d_part, c->n_tiles, o.polar_gamma, c->d_e_static,
 		                      c->d_mu[0]);
@@ -854,13 +894,25 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 				break;
 			}
 			if (by_precision) HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
-			{
+			if (compact && c->jacobi_hybrid) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
-				if (compact)
-					launch_dipole_iter_compact(st, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_ab,
-					                           c->d_part);
-				else
-					launch_dipole_iter_mf(st, at, c->box, o.polar_damp, c->d_mu[c->mu_cur], c->n_split, c->d_part);
+				launch_dipole_iter_hybrid(st, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_ab, c->d_part);
+			} else if (compact) {
+				const int *counts = c->d_lists + 2 * (size_t)c->n_tile_pairs;
+				hipStream_t s2 = fork_side(c); // the fp64-bound far-field kernel runs beside the HBM-bound streaming kernel
+				{
+					ProfScope p(c, MPMC_K_DIPOLE_FAR, s2);
+					launch_dipole_iter_far(s2, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_lists, counts, c->n_tile_pairs, c->d_part);
+				}
+				{
+					ProfScope p(c, MPMC_K_DIPOLE_ITER);
+					launch_dipole_iter_stream(st, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_lists, counts, c->n_tile_pairs,
+					                          c->d_ab, c->d_part);
+				}
+				join_side(c);
+			} else {
+				ProfScope p(c, MPMC_K_DIPOLE_ITER);
+				launch_dipole_iter_mf(st, at, c->box, o.polar_damp, c->d_mu[c->mu_cur], c->n_split, c->d_part);
 			}
 			{
 				ProfScope p(c, MPMC_K_REDUCE);
@@ -1146,6 +1198,23 @@ extern "C" int mpmc_synchronize(mpmc_ctx *c) {
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return MPMC_OK;
 }
+extern "C" int mpmc_get_tile_stats(mpmc_ctx *c, int64_t out4[4]) {
+	if (!c || !out4) return MPMC_ERR_ARG;
+	if (!c->atoms_set || !c->d_cls) return fail(c, MPMC_ERR_ARG, "mpmc_get_tile_stats: no evaluation has run");
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	std::vector<int> cls((size_t)c->n_tile_pairs);
+	HIP_TRY(c, hipMemcpy(cls.data(), c->d_cls, cls.size() * sizeof(int), hipMemcpyDeviceToHost));
+	out4[0] = c->n_tile_pairs;
+	out4[1] = out4[2] = out4[3] = 0;
+	for (int v : cls) {
+		if (v & CLS_THOLE_FAR) out4[2]++;
+		else out4[1]++;
+		if (v & CLS_BEYOND_CUTOFF) out4[3]++;
+	}
+	return MPMC_OK;
+}
+
 extern "C" int mpmc_memory_usage(mpmc_ctx *c, int64_t *total, int64_t *tensor) {
 	if (!c) return MPMC_ERR_ARG;
 	if (total) *total = c->bytes_total;

@@ -95,9 +95,16 @@ void launch_intra_terms(hipStream_t st, const AtomsDev &at, const int *slot_of, 
 // per-tile bounding boxes (wrapped fractional coordinates) and tile-pair classes (CLS_*)
 void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, const int2 *tile_pairs, int n_tile_pairs, double polar_damp,
                          double *tile_bounds /*[nt][6]*/, int *cls);
-// one Jacobi contraction streaming the store: part[nt][n_pad][3]
-void launch_dipole_iter_compact(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                                const int *cls, int n_tile_pairs, const double2 *ab, double *part);
+// work lists of the two Jacobi kernels from the class array: lists[0..ntp) stored tile pairs, lists[ntp..2ntp) far ones
+void launch_build_lists(hipStream_t st, const int *cls, int n_tile_pairs, int *lists /*[2 ntp]*/, int *counts /*[2]*/);
+// one Jacobi contraction = these two launches (each partial slot is written by exactly one of them): part[nt][n_pad][3]
+void launch_dipole_iter_stream(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+                               const int *lists, const int *counts, int n_tile_pairs, const double2 *ab, double *part);
+void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+                            const int *lists, const int *counts, int n_tile_pairs, double *part);
+// single-launch alternative (all tile pairs, class read per block)
+void launch_dipole_iter_hybrid(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+                               const int *cls, int n_tile_pairs, const double2 *ab, double *part);
 // lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
 void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm);
 

@@ -75,11 +75,33 @@ void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm) {
 	hipLaunchKernelGGL(k_rot_selftest, dim3(1), dim3(64), 0, st, out_dpp, out_perm);
 }
 
+// One Horner step p*t + c with the constant in an SGPR pair.  hipcc's own choice for fma(p, t, literal) on gfx950 is
+// "2 x v_mov_b32 (literal -> VGPR pair) + v_fmac_f64", i.e. three VALU issues per step; v_fma_f64 may read one SGPR operand,
+// and s_mov_b32 runs on the scalar unit, so this form costs ONE VALU issue per step.
+__device__ __forceinline__ double hstep(double p, double t, double c) {
+	double o;
+	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(t), "s"(c));
+	return o;
+}
+
+// exp(x) = 2^k exp(r), k = rint(x log2 e), r = x - k ln2 (two-part ln2), exp(r) by the degree-11 polynomial of
+// tools/fit_erfcx.py on [-ln2/2, ln2/2] (rel. err 1.6e-15).  Arguments here are <= 0 (Gaussian, Thole damping).
+__device__ __forceinline__ double exp_fast(double x) {
+	const double k = rint(x * 1.4426950408889634);
+	double r = fma(-k, 6.93147180369123816490e-01, x);
+	r = fma(-k, 1.90821492927058770002e-10, r);
+	constexpr double e[MPMC_EXP_DEG + 1] = {MPMC_EXP_COEFFS};
+	double p = e[MPMC_EXP_DEG];
+#pragma unroll
+	for (int i = MPMC_EXP_DEG - 1; i >= 0; --i) p = hstep(p, r, e[i]);
+	return ldexp(p, (int)k);
+}
+
 // erfc(x) = exp(-x^2) * erfcx(x) for every x >= 0; (1+2x) erfcx(x) is the degree-20 polynomial of tools/fit_erfcx.py in
 // t = (x-K)/(x+K) (rel. err < 1e-14), so there is no range branch and no libm erfc/erf in the kernel.
 // Also returns e = exp(-x^2), which the Ewald field term needs anyway.
 __device__ __forceinline__ double erfc_and_gauss(double x, double &e) {
-	e = exp(-x * x);
+	e = exp_fast(-x * x);
 	constexpr double c[MPMC_ERFCX_DEG + 1] = {MPMC_ERFCX_COEFFS};
 	const double d1 = x + MPMC_ERFCX_K, d2 = fma(2.0, x, 1.0);
 	const double den = d1 * d2;
@@ -89,9 +111,11 @@ __device__ __forceinline__ double erfc_and_gauss(double x, double &e) {
 	const double t = (x - MPMC_ERFCX_K) * (d2 * inv); // (x-K)/(x+K)
 	double p = c[MPMC_ERFCX_DEG];
 #pragma unroll
-	for (int k = MPMC_ERFCX_DEG - 1; k >= 0; --k) p = fma(p, t, c[k]);
+	for (int k = MPMC_ERFCX_DEG - 1; k >= 0; --k) p = hstep(p, t, c[k]);
 	return e * (p * (d1 * inv)); // p / (1+2x)
 }
+// out-of-line copy for the rare second evaluation (user-set polar_ewald_alpha != ewald_alpha)
+__device__ __noinline__ double erfc_and_gauss_cold(double x, double &e) { return erfc_and_gauss(x, e); }
 
 // ------------------------------------------------------------------------------------------------------
 // fused symmetric pair kernel
@@ -193,7 +217,7 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 					ir5 = ir3 * ir * ir;
 				}
 				const double rr = (ri2 == 0.0) ? 0.0 : r;
-				const double explr = exp(-lam * rr);
+				const double explr = exp_fast(-lam * rr);
 				const double damp1 = 1.0 - explr * (0.5 * lam2 * ri2 + lam * rr + 1.0);
 				const double damp2 = damp1 - explr * (lam3 * ri2 * rr / 6.0);
 				ta = damp1 * ir3;
@@ -213,26 +237,20 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 				}
 				if (ES) {
 					const double qq = pi.w * qj;
+					const bool es_pair = in_es && !f.es_excluded; // coulombic_real :1490
+					const bool fld_pair = (FIELD == 1) && in_es && (ri2 != 0.0) && !(pi.w == 0.0 && qj == 0.0); // real_term :2916-2917
 					double erfc_a = 0.0, gauss_a = 0.0;
-					const bool es_pair = in_es && !f.es_excluded;
-					const bool fld_pair = (FIELD == 1) && in_es && (ri2 != 0.0) && !(pi.w == 0.0 && qj == 0.0);
-					if (es_pair || (fld_pair && same_alpha && !f.es_excluded)) erfc_a = erfc_and_gauss(fp.ewald_alpha * r, gauss_a);
+					if (es_pair || (fld_pair && same_alpha)) erfc_a = erfc_and_gauss(fp.ewald_alpha * r, gauss_a); // the ONE erfc of this pair
 					if (es_pair) {
 						e_re += qq * erfc_a * ir;
 						n_es++;
 					} // (the intramolecular charge-to-screen term, :1503-1504, is summed by k_intra_terms)
-					if (FIELD == 1 && fld_pair) { // real_term :2916-2934
+					if (FIELD == 1 && fld_pair) { // real_term :2919-2934: erfc form, or erf form (= 1 - erfc) for es_excluded pairs
 						const double ap = fp.polar_ewald_alpha;
-						double fac;
-						if (f.es_excluded) { // erf form (:2921); erf = 1 - erfc from the same polynomial
-							double ga;
-							const double ec = erfc_and_gauss(ap * r, ga);
-							fac = (2.0 * ap * kOneOverSqrtPi * ga * r - (1.0 - ec)) * (ir * ir * ir);
-						} else {
-							double ec = erfc_a, ga = gauss_a;
-							if (!same_alpha) ec = erfc_and_gauss(ap * r, ga);
-							fac = (2.0 * ap * kOneOverSqrtPi * ga * r + ec) * (ir * ir * ir);
-						}
+						double ec = erfc_a, ga = gauss_a;
+						if (!same_alpha) ec = erfc_and_gauss_cold(ap * r, ga);
+						const double g = 2.0 * ap * kOneOverSqrtPi * ga * r;
+						const double fac = (f.es_excluded ? (g - (1.0 - ec)) : (g + ec)) * (ir * ir * ir);
 						const double fj = fac * qj, fi = fac * pi.w;
 						eix += fj * ox;
 						eiy += fj * oy;
@@ -438,12 +456,259 @@ void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, cons
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Jacobi contraction streaming the compact tensor store (reference contract_dipoles :3564-3598 over the A matrix of
-// thole_amatrix :2661-2770):  for the pair (i,j):  F_i -= a mu_j - b d (d.mu_j),   F_j -= a mu_i - b d (d.mu_i)
-// Entries of masked pairs were stored as (0,0), so the loop carries no predicates at all.
+// tile-pair work lists of the two Jacobi kernels: stable compaction of the class array (single block, fixed order,
+// so the block -> tile pair map is the same in every launch)
+//   lists[0 .. ntp)        tile pairs whose tensors are stored (inside the damping range, diagonal tiles included)
+//   lists[ntp .. 2 ntp)    tile pairs beyond the damping range
+//   counts[0], counts[1]   their lengths
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_build_lists(const int *__restrict__ cls, int ntp, int *__restrict__ lists, int *__restrict__ counts) {
+	__shared__ int s_near[1024], s_far[1024];
+	const int t = threadIdx.x;
+	const int per = (ntp + 1023) / 1024;
+	const int b0 = t * per, b1 = min(ntp, b0 + per);
+	int nn = 0, nf = 0;
+	for (int k = b0; k < b1; ++k) {
+		if (cls[k] & CLS_THOLE_FAR) nf++;
+		else nn++;
+	}
+	s_near[t] = nn;
+	s_far[t] = nf;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1) { // inclusive Hillis-Steele scan
+		const int vn = (t >= off) ? s_near[t - off] : 0, vf = (t >= off) ? s_far[t - off] : 0;
+		__syncthreads();
+		s_near[t] += vn;
+		s_far[t] += vf;
+		__syncthreads();
+	}
+	int on = s_near[t] - nn, of = s_far[t] - nf;
+	for (int k = b0; k < b1; ++k) {
+		if (cls[k] & CLS_THOLE_FAR) lists[ntp + of++] = k;
+		else lists[on++] = k;
+	}
+	if (t == 1023) {
+		counts[0] = s_near[1023];
+		counts[1] = s_far[1023];
+	}
+}
+void launch_build_lists(hipStream_t st, const int *cls, int n_tile_pairs, int *lists, int *counts) {
+	hipLaunchKernelGGL(k_build_lists, dim3(1), dim3(1024), 0, st, cls, n_tile_pairs, lists, counts);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// One Jacobi contraction (reference contract_dipoles :3564-3598 over the A matrix of thole_amatrix :2661-2770).
+// For the pair (i,j):   F_i -= a mu_j - b d (d.mu_j),   F_j -= a mu_i - b d (d.mu_i),   T = a I - b d(x)d.
+//
+//   k_dipole_iter_stream  tile pairs inside the damping range: (a,b) streamed from the compact store, 16 B per
+//                         unordered pair, each block 64 KiB contiguous.  HBM-bound by construction: 33 flop per 16 B.
+//                         Masked pairs were stored as (0,0): the loop carries no predicates.
+//   k_dipole_iter_far     tile pairs beyond lambda r = 40: damping < 1e-13, a = 1/r^3, b = 3/r^5 recomputed from the
+//                         positions (v_rsq_f64 + 1 Newton step).  fp64-bound, no HBM traffic beyond the atom tiles.
+// Both write the partial slots [source tile][atom] of the same buffer; every slot is written exactly once per
+// iteration by exactly one of the two kernels.
+// ------------------------------------------------------------------------------------------------------
+template <bool ORTHO>
+__device__ __forceinline__ void image_vec(const Box &bx, double dx, double dy, double dz, double &ox, double &oy, double &oz) {
+	// displacement as VALUES only (no predicate here): the image index is the reference's rint(R d), the back-projection may be fused
+	if (ORTHO) {
+		ox = fma(-bx.b[0], rint(bx.r[0] * dx), dx);
+		oy = fma(-bx.b[4], rint(bx.r[4] * dy), dy);
+		oz = fma(-bx.b[8], rint(bx.r[8] * dz), dz);
+	} else {
+		(void)min_image_sq<false>(bx, dx, dy, dz, ox, oy, oz);
+	}
+}
+
+template <bool ORTHO, bool DPP>
+__global__ __launch_bounds__(64) void k_dipole_iter_stream(AtomsDev at, Box bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
+                                                           const int *__restrict__ list, const int *__restrict__ count,
+                                                           const double2 *__restrict__ ab, double *__restrict__ part /*[nt][n_pad][3]*/) {
+	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_mx[kTile], s_my[kTile], s_mz[kTile];
+	__shared__ double s_g[3 * kTile];
+	if ((int)blockIdx.x >= count[0]) return;
+	const int lane = threadIdx.x;
+	const int tp = list[blockIdx.x];
+	const int2 IJ = tile_pairs[tp];
+	const bool diag = (IJ.x == IJ.y);
+	const int i = IJ.x * kTile + lane;
+	const int j0 = IJ.y * kTile;
+	const int src4 = ((lane + 1) & 63) * 4;
+
+	const double4 pi = at.xyzq[i];
+	const double mix = mu[3 * (size_t)i], miy = mu[3 * (size_t)i + 1], miz = mu[3 * (size_t)i + 2];
+	{
+		const double4 pj = at.xyzq[j0 + lane];
+		s_x[lane] = pj.x;
+		s_y[lane] = pj.y;
+		s_z[lane] = pj.z;
+		s_mx[lane] = mu[3 * (size_t)(j0 + lane)];
+		s_my[lane] = mu[3 * (size_t)(j0 + lane) + 1];
+		s_mz[lane] = mu[3 * (size_t)(j0 + lane) + 2];
+	}
+	__syncthreads();
+
+	const double2 *__restrict__ abt = ab + (size_t)tp * (kTile * kTile) + lane;
+	double fx = 0, fy = 0, fz = 0, gx = 0, gy = 0, gz = 0;
+	// 64 steps (off-diagonal, staggered start) or 32 steps (diagonal, s = 1..32): always whole chunks of 4
+	const int s_first = diag ? 1 : stagger_start(tp), n_steps = diag ? 32 : 64;
+	// software pipeline: the (a,b) of the NEXT 4 steps are in flight while the current 4 are applied
+	double2 cur[4], nxt[4];
+#pragma unroll
+	for (int u = 0; u < 4; ++u) cur[u] = ld_stream<true>(abt + (diag ? (s_first + u) : ((s_first + u) & 63)) * kTile);
+	for (int kc = 0; kc < n_steps; kc += 4) {
+		const bool more = (kc + 4 < n_steps);
+		if (more) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int sn = diag ? (s_first + kc + 4 + u) : ((s_first + kc + 4 + u) & 63);
+				nxt[u] = ld_stream<true>(abt + sn * kTile);
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int s = diag ? (s_first + kc + u) : ((s_first + kc + u) & 63);
+			const int jl = (lane + s) & 63;
+			const double2 t = cur[u];
+			double ox, oy, oz;
+			image_vec<ORTHO>(bx, pi.x - s_x[jl], pi.y - s_y[jl], pi.z - s_z[jl], ox, oy, oz);
+			const double mjx = s_mx[jl], mjy = s_my[jl], mjz = s_mz[jl];
+			const double dj = t.y * fma(oz, mjz, fma(oy, mjy, ox * mjx));
+			const double di = t.y * fma(oz, miz, fma(oy, miy, ox * mix));
+			fx = fma(-t.x, mjx, fma(dj, ox, fx));
+			fy = fma(-t.x, mjy, fma(dj, oy, fy));
+			fz = fma(-t.x, mjz, fma(dj, oz, fz));
+			gx = fma(-t.x, mix, fma(di, ox, gx));
+			gy = fma(-t.x, miy, fma(di, oy, gy));
+			gz = fma(-t.x, miz, fma(di, oz, gz));
+			if (kc + u != n_steps - 1) {
+				gx = rot_from_next<DPP>(gx, src4);
+				gy = rot_from_next<DPP>(gy, src4);
+				gz = rot_from_next<DPP>(gz, src4);
+			}
+		}
+		if (more) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+		}
+	}
+	const int jl_last = (lane + s_first + n_steps - 1) & 63;
+	const int nt_pad3 = at.n_pad * 3;
+	if (diag) {
+		s_g[3 * jl_last + 0] = gx;
+		s_g[3 * jl_last + 1] = gy;
+		s_g[3 * jl_last + 2] = gz;
+		__syncthreads();
+		double *o = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)i;
+		o[0] = fx + s_g[3 * lane + 0];
+		o[1] = fy + s_g[3 * lane + 1];
+		o[2] = fz + s_g[3 * lane + 2];
+	} else {
+		double *oi = part + (size_t)IJ.y * nt_pad3 + 3 * (size_t)i;
+		oi[0] = fx;
+		oi[1] = fy;
+		oi[2] = fz;
+		double *oj = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + jl_last);
+		oj[0] = gx;
+		oj[1] = gy;
+		oj[2] = gz;
+	}
+}
+
+template <bool ORTHO, bool DPP>
+__global__ __launch_bounds__(64) void k_dipole_iter_far(AtomsDev at, Box bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
+                                                        const int *__restrict__ list, const int *__restrict__ count,
+                                                        double *__restrict__ part /*[nt][n_pad][3]*/) {
+	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_mx[kTile], s_my[kTile], s_mz[kTile], s_v[kTile];
+	if ((int)blockIdx.x >= count[1]) return;
+	const int lane = threadIdx.x;
+	const int tp = list[blockIdx.x];
+	const int2 IJ = tile_pairs[tp]; // never a diagonal tile (distance 0 is not "far")
+	const int i = IJ.x * kTile + lane;
+	const int j0 = IJ.y * kTile;
+	const int src4 = ((lane + 1) & 63) * 4;
+
+	const double4 pi = at.xyzq[i];
+	const double vi = (at.mf[i].y & AF_PAD) ? 0.0 : 1.0;
+	const double mix = mu[3 * (size_t)i], miy = mu[3 * (size_t)i + 1], miz = mu[3 * (size_t)i + 2];
+	{
+		const double4 pj = at.xyzq[j0 + lane];
+		s_x[lane] = pj.x;
+		s_y[lane] = pj.y;
+		s_z[lane] = pj.z;
+		s_mx[lane] = mu[3 * (size_t)(j0 + lane)];
+		s_my[lane] = mu[3 * (size_t)(j0 + lane) + 1];
+		s_mz[lane] = mu[3 * (size_t)(j0 + lane) + 2];
+		s_v[lane] = (at.mf[j0 + lane].y & AF_PAD) ? 0.0 : 1.0;
+	}
+	__syncthreads();
+
+	double fx = 0, fy = 0, fz = 0, gx = 0, gy = 0, gz = 0;
+#pragma unroll 4
+	for (int s = 0; s < kTile; ++s) {
+		const int jl = (lane + s) & 63;
+		double ox, oy, oz;
+		image_vec<ORTHO>(bx, pi.x - s_x[jl], pi.y - s_y[jl], pi.z - s_z[jl], ox, oy, oz);
+		// undamped dipole tensor: a = 1/r^3, b = 3/r^5 (the damping factors differ from 1 by < 1e-13 beyond lambda r = 40)
+		const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
+		const double ir = fast_rsqrt_1(r2);
+		const double ir2 = ir * ir;
+		const double ta = (vi * s_v[jl]) * (ir2 * ir);
+		const double tb = 3.0 * ta * ir2;
+		const double mjx = s_mx[jl], mjy = s_my[jl], mjz = s_mz[jl];
+		const double dj = tb * fma(oz, mjz, fma(oy, mjy, ox * mjx));
+		const double di = tb * fma(oz, miz, fma(oy, miy, ox * mix));
+		fx = fma(-ta, mjx, fma(dj, ox, fx));
+		fy = fma(-ta, mjy, fma(dj, oy, fy));
+		fz = fma(-ta, mjz, fma(dj, oz, fz));
+		gx = fma(-ta, mix, fma(di, ox, gx));
+		gy = fma(-ta, miy, fma(di, oy, gy));
+		gz = fma(-ta, miz, fma(di, oz, gz));
+		if (s != kTile - 1) {
+			gx = rot_from_next<DPP>(gx, src4);
+			gy = rot_from_next<DPP>(gy, src4);
+			gz = rot_from_next<DPP>(gz, src4);
+		}
+	}
+	const int jl_last = (lane + kTile - 1) & 63;
+	const int nt_pad3 = at.n_pad * 3;
+	double *oi = part + (size_t)IJ.y * nt_pad3 + 3 * (size_t)i;
+	oi[0] = fx;
+	oi[1] = fy;
+	oi[2] = fz;
+	double *oj = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + jl_last);
+	oj[0] = gx;
+	oj[1] = gy;
+	oj[2] = gz;
+}
+
+void launch_dipole_iter_stream(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+                               const int *lists, const int *counts, int n_tile_pairs, const double2 *ab, double *part) {
+	dim3 grid(n_tile_pairs), block(kTile); // blocks beyond the list length exit at once (the length lives on the device)
+	if (bx.ortho) {
+		if (dpp) hipLaunchKernelGGL((k_dipole_iter_stream<true, true>), grid, block, 0, st, at, bx, mu, tile_pairs, lists, counts, ab, part);
+		else hipLaunchKernelGGL((k_dipole_iter_stream<true, false>), grid, block, 0, st, at, bx, mu, tile_pairs, lists, counts, ab, part);
+	} else {
+		if (dpp) hipLaunchKernelGGL((k_dipole_iter_stream<false, true>), grid, block, 0, st, at, bx, mu, tile_pairs, lists, counts, ab, part);
+		else hipLaunchKernelGGL((k_dipole_iter_stream<false, false>), grid, block, 0, st, at, bx, mu, tile_pairs, lists, counts, ab, part);
+	}
+}
+
+void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+                            const int *lists, const int *counts, int n_tile_pairs, double *part) {
+	if (!bx.ortho) return; // only orthorhombic cells are classified: the far list is empty
+	dim3 grid(n_tile_pairs), block(kTile);
+	const int *far_list = lists + n_tile_pairs;
+	if (dpp) hipLaunchKernelGGL((k_dipole_iter_far<true, true>), grid, block, 0, st, at, bx, mu, tile_pairs, far_list, counts, part);
+	else hipLaunchKernelGGL((k_dipole_iter_far<true, false>), grid, block, 0, st, at, bx, mu, tile_pairs, far_list, counts, part);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Single-launch form of the same contraction (MPMC_JACOBI=hybrid): one kernel walks ALL tile pairs, streaming the stored
+// ones and recomputing the far ones (wave-uniform branch), so HBM-bound and fp64-bound waves share the CUs.
 // ------------------------------------------------------------------------------------------------------
 template <bool ORTHO, bool DPP>
-__global__ __launch_bounds__(64) void k_dipole_iter_compact(AtomsDev at, Box bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
+__global__ __launch_bounds__(64) void k_dipole_iter_hybrid(AtomsDev at, Box bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
                                                             const int *__restrict__ cls, int n_tile_pairs, const double2 *__restrict__ ab,
                                                             double *__restrict__ part /*[nt][n_pad][3]*/) {
 	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_mx[kTile], s_my[kTile], s_mz[kTile], s_v[kTile];
@@ -558,15 +823,15 @@ __global__ __launch_bounds__(64) void k_dipole_iter_compact(AtomsDev at, Box bx,
 	} // tile pairs
 }
 
-void launch_dipole_iter_compact(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+void launch_dipole_iter_hybrid(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                                 const int *cls, int n_tile_pairs, const double2 *ab, double *part) {
 	dim3 grid(n_tile_pairs), block(kTile);
 	if (bx.ortho) {
-		if (dpp) hipLaunchKernelGGL((k_dipole_iter_compact<true, true>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
-		else hipLaunchKernelGGL((k_dipole_iter_compact<true, false>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
+		if (dpp) hipLaunchKernelGGL((k_dipole_iter_hybrid<true, true>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
+		else hipLaunchKernelGGL((k_dipole_iter_hybrid<true, false>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
 	} else {
-		if (dpp) hipLaunchKernelGGL((k_dipole_iter_compact<false, true>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
-		else hipLaunchKernelGGL((k_dipole_iter_compact<false, false>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
+		if (dpp) hipLaunchKernelGGL((k_dipole_iter_hybrid<false, true>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
+		else hipLaunchKernelGGL((k_dipole_iter_hybrid<false, false>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
 	}
 }
 

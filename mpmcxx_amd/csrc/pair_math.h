@@ -126,6 +126,18 @@ MPMC_HD double fast_rsqrt(double x) {
 #endif
 }
 
+// one Newton step only (~2e-14 relative): enough for the far-field dipole tensor, whose entries feed sums that are
+// compared at 1e-9
+MPMC_HD double fast_rsqrt_1(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	double y = __builtin_amdgcn_rsq(x);
+	const double e = fma(-(x * y), y, 1.0);
+	return fma(0.5 * y, e, y);
+#else
+	return 1.0 / sqrt(x);
+#endif
+}
+
 // ---- pair_exclusions, reference System.cpp:1035-1197 (Lorentz-Berthelot branch) --------------------------
 struct PairFlags {
 	bool intra, frozen, rd_excluded, es_excluded, attractive_only;

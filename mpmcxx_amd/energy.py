@@ -27,7 +27,7 @@ ERR_INVALID_SETTING = 4000
 ERR_NO_DEVICE = -1
 DAMPING = {"off": 0, "linear": 1, "exponential": 2, None: 2}
 SOLVER = {"auto": 0, "matrix_free": 1, "compact": 2, "dense": 3}
-K_NAMES = ["pair", "recip", "field", "tensor", "dipole_iter", "reduce"]
+K_NAMES = ["pair", "recip", "field", "tensor", "dipole_iter", "reduce", "dipole_far"]
 
 
 class MpmcError(RuntimeError):
@@ -63,7 +63,7 @@ class Result(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int64 * 6)]
+    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_int64 * 7)]
 
 
 _lib = None
@@ -110,6 +110,7 @@ def lib():
     L.mpmc_get_timings.argtypes = [vp, C.POINTER(Timings), C.c_int]
     L.mpmc_synchronize.argtypes = [vp]
     L.mpmc_memory_usage.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.mpmc_get_tile_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     _lib = L
     return L
 
@@ -296,10 +297,16 @@ class System:
     def timings(self, reset: bool = False) -> Dict[str, Dict[str, float]]:
         t = Timings()
         self._check(self._L.mpmc_get_timings(self._h, C.byref(t), 1 if reset else 0))
-        return {K_NAMES[i]: {"ms": t.ms[i], "launches": int(t.launches[i])} for i in range(6)}
+        return {K_NAMES[i]: {"ms": t.ms[i], "launches": int(t.launches[i])} for i in range(7)}
 
     def synchronize(self):
         self._check(self._L.mpmc_synchronize(self._h))
+
+    def tile_stats(self) -> Dict[str, int]:
+        """tile-pair classes of the last evaluation (see mpmc_get_tile_stats)."""
+        a = (C.c_int64 * 4)()
+        self._check(self._L.mpmc_get_tile_stats(self._h, a))
+        return {"tile_pairs": a[0], "thole_stored": a[1], "thole_far": a[2], "beyond_cutoff": a[3]}
 
     def memory_usage(self):
         a, b = C.c_int64(), C.c_int64()
