@@ -189,16 +189,34 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 	const int s_first = diag ? 1 : stagger_start(blockIdx.x), n_steps = diag ? 32 : 64;
 	double2 *ab_tile = store_thole ? ab + (size_t)blockIdx.x * (kTile * kTile) : nullptr;
 
+	// "plain" tile pair (wave-uniform): no atom of either tile is frozen, padded, chargeless, has a zero / negative
+	// sigma, zero epsilon or dispersion coefficients -- then the exclusion logic of pair_exclusions collapses to
+	// "same molecule" and the Lorentz-Berthelot mixing to one add and one multiply
+	constexpr int kSpecial = AF_FROZEN | AF_NULL_RD | AF_HAS_DISP | AF_NEG_SIGMA | AF_ZERO_SIGMA | AF_ZERO_Q | AF_PAD;
+	const bool plain = !__any(((mi.y | s_fl[lane]) & kSpecial) != 0);
+
 	for (int k = 0; k < n_steps; ++k) {
 		const int s = diag ? (s_first + k) : ((s_first + k) & 63);
 		const bool last = (k == n_steps - 1);
 		const int jl = (lane + s) & 63;
-		const int flj = s_fl[jl];
-		const bool act = i_real && !(flj & AF_PAD) && (!diag || s < 32 || lane < 32);
+		const int molj = s_mol[jl];
+		bool act;
+		int flj;
+		PairFlags f;
+		if (plain) {
+			flj = 0;
+			act = (!diag || s < 32 || lane < 32);
+			f.intra = (mi.x == molj);
+			f.frozen = false;
+			f.rd_excluded = f.es_excluded = f.intra;
+			f.attractive_only = false;
+		} else {
+			flj = s_fl[jl];
+			act = i_real && !(flj & AF_PAD) && (!diag || s < 32 || lane < 32);
+			f = pair_flags(mi.x, mi.y, molj, flj);
+		}
 		double ta = 0.0, tb = 0.0;
 		if (act) {
-			const int molj = s_mol[jl];
-			const PairFlags f = pair_flags(mi.x, mi.y, molj, flj);
 			const double qj = s_q[jl];
 			const double dx = pi.x - s_x[jl], dy = pi.y - s_y[jl], dz = pi.z - s_z[jl];
 			double ox, oy, oz;
@@ -217,22 +235,28 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 					ir5 = ir3 * ir * ir;
 				}
 				const double rr = (ri2 == 0.0) ? 0.0 : r;
-				const double explr = exp_fast(-lam * rr);
-				const double damp1 = 1.0 - explr * (0.5 * lam2 * ri2 + lam * rr + 1.0);
-				const double damp2 = damp1 - explr * (lam3 * ri2 * rr / 6.0);
+				const double lr = lam * rr;
+				const double explr = exp_fast(-lr);
+				const double damp1 = fma(-explr, fma(lr, fma(0.5, lr, 1.0), 1.0), 1.0);   // 1 - e^{-lr} (lr^2/2 + lr + 1)
+				const double damp2 = fma(-explr, (lr * lr) * (lr * (1.0 / 6.0)), damp1);    // damp1 - e^{-lr} lr^3/6
 				ta = damp1 * ir3;
 				tb = 3.0 * damp2 * ir5;
 			}
 
 			if (!f.frozen && !beyond) {
 				double sig, eps;
-				lj_mix(mi.y, flj, li.x, li.y, s_sig[jl], s_sqe[jl], sig, eps);
+				if (plain) {
+					sig = 0.5 * (li.x + s_sig[jl]);
+					eps = li.y * s_sqe[jl];
+				} else {
+					lj_mix(mi.y, flj, li.x, li.y, s_sig[jl], s_sqe[jl], sig, eps);
+				}
 				if (in_lj && !f.rd_excluded) {
 					const double sr = sig * ir;
 					double s6 = sr * sr * sr;
 					s6 *= s6;
 					const double t12 = f.attractive_only ? 0.0 : s6 * s6;
-					e_lj += 4.0 * eps * (t12 - s6);
+					e_lj = fma(4.0 * eps, t12 - s6, e_lj);
 					n_lj++;
 				}
 				if (ES) {
@@ -242,32 +266,32 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 					double erfc_a = 0.0, gauss_a = 0.0;
 					if (es_pair || (fld_pair && same_alpha)) erfc_a = erfc_and_gauss(fp.ewald_alpha * r, gauss_a); // the ONE erfc of this pair
 					if (es_pair) {
-						e_re += qq * erfc_a * ir;
+						e_re = fma(qq * erfc_a, ir, e_re);
 						n_es++;
 					} // (the intramolecular charge-to-screen term, :1503-1504, is summed by k_intra_terms)
 					if (FIELD == 1 && fld_pair) { // real_term :2919-2934: erfc form, or erf form (= 1 - erfc) for es_excluded pairs
 						const double ap = fp.polar_ewald_alpha;
 						double ec = erfc_a, ga = gauss_a;
 						if (!same_alpha) ec = erfc_and_gauss_cold(ap * r, ga);
-						const double g = 2.0 * ap * kOneOverSqrtPi * ga * r;
+						const double g = (2.0 * kOneOverSqrtPi * ap) * (ga * r);
 						const double fac = (f.es_excluded ? (g - (1.0 - ec)) : (g + ec)) * (ir * ir * ir);
 						const double fj = fac * qj, fi = fac * pi.w;
-						eix += fj * ox;
-						eiy += fj * oy;
-						eiz += fj * oz;
-						gx -= fi * ox;
-						gy -= fi * oy;
-						gz -= fi * oz;
+						eix = fma(fj, ox, eix);
+						eiy = fma(fj, oy, eiy);
+						eiz = fma(fj, oz, eiz);
+						gx = fma(-fi, ox, gx);
+						gy = fma(-fi, oy, gy);
+						gz = fma(-fi, oz, gz);
 					}
 					if (FIELD == 2 && !f.intra && in_lj && ri2 != 0.0) { // thole_field_nopbc :3311-3326
 						const double ir3 = ir * ir * ir;
 						const double fj = qj * ir3, fi = pi.w * ir3;
-						eix += fj * ox;
-						eiy += fj * oy;
-						eiz += fj * oz;
-						gx -= fi * ox;
-						gy -= fi * oy;
-						gz -= fi * oz;
+						eix = fma(fj, ox, eix);
+						eiy = fma(fj, oy, eiy);
+						eiz = fma(fj, oz, eiz);
+						gx = fma(-fi, ox, gx);
+						gy = fma(-fi, oy, gy);
+						gz = fma(-fi, oz, gz);
 					}
 				}
 			}
