@@ -34,6 +34,7 @@ struct mpmc_ctx {
 	hipStream_t stream2 = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	bool two_streams = true; // MPMC_ONE_STREAM=1 disables the fork/join
+	int jacc = 0; // j-side accumulation of the hybrid Jacobi kernel: 0 DPP rotation, 1 bpermute, 2 LDS ds_add_f64 (MPMC_JACC)
 	bool jacobi_hybrid = true; // one launch per Jacobi iteration over all tile pairs; MPMC_JACOBI=split: two kernels (stream / far)
 	int max_atoms = 0, max_pad = 0;
 	int n = 0, n_pad = 0, n_tiles = 0, n_tile_pairs = 0, n_split = 1;
@@ -333,6 +334,8 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	}
 	if (const char *e = std::getenv("MPMC_ONE_STREAM")) c->two_streams = !(e[0] == '1');
 	if (const char *e = std::getenv("MPMC_JACOBI")) c->jacobi_hybrid = (e[0] != 's');
+	c->jacc = c->use_dpp ? 0 : 1;
+	if (const char *e = std::getenv("MPMC_JACC")) c->jacc = std::atoi(e);
 	const size_t P = (size_t)c->max_pad;
 	A(dev_alloc(c, &c->d_xyzq, P));
 	A(dev_alloc(c, &c->d_lj, P));
@@ -896,7 +899,7 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 			if (by_precision) HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
 			if (compact && c->jacobi_hybrid) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
-				launch_dipole_iter_hybrid(st, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_ab, c->d_part);
+				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_ab, c->d_part);
 			} else if (compact) {
 				const int *counts = c->d_lists + 2 * (size_t)c->n_tile_pairs;
 				hipStream_t s2 = fork_side(c); // the fp64-bound far-field kernel runs beside the HBM-bound streaming kernel

@@ -103,7 +103,8 @@ void launch_dipole_iter_stream(hipStream_t st, bool dpp, const AtomsDev &at, con
 void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                             const int *lists, const int *counts, int n_tile_pairs, double *part);
 // single-launch alternative (all tile pairs, class read per block)
-void launch_dipole_iter_hybrid(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+// jacc: 0 DPP lane rotation, 1 ds_bpermute rotation, 2 ds_add_f64 into an LDS image of the j-atoms
+void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                                const int *cls, int n_tile_pairs, const double2 *ab, double *part);
 // lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
 void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm);

@@ -728,19 +728,23 @@ void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Single-launch form of the same contraction (MPMC_JACOBI=hybrid): one kernel walks ALL tile pairs, streaming the stored
-// ones and recomputing the far ones (wave-uniform branch), so HBM-bound and fp64-bound waves share the CUs.
+// Single-launch form of the same contraction (the default): one kernel walks ALL tile pairs, streaming the stored ones
+// and recomputing the far ones (wave-uniform branch), so HBM-bound and fp64-bound waves share the CUs.
+//   JACC selects how the j-side accumulators meet their atoms:
+//     0  registers rotated by one lane per step with v_mov_b32_dpp wave_rol:1 (6 VALU issues per step)
+//     1  the same through ds_bpermute_b32 (fallback when the DPP self-test fails)
+//     2  ds_add_f64 into an LDS image of the 64 j-atoms: the 64 lanes hit 64 different addresses in every step (no
+//        conflicts, no contention) and a wave's LDS operations execute in program order, so the sum order is fixed;
+//        the adds run in the LDS unit and cost no VALU issue.
 // ------------------------------------------------------------------------------------------------------
-template <bool ORTHO, bool DPP>
+template <bool ORTHO, int JACC>
 __global__ __launch_bounds__(64) void k_dipole_iter_hybrid(AtomsDev at, Box bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
-                                                            const int *__restrict__ cls, int n_tile_pairs, const double2 *__restrict__ ab,
+                                                            const int *__restrict__ cls, const double2 *__restrict__ ab,
                                                             double *__restrict__ part /*[nt][n_pad][3]*/) {
 	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_mx[kTile], s_my[kTile], s_mz[kTile], s_v[kTile];
-	__shared__ double s_g[3 * kTile];
+	__shared__ double s_gx[kTile], s_gy[kTile], s_gz[kTile];
 	const int lane = threadIdx.x;
-	// one tile pair per block, or (persistent launch, gridDim < n_tile_pairs) a strided walk over them
-	for (int tp = blockIdx.x; tp < n_tile_pairs; tp += gridDim.x) {
-	__syncthreads(); // the previous tile pair's LDS reads are done before its image is overwritten
+	const int tp = blockIdx.x;
 	const int2 IJ = tile_pairs[tp];
 	const bool diag = (IJ.x == IJ.y);
 	const int i = IJ.x * kTile + lane;
@@ -758,10 +762,12 @@ __global__ __launch_bounds__(64) void k_dipole_iter_hybrid(AtomsDev at, Box bx, 
 		s_my[lane] = mu[3 * (size_t)(j0 + lane) + 1];
 		s_mz[lane] = mu[3 * (size_t)(j0 + lane) + 2];
 		s_v[lane] = (at.mf[j0 + lane].y & AF_PAD) ? 0.0 : 1.0;
+		if (JACC == 2) s_gx[lane] = s_gy[lane] = s_gz[lane] = 0.0;
 	}
 	__syncthreads();
 	const bool far = (cls[tp] & CLS_THOLE_FAR) != 0; // wave-uniform: beyond the damping range, nothing was stored
 	const double vi = (at.mf[i].y & AF_PAD) ? 0.0 : 1.0;
+	const bool has_pad = (at.n != at.n_pad) && (IJ.y == at.n_pad / kTile - 1); // only the last tile holds padding slots (I <= J)
 
 	const double2 *__restrict__ abt = ab + (size_t)tp * (kTile * kTile) + lane;
 	double fx = 0, fy = 0, fz = 0, gx = 0, gy = 0, gz = 0;
@@ -785,22 +791,14 @@ __global__ __launch_bounds__(64) void k_dipole_iter_hybrid(AtomsDev at, Box bx, 
 			const int s = diag ? (s_first + kc + u) : ((s_first + kc + u) & 63);
 			const int jl = (lane + s) & 63;
 			double2 t = cur[u];
-			// displacement as VALUES only (no predicate here): the image index is the reference's rint(R d), the
-			// back-projection may be fused
-			const double dx = pi.x - s_x[jl], dy = pi.y - s_y[jl], dz = pi.z - s_z[jl];
 			double ox, oy, oz;
-			if (ORTHO) {
-				ox = fma(-bx.b[0], rint(bx.r[0] * dx), dx);
-				oy = fma(-bx.b[4], rint(bx.r[4] * dy), dy);
-				oz = fma(-bx.b[8], rint(bx.r[8] * dz), dz);
-			} else {
-				(void)min_image_sq<false>(bx, dx, dy, dz, ox, oy, oz);
-			}
+			image_vec<ORTHO>(bx, pi.x - s_x[jl], pi.y - s_y[jl], pi.z - s_z[jl], ox, oy, oz);
 			if (far) { // undamped dipole tensor: a = 1/r^3, b = 3/r^5 (damping < 1e-13 beyond lambda r = 40)
 				const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
-				const double ir = fast_rsqrt(r2);
+				const double ir = fast_rsqrt_1(r2);
 				const double ir2 = ir * ir;
-				t.x = (vi * s_v[jl]) * (ir2 * ir);
+				t.x = ir2 * ir;
+				if (has_pad) t.x *= vi * s_v[jl];
 				t.y = 3.0 * t.x * ir2;
 			}
 			const double mjx = s_mx[jl], mjy = s_my[jl], mjz = s_mz[jl];
@@ -809,13 +807,19 @@ __global__ __launch_bounds__(64) void k_dipole_iter_hybrid(AtomsDev at, Box bx, 
 			fx = fma(-t.x, mjx, fma(dj, ox, fx));
 			fy = fma(-t.x, mjy, fma(dj, oy, fy));
 			fz = fma(-t.x, mjz, fma(dj, oz, fz));
-			gx = fma(-t.x, mix, fma(di, ox, gx));
-			gy = fma(-t.x, miy, fma(di, oy, gy));
-			gz = fma(-t.x, miz, fma(di, oz, gz));
-			if (kc + u != n_steps - 1) {
-				gx = rot_from_next<DPP>(gx, src4);
-				gy = rot_from_next<DPP>(gy, src4);
-				gz = rot_from_next<DPP>(gz, src4);
+			if (JACC == 2) {
+				atomicAdd(&s_gx[jl], fma(di, ox, -(t.x * mix)));
+				atomicAdd(&s_gy[jl], fma(di, oy, -(t.x * miy)));
+				atomicAdd(&s_gz[jl], fma(di, oz, -(t.x * miz)));
+			} else {
+				gx = fma(-t.x, mix, fma(di, ox, gx));
+				gy = fma(-t.x, miy, fma(di, oy, gy));
+				gz = fma(-t.x, miz, fma(di, oz, gz));
+				if (kc + u != n_steps - 1) {
+					gx = rot_from_next<JACC == 0>(gx, src4);
+					gy = rot_from_next<JACC == 0>(gy, src4);
+					gz = rot_from_next<JACC == 0>(gz, src4);
+				}
 			}
 		}
 		if (more) {
@@ -823,40 +827,45 @@ __global__ __launch_bounds__(64) void k_dipole_iter_hybrid(AtomsDev at, Box bx, 
 			for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
 		}
 	}
-	const int jl_last = (lane + s_first + n_steps - 1) & 63;
 	const int nt_pad3 = at.n_pad * 3;
+	if (JACC != 2) { // park the rotated accumulators at their atoms' LDS slots
+		const int jl_last = (lane + s_first + n_steps - 1) & 63;
+		s_gx[jl_last] = gx;
+		s_gy[jl_last] = gy;
+		s_gz[jl_last] = gz;
+	}
+	__syncthreads();
 	if (diag) {
-		s_g[3 * jl_last + 0] = gx;
-		s_g[3 * jl_last + 1] = gy;
-		s_g[3 * jl_last + 2] = gz;
-		__syncthreads();
 		double *o = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)i;
-		o[0] = fx + s_g[3 * lane + 0];
-		o[1] = fy + s_g[3 * lane + 1];
-		o[2] = fz + s_g[3 * lane + 2];
+		o[0] = fx + s_gx[lane];
+		o[1] = fy + s_gy[lane];
+		o[2] = fz + s_gz[lane];
 	} else {
 		double *oi = part + (size_t)IJ.y * nt_pad3 + 3 * (size_t)i;
 		oi[0] = fx;
 		oi[1] = fy;
 		oi[2] = fz;
-		double *oj = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + jl_last);
-		oj[0] = gx;
-		oj[1] = gy;
-		oj[2] = gz;
+		double *oj = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + lane);
+		oj[0] = s_gx[lane];
+		oj[1] = s_gy[lane];
+		oj[2] = s_gz[lane];
 	}
-	} // tile pairs
 }
 
-void launch_dipole_iter_hybrid(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                                const int *cls, int n_tile_pairs, const double2 *ab, double *part) {
+void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+                               const int *cls, int n_tile_pairs, const double2 *ab, double *part) {
 	dim3 grid(n_tile_pairs), block(kTile);
+#define MPMC_LAUNCH_HYB(O, J) hipLaunchKernelGGL((k_dipole_iter_hybrid<O, J>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, ab, part)
 	if (bx.ortho) {
-		if (dpp) hipLaunchKernelGGL((k_dipole_iter_hybrid<true, true>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
-		else hipLaunchKernelGGL((k_dipole_iter_hybrid<true, false>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
+		if (jacc == 2) MPMC_LAUNCH_HYB(true, 2);
+		else if (jacc == 1) MPMC_LAUNCH_HYB(true, 1);
+		else MPMC_LAUNCH_HYB(true, 0);
 	} else {
-		if (dpp) hipLaunchKernelGGL((k_dipole_iter_hybrid<false, true>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
-		else hipLaunchKernelGGL((k_dipole_iter_hybrid<false, false>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, n_tile_pairs, ab, part);
+		if (jacc == 2) MPMC_LAUNCH_HYB(false, 2);
+		else if (jacc == 1) MPMC_LAUNCH_HYB(false, 1);
+		else MPMC_LAUNCH_HYB(false, 0);
 	}
+#undef MPMC_LAUNCH_HYB
 }
 
 } // namespace mpmc

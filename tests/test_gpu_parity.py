@@ -208,21 +208,26 @@ def test_spatial_order_is_transparent(monkeypatch):
 
 
 def test_set_positions_device_matches_host_upload():
-    import torch
+    """positions that already live in device memory (what a torch tensor's data_ptr() is); plain HIP calls through ctypes
+    so that the test does not depend on torch's own device discovery."""
+    import ctypes
 
+    hip = ctypes.CDLL("libamdhip64.so")
     atoms, basis, opts = util.load_fixture("ion1000_polar")
     S = energy.System(atoms, basis, opts)
     e0 = S.energy()
     rng = np.random.default_rng(3)
-    newpos = atoms["pos"] + rng.normal(scale=0.03, size=atoms["pos"].shape)
-    t = torch.tensor(newpos, dtype=torch.float64, device="cuda:0").contiguous()
-    torch.cuda.synchronize()
-    S.set_positions_device(t.data_ptr())
+    newpos = np.ascontiguousarray(atoms["pos"] + rng.normal(scale=0.03, size=atoms["pos"].shape))
+    dptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(newpos.nbytes)) == 0
+    assert hip.hipMemcpy(dptr, newpos.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(newpos.nbytes), 1) == 0  # hipMemcpyHostToDevice
+    S.set_positions_device(dptr.value)
     e1 = S.energy()
     a2 = dict(atoms)
     a2["pos"] = newpos
     T = energy.System(a2, basis, opts)
     e2 = T.energy()
-    assert e1 != e0 and util.close(e1, e2, 1e-12)
+    assert e1 != e0 and util.close(e1, e2, 1e-11)
+    hip.hipFree(dptr)
     S.close()
     T.close()
