@@ -214,6 +214,11 @@ def main():
         dist.barrier()
 
     hybrid = not agg.get("dipole_far", {}).get("launches")
+    try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            pmc_traffic = json.load(f)
+    except OSError:
+        pmc_traffic = {}
     n_pairs_all = n * (n - 1) // 2
     n_pairs_stored = tiles["thole_stored"] * 4096
     n_pairs_far = tiles["thole_far"] * 4096
@@ -232,6 +237,10 @@ def main():
             out = {"bound": "hbm", "kernel": "k_dipole_iter_hybrid" if hybrid else "k_dipole_iter_stream", "achieved": ach, "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": tv["launches"],
                    "algorithmic_bytes_per_launch": alg, "measured": label}
+            tr = pmc_traffic.get(out["kernel"])
+            if tr and tr.get("natoms") == n:
+                out["traffic"] = tr["hbm_bytes_per_launch"]
+                out["traffic_source"] = tr["source"]
             if hybrid:  # the single-launch form also recomputes the far-field tile pairs: report that work beside the bytes
                 fl = 33.0 * n_pairs_stored + 49.0 * n_pairs_far
                 tf = fl / sec / 1e12 if sec > 0 else 0.0
