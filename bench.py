@@ -206,14 +206,43 @@ def main():
     # In the timed region up to 32 beads are in flight on 32 streams, so an event pair there brackets a kernel that shares
     # the GPU with other beads' kernels.
     iso = None
-    if rank == 0 and args.concurrency == "async":
-        for s in beads[: min(4, len(beads))]:
-            s.energy()
-        iso = collect()
+    if rank == 0:
+        # two fresh contexts with the Jacobi contraction as two kernels (MPMC_JACOBI=split): k_dipole_iter_stream is the pure
+        # HBM-streaming part, k_dipole_iter_far the pure fp64 part of the default single-launch kernel
+        old = os.environ.get("MPMC_JACOBI")
+        old1 = os.environ.get("MPMC_ONE_STREAM")
+        os.environ["MPMC_JACOBI"] = "split"
+        os.environ["MPMC_ONE_STREAM"] = "1"  # no side stream either: every kernel of these contexts runs alone
+        try:
+            iso_beads = []
+            for b in mine[:2]:
+                a = dict(atoms)
+                a["pos"] = bead_positions(atoms["pos"], b)
+                iso_beads.append(energy.System(a, basis, opts, device=local_rank))
+        finally:
+            for k_, v_ in (("MPMC_JACOBI", old), ("MPMC_ONE_STREAM", old1)):
+                if v_ is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v_
+        for s in iso_beads:
+            s.energy()  # warm-up (uploads, buffers)
+        for s in iso_beads:
+            s.set_profiling(True)
+        for _ in range(2):
+            for s in iso_beads:
+                s.energy()
+        iso = {}
+        for s in iso_beads:
+            for k, tv in s.timings(reset=True).items():
+                a = iso.setdefault(k, {"ms": 0.0, "launches": 0})
+                a["ms"] += tv["ms"]
+                a["launches"] += tv["launches"]
+            s.close()
     if world > 1:
         dist.barrier()
 
-    hybrid = not agg.get("dipole_far", {}).get("launches")
+    hybrid_default = not agg.get("dipole_far", {}).get("launches")
     try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
             pmc_traffic = json.load(f)
@@ -223,7 +252,8 @@ def main():
     n_pairs_stored = tiles["thole_stored"] * 4096
     n_pairs_far = tiles["thole_far"] * 4096
 
-    def roofline_of(name, tv, label):
+    def roofline_of(name, tv, label, hybrid=None):
+        hybrid = hybrid_default if hybrid is None else hybrid
         """roofline of one kernel class from its HIP-event time.  Algorithmic figures (DESIGN.md §3):
         dipole_iter (k_dipole_iter_stream): HBM -- 16 B per stored unordered pair + 80 B per atom (positions, dipoles in, field out)
         dipole_far  (k_dipole_iter_far)   : fp64 -- 49 flop per far-field pair (min-image 9, r^2 5, 1/r^3 & 3/r^5 11, two dots 10, two applications 14)
@@ -268,8 +298,9 @@ def main():
         roof["tile_pairs"] = tiles
         roof["other_kernels"] = {k: roofline_of(k, agg[k], label) for k in cand if k != dom}
         if iso is not None:
-            lab2 = "HIP events, extra untimed pass with one bead at a time (kernel alone on the GPU)"
-            roof["isolated"] = {k: roofline_of(k, iso[k], lab2) for k in cand if iso.get(k, {}).get("launches")}
+            lab2 = ("HIP events, extra untimed pass after the timed region: one bead at a time (each kernel alone on the GPU), Jacobi contraction "
+                    "as two kernels on one stream (MPMC_JACOBI=split MPMC_ONE_STREAM=1)")
+            roof["isolated"] = {k: roofline_of(k, iso[k], lab2, hybrid=False) for k in ("dipole_iter", "dipole_far", "pair") if iso.get(k, {}).get("launches")}
             roof["isolated_kernel_ms"] = {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in iso.items() if tv["launches"]}
         cpu = cpu_baseline(args.cpu_baseline, {**atoms, "pos": bead_positions(atoms["pos"], 0)}, basis, opts, workdir) if world == 1 else None
         out = {
