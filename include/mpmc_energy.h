@@ -176,6 +176,21 @@ int mpmc_energy(mpmc_ctx *ctx, mpmc_result *out);
 int mpmc_energy_async(mpmc_ctx *ctx);
 int mpmc_energy_wait(mpmc_ctx *ctx, mpmc_result *out);
 
+/* ---- trial moves: the device-side counterpart of the reference's per-pair cache ----------------------------------------
+ * The reference re-evaluates only the pairs whose displacement changed (Pair::recalculate_energy, src/System.cpp:1211-1224,
+ * src/System.Energy.cpp:925,1484).  After a full mpmc_energy() of the accepted configuration:
+ *   mpmc_trial_begin  : atoms [first, first+count) (original order; typically one molecule) get trial positions
+ *   mpmc_trial_energy : energy of the trial configuration.  Non-polarizable boxes: O(count * N) pair terms (old and new
+ *                       geometry of every pair that involves a moved atom) + O(K * count) structure-factor update, added
+ *                       to the accepted totals.  Polarizable boxes: a full evaluation (the dipole solve is global).
+ *   mpmc_trial_accept : the trial configuration becomes the accepted one / mpmc_trial_reject : it is discarded.
+ * A full mpmc_energy() at any time re-bases the totals (the reference's flag_all_pairs, src/System.cpp:1284). */
+#define MPMC_TRIAL_MAX_ATOMS 256
+int mpmc_trial_begin(mpmc_ctx *ctx, int first, int count, const double *new_pos /*[count][3]*/);
+int mpmc_trial_energy(mpmc_ctx *ctx, mpmc_result *out);
+int mpmc_trial_accept(mpmc_ctx *ctx);
+int mpmc_trial_reject(mpmc_ctx *ctx);
+
 /* ---- public component entry points of the reference (src/System.h:346-402), for parity tests ----------- */
 int mpmc_lj(mpmc_ctx *ctx, double *out);                  /* System::lj()                   */
 int mpmc_coulombic(mpmc_ctx *ctx, double *out);           /* System::coulombic()            */

@@ -136,6 +136,31 @@ public:
 		return r.energy;
 	}
 
+	// ---- trial moves: the role of the reference's per-pair recalculate_energy cache (src/System.cpp:1211-1224) ----
+	// energy of the configuration in which atoms [first, first+count) sit at new_pos ([count][3]); then accept_trial()
+	// (atoms[].pos are updated to the trial positions) or reject_trial().  Needs a prior energy() of the accepted state.
+	double energy_trial(int first, int count, const double *new_pos) {
+		sync_state();
+		check(mpmc_trial_begin(ctx_, first, count, new_pos), "mpmc_trial_begin");
+		mpmc_result r;
+		int rc = mpmc_trial_energy(ctx_, &r);
+		if (rc != MPMC_OK) {
+			mpmc_trial_reject(ctx_);
+			check(rc, "mpmc_trial_energy");
+		}
+		trial_first_ = first;
+		trial_pos_.assign(new_pos, new_pos + 3 * (size_t)count);
+		trial_result_ = r;
+		return r.energy;
+	}
+	void accept_trial() {
+		check(mpmc_trial_accept(ctx_), "mpmc_trial_accept");
+		for (size_t k = 0; k < trial_pos_.size() / 3; k++)
+			for (int d = 0; d < 3; d++) atoms[trial_first_ + k].pos[d] = trial_pos_[3 * k + d];
+		absorb(trial_result_);
+	}
+	void reject_trial() { check(mpmc_trial_reject(ctx_), "mpmc_trial_reject"); }
+
 	double lj() { return piece(mpmc_lj); }
 	double coulombic() { return piece(mpmc_coulombic); }
 	double coulombic_real() { return piece(mpmc_coulombic_real); }
@@ -172,6 +197,9 @@ private:
 	mpmc_ctx *ctx_ = nullptr;
 	int capacity_ = 0;
 	bool atoms_dirty_ = true, box_dirty_ = true;
+	int trial_first_ = 0;
+	std::vector<double> trial_pos_;
+	mpmc_result trial_result_{};
 
 	void check(int rc, const char *what) {
 		if (rc == MPMC_OK) return;

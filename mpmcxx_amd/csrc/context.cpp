@@ -108,6 +108,20 @@ struct mpmc_ctx {
 	int iters = 0, failed = 0;
 	unsigned run_mask = 0;
 
+	// trial moves (delta energies)
+	bool cache_valid = false;   // last_full = totals of the accepted configuration, d_sf = its structure factors
+	mpmc_result last_full{};
+	mpmc_result trial_res{};
+	bool trial_open = false, trial_evaluated = false, trial_was_full = false;
+	int trial_first = 0, trial_count = 0;
+	std::vector<double> trial_new, trial_old;
+	int *d_mv_slot = nullptr, *d_mv_orig = nullptr, *d_moved_idx = nullptr; // d_mv_slot/d_mv_orig/d_mv_new live in ONE allocation (d_mv_blob)
+	double4 *d_mv_new = nullptr, *d_sf_trial = nullptr;
+	unsigned char *d_mv_blob = nullptr, *h_mv_blob = nullptr; // device / pinned host staging of a trial's moved-atom list
+	int cap_sf_trial = 0;
+	double *d_delta_out = nullptr, *h_delta_out = nullptr;
+	long long *d_delta_cnt = nullptr, *h_delta_cnt = nullptr;
+
 	// profiling
 	bool prof = false;
 	std::vector<EvPair> ev_free, ev_used;
@@ -375,12 +389,15 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tile_bounds, c->d_lists};
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
+	                c->d_sf_trial, c->d_delta_out};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (c->h_scal) (void)hipHostFree(c->h_scal);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 	if (c->h_flag) (void)hipHostFree(c->h_flag);
+	if (c->h_delta_out) (void)hipHostFree(c->h_delta_out);
+	if (c->h_mv_blob) (void)hipHostFree(c->h_mv_blob);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return MPMC_OK;
@@ -410,6 +427,7 @@ extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *re
 	c->box_set = true;
 	c->k_dirty = true;
 	c->atoms_dirty = true; // the spatial order depends on the cell
+	c->cache_valid = false;
 	return MPMC_OK;
 }
 
@@ -438,6 +456,7 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 	c->opts = *o;
 	c->opts_set = true;
 	c->k_dirty = true;
+	c->cache_valid = false;
 	return MPMC_OK;
 }
 
@@ -620,6 +639,8 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 	c->n_split = std::max(1, std::min(nt, (4096 + nt - 1) / nt));
 	c->atoms_set = true;
 	c->pending = false;
+	c->cache_valid = false;
+	c->trial_open = false;
 	return MPMC_OK;
 }
 
@@ -638,6 +659,7 @@ extern "C" int mpmc_update_positions(mpmc_ctx *c, int first, int count, const do
 		c->h_pos[3 * i + 1] = pos[3 * t + 1];
 		c->h_pos[3 * i + 2] = pos[3 * t + 2];
 	}
+	c->cache_valid = false; // the accepted totals no longer describe the resident configuration
 	if (c->atoms_dirty) return MPMC_OK; // a full (re-sorted) upload is pending anyway
 	if (count > 256) { // large updates: one full re-upload (also refreshes the spatial order)
 		c->atoms_dirty = true;
@@ -945,6 +967,8 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 	return MPMC_OK;
 }
 
+static unsigned full_mask(const mpmc_ctx *c);
+
 static int wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 	if (!c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_energy_wait: nothing enqueued");
 	HIP_TRY(c, hipSetDevice(c->device));
@@ -976,6 +1000,10 @@ static int wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 	out->n_frozen = c->static_cnt[3];
 	out->polar_iterations = c->iters;
 	out->iterator_failed = c->failed;
+	if (c->run_mask == full_mask(c)) { // a complete energy(): it re-bases the trial-move totals
+		c->last_full = *out;
+		c->cache_valid = true;
+	}
 	return MPMC_OK;
 }
 
@@ -1001,6 +1029,151 @@ extern "C" int mpmc_energy(mpmc_ctx *c, mpmc_result *out) {
 	int rc = enqueue(c, full_mask(c));
 	if (rc != MPMC_OK) return rc;
 	return wait_and_fill(c, out);
+}
+
+// ---- trial moves -----------------------------------------------------------------------------------------------
+constexpr size_t kMvBlobBytes = MPMC_TRIAL_MAX_ATOMS * (2 * sizeof(int) + sizeof(double4));
+static int ensure_trial_buffers(mpmc_ctx *c) {
+	int rc;
+	if (!c->d_mv_blob) {
+		if ((rc = dev_alloc(c, &c->d_mv_blob, kMvBlobBytes)) != MPMC_OK) return rc;
+		c->d_mv_new = reinterpret_cast<double4 *>(c->d_mv_blob); // 32-byte records first (alignment), then the two int lists
+		c->d_mv_slot = reinterpret_cast<int *>(c->d_mv_blob + MPMC_TRIAL_MAX_ATOMS * sizeof(double4));
+		c->d_mv_orig = c->d_mv_slot + MPMC_TRIAL_MAX_ATOMS;
+		if ((rc = dev_alloc(c, &c->d_moved_idx, (size_t)c->max_pad)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_delta_out, (size_t)8)) != MPMC_OK) return rc; // 5 doubles + 2 int64 counts
+		c->d_delta_cnt = reinterpret_cast<long long *>(c->d_delta_out + 5);
+		HIP_TRY(c, hipMemset(c->d_moved_idx, 0xff, (size_t)c->max_pad * sizeof(int))); // all -1
+		HIP_TRY(c, hipHostMalloc((void **)&c->h_delta_out, 8 * sizeof(double)));
+		c->h_delta_cnt = reinterpret_cast<long long *>(c->h_delta_out + 5);
+		HIP_TRY(c, hipHostMalloc((void **)&c->h_mv_blob, kMvBlobBytes));
+	}
+	if (c->K > c->cap_sf_trial) {
+		dev_free(c, &c->d_sf_trial, (size_t)c->cap_sf_trial);
+		c->cap_sf_trial = 0;
+		if ((rc = dev_alloc(c, &c->d_sf_trial, (size_t)std::max(c->K, 1))) != MPMC_OK) return rc;
+		c->cap_sf_trial = std::max(c->K, 1);
+	}
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_trial_begin(mpmc_ctx *c, int first, int count, const double *new_pos) {
+	if (!c || !new_pos || first < 0 || count <= 0) return MPMC_ERR_ARG;
+	if (!c->atoms_set || first + count > c->n) return fail(c, MPMC_ERR_ARG, "mpmc_trial_begin: range outside the atom list");
+	if (c->trial_open) return fail(c, MPMC_ERR_ARG, "mpmc_trial_begin: a trial move is already open (accept or reject it first)");
+	if (!c->cache_valid) return fail(c, MPMC_ERR_ARG, "mpmc_trial_begin: no accepted configuration (call mpmc_energy first)");
+	for (int t = 0; t < 3 * count; t++)
+		if (!std::isfinite(new_pos[t])) return fail(c, MPMC_ERR_INVALID_DATUM, "mpmc_trial_begin: non-finite position");
+	c->trial_first = first;
+	c->trial_count = count;
+	c->trial_new.assign(new_pos, new_pos + 3 * (size_t)count);
+	c->trial_old.assign(c->h_pos.begin() + 3 * (size_t)first, c->h_pos.begin() + 3 * (size_t)(first + count));
+	c->trial_open = true;
+	c->trial_evaluated = false;
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_trial_energy(mpmc_ctx *c, mpmc_result *out) {
+	if (!c || !out) return MPMC_ERR_ARG;
+	if (!c->trial_open) return fail(c, MPMC_ERR_ARG, "mpmc_trial_energy: no trial move is open");
+	const mpmc_options &o = c->opts;
+	const bool polar = o.polarization && !o.rd_only;
+	const int m = c->trial_count;
+	if (polar || m > MPMC_TRIAL_MAX_ATOMS) {
+		// the dipole solve couples every atom: evaluate the trial configuration in full (still on the device)
+		const mpmc_result keep = c->last_full;
+		int rc = mpmc_update_positions(c, c->trial_first, m, c->trial_new.data());
+		if (rc != MPMC_OK) return rc;
+		rc = mpmc_energy(c, out);
+		if (rc != MPMC_OK) return rc;
+		c->trial_res = *out;
+		c->last_full = keep; // still the ACCEPTED configuration's totals until mpmc_trial_accept
+		c->trial_was_full = true;
+		c->trial_evaluated = true;
+		return MPMC_OK;
+	}
+	int rc = prepare(c);
+	if (rc != MPMC_OK) return rc;
+	if ((rc = ensure_trial_buffers(c)) != MPMC_OK) return rc;
+	hipStream_t st = c->stream;
+	{ // one pinned staging record, one host-to-device copy
+		double4 *nw = reinterpret_cast<double4 *>(c->h_mv_blob);
+		int *slots = reinterpret_cast<int *>(c->h_mv_blob + MPMC_TRIAL_MAX_ATOMS * sizeof(double4));
+		int *origs = slots + MPMC_TRIAL_MAX_ATOMS;
+		for (int t = 0; t < m; t++) {
+			const int i = c->trial_first + t;
+			origs[t] = i;
+			slots[t] = c->slot_of[i];
+			nw[t] = make_double4(c->trial_new[3 * t], c->trial_new[3 * t + 1], c->trial_new[3 * t + 2], c->h_q[i]);
+		}
+		HIP_TRY(c, hipMemcpyAsync(c->d_mv_blob, c->h_mv_blob, kMvBlobBytes, hipMemcpyHostToDevice, st));
+	}
+	const int do_es = o.rd_only ? 0 : 1;
+	{
+		ProfScope p(c, MPMC_K_PAIR);
+		launch_delta(st, atoms_view(c), c->d_slot_of, c->box, recip_view(c), c->ewald_alpha, do_es, c->d_mv_slot, c->d_mv_orig, c->d_mv_new, m,
+		             c->d_moved_idx, c->d_sf_trial, c->d_block_part, c->d_block_cnt, c->d_delta_out, c->d_delta_cnt);
+	}
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipMemcpyAsync(c->h_delta_out, c->d_delta_out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipStreamSynchronize(st));
+	prof_harvest(c);
+	const mpmc_result &a = c->last_full;
+	mpmc_result r = a;
+	r.lj_pairs = a.lj_pairs + c->h_delta_out[0];
+	r.rd_energy = (r.lj_pairs + r.lrc_pair) + r.lrc_self;
+	r.n_lj_in_cutoff = a.n_lj_in_cutoff + c->h_delta_cnt[0];
+	if (do_es) {
+		r.es_real = a.es_real + (c->h_delta_out[1] - c->h_delta_out[2]);
+		r.es_recip = c->h_delta_out[3];
+		r.coulombic_energy = (r.es_real + r.es_recip) + r.es_self;
+		r.n_es_in_cutoff = a.n_es_in_cutoff + c->h_delta_cnt[1];
+	}
+	r.energy = r.rd_energy + r.coulombic_energy + r.polarization_energy + r.vdw_energy + r.three_body_energy;
+	r.NU = r.N * r.energy;
+	c->trial_res = r;
+	c->trial_was_full = false;
+	c->trial_evaluated = true;
+	*out = r;
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
+	if (!c) return MPMC_ERR_ARG;
+	if (!c->trial_open || !c->trial_evaluated) return fail(c, MPMC_ERR_ARG, "mpmc_trial_accept: no evaluated trial move");
+	HIP_TRY(c, hipSetDevice(c->device));
+	const int m = c->trial_count;
+	if (!c->trial_was_full) {
+		launch_commit_positions(c->stream, c->d_xyzq, c->d_mv_slot, c->d_mv_new, m);
+		HIP_TRY(c, hipGetLastError());
+		std::swap(c->d_sf, c->d_sf_trial); // the trial structure factors become the accepted ones
+		std::swap(c->cap_K, c->cap_sf_trial);
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		for (int t = 0; t < 3 * m; t++) c->h_pos[3 * (size_t)c->trial_first + t] = c->trial_new[t];
+	}
+	c->last_full = c->trial_res;
+	c->cache_valid = true;
+	c->trial_open = false;
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_trial_reject(mpmc_ctx *c) {
+	if (!c) return MPMC_ERR_ARG;
+	if (!c->trial_open) return fail(c, MPMC_ERR_ARG, "mpmc_trial_reject: no trial move is open");
+	c->trial_open = false;
+	if (c->trial_evaluated && c->trial_was_full) { // the resident configuration is the trial one: put the old positions back
+		const mpmc_result keep = c->last_full;
+		int rc = mpmc_update_positions(c, c->trial_first, c->trial_count, c->trial_old.data());
+		if (rc != MPMC_OK) return rc;
+		c->last_full = keep;
+		c->cache_valid = true;
+		const bool polar = c->opts.polarization && !c->opts.rd_only;
+		if (!polar) { // the resident structure factors are the trial ones: re-base on the restored configuration
+			mpmc_result tmp;
+			if ((rc = mpmc_energy(c, &tmp)) != MPMC_OK) return rc;
+		}
+	}
+	return MPMC_OK;
 }
 
 // ---- component entry points --------------------------------------------------------------------------------

@@ -109,6 +109,13 @@ void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, con
 // lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
 void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm);
 
+// ---- trial moves (kernels_delta.hip) ----------------------------------------------------------------------
+// out4 = { d lj_pairs, d es_real(erfc part), d intramolecular term, E_recip of the trial structure factors }, dcnt2 = { d n_lj, d n_es }
+void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc, double alpha, int do_es,
+                  const int *mv_slot, const int *orig_of_mv, const double4 *mv_new, int m, int *moved_idx, double4 *sf_trial,
+                  double *block_part, int *block_cnt, double *out4, long long *dcnt2);
+void launch_commit_positions(hipStream_t st, double4 *xyzq, const int *mv_slot, const double4 *mv_new, int m);
+
 // device-resident positions [n][3] in original atom order -> xyzq[slot].xyz (perm[slot] = original index)
 void launch_set_positions(hipStream_t st, const double *pos_dev, const int *perm, double4 *xyzq, int n);
 

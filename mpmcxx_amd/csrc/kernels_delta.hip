@@ -1,0 +1,238 @@
+// kernels_delta.hip -- trial-move ("delta") energies for non-polarizable boxes.
+//
+// The reference avoids recomputing unchanged pairs through its per-pair cache (`recalculate_energy`, set by
+// minimum_image when a pair's raw displacement changed, System.cpp:1211-1224; lj() :925 and coulombic_real() :1484 then
+// re-evaluate only flagged pairs and re-sum the cached values).  The device-side counterpart keeps the accepted
+// configuration resident and, for a trial move of m atoms, evaluates only the pairs that involve a moved atom -- each one
+// in its old and in its new geometry, with exactly the per-pair arithmetic of k_pair_fused -- plus the change of the
+// structure factors:   E_trial = E_accepted + sum_{pairs with a moved atom} (u_new - u_old) + (E_recip[S + dS] - E_recip[S]).
+// Cost O(m N) + O(K m) instead of O(N^2) + O(K N).
+#include "kernels.h"
+#include "device_math.h"
+
+namespace mpmc {
+
+// u(i,j) of lj() and coulombic_real() (erfc part) for one geometry; adds to e_lj/e_re and the in-cutoff counts with sign sg
+template <bool ORTHO>
+__device__ __forceinline__ void pair_terms(const Box &bx, double alpha, int do_es, const double4 &pi, const double4 &pj, double sig, double eps,
+                                           const PairFlags &f, double sg, double &e_lj, double &e_re, int &n_lj, int &n_es) {
+	double ox, oy, oz;
+	const double ri2 = min_image_sq<ORTHO>(bx, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, ox, oy, oz);
+	const double ir = fast_rsqrt(ri2);
+	if ((ri2 <= bx.t_lj) && !f.rd_excluded) {
+		const double sr = sig * ir;
+		double s6 = sr * sr * sr;
+		s6 *= s6;
+		const double t12 = f.attractive_only ? 0.0 : s6 * s6;
+		e_lj = fma(sg * 4.0 * eps, t12 - s6, e_lj);
+		n_lj += (sg > 0) ? 1 : -1;
+	}
+	if (do_es && (ri2 <= bx.t_es) && !f.es_excluded) {
+		double g;
+		const double ec = erfc_and_gauss(alpha * (ri2 * ir), g);
+		e_re = fma(sg * (pi.w * pj.w) * ec, ir, e_re);
+		n_es += (sg > 0) ? 1 : -1;
+	}
+}
+
+// grid (n_tiles, 1); block 64: thread = atom slot j of tile blockIdx.x; loops over the m moved atoms.
+// mv_slot[k]: slot of moved atom k; mv_new[k]: its trial position (+ charge); moved_idx[slot]: k or -1.
+template <bool ORTHO>
+__global__ __launch_bounds__(64) void k_delta_pairs(AtomsDev at, Box bx, double alpha, int do_es, const int *__restrict__ mv_slot,
+                                                    const double4 *__restrict__ mv_new, int m, const int *__restrict__ moved_idx,
+                                                    double *__restrict__ block_part, int *__restrict__ block_cnt) {
+	const int j = blockIdx.x * kTile + threadIdx.x;
+	const double4 pj_old = at.xyzq[j];
+	const double2 lj = at.lj[j];
+	const int2 mj = at.mf[j];
+	int kj = -1; // >= 0 when j itself is a moved atom
+	if (moved_idx) kj = moved_idx[j];
+	else
+		for (int k = 0; k < m; ++k)
+			if (mv_slot[k] == j) kj = k;
+	const double4 pj_new = (kj >= 0) ? mv_new[kj] : pj_old;
+	double e_lj = 0, e_re = 0;
+	int n_lj = 0, n_es = 0;
+	if (!(mj.y & AF_PAD)) {
+		for (int k = 0; k < m; ++k) {
+			if (kj >= 0 && kj <= k) continue; // moved-moved pairs once (k < kj), never the atom with itself
+			const int si = mv_slot[k];
+			const int2 mi = at.mf[si];
+			const PairFlags f = pair_flags(mi.x, mi.y, mj.x, mj.y);
+			if (f.frozen) continue;
+			const double2 li = at.lj[si];
+			double sig, eps;
+			lj_mix(mi.y, mj.y, li.x, li.y, lj.x, lj.y, sig, eps);
+			pair_terms<ORTHO>(bx, alpha, do_es, mv_new[k], pj_new, sig, eps, f, 1.0, e_lj, e_re, n_lj, n_es);
+			pair_terms<ORTHO>(bx, alpha, do_es, at.xyzq[si], pj_old, sig, eps, f, -1.0, e_lj, e_re, n_lj, n_es);
+		}
+	}
+	e_lj = wave_sum(e_lj);
+	e_re = wave_sum(e_re);
+	n_lj = wave_sum_i(n_lj);
+	n_es = wave_sum_i(n_es);
+	if (threadIdx.x == 0) {
+		block_part[2 * (size_t)blockIdx.x] = e_lj;
+		block_part[2 * (size_t)blockIdx.x + 1] = e_re;
+		block_cnt[2 * (size_t)blockIdx.x] = n_lj;
+		block_cnt[2 * (size_t)blockIdx.x + 1] = n_es;
+	}
+}
+
+// change of the intramolecular charge-to-screen sum (coulombic_real :1503-1504) for the moved atoms: one block.
+// orig_of_mv[k]: original index of moved atom k; molecules are contiguous runs of the original order.
+__global__ __launch_bounds__(64) void k_delta_intra(AtomsDev at, const int *__restrict__ slot_of, double alpha, const int *__restrict__ orig_of_mv,
+                                                    const double4 *__restrict__ mv_new, int m, const int *__restrict__ moved_idx,
+                                                    double *__restrict__ out) {
+	double acc = 0;
+	for (int k = threadIdx.x; k < m; k += 64) {
+		const int i = orig_of_mv[k];
+		const int si = slot_of[i];
+		const int2 mi = at.mf[si];
+		const double4 pi_old = at.xyzq[si], pi_new = mv_new[k];
+		// walk the molecule of atom i in both directions of the original order
+		for (int dir = -1; dir <= 1; dir += 2)
+			for (int jo = i + dir; jo >= 0 && jo < at.n; jo += dir) {
+				const int sj = slot_of[jo];
+				const int2 mj = at.mf[sj];
+				if (mj.x != mi.x) break;
+				int kj = -1;
+				if (moved_idx) kj = moved_idx[sj];
+				else
+					for (int q = 0; q < m; ++q)
+						if (orig_of_mv[q] == jo) kj = q;
+				if (kj >= 0 && kj < k) continue; // a moved-moved pair is counted once, from its lower list index
+				if (mi.y & mj.y & AF_FROZEN) continue;
+				const double4 pj_old = at.xyzq[sj];
+				const double4 pj_new = (kj >= 0) ? mv_new[kj] : pj_old;
+				const double qq = pi_old.w * pj_old.w;
+				if (qq == 0.0) continue;
+				for (int pass = 0; pass < 2; ++pass) {
+					const double4 a = pass ? pi_old : pi_new, b = pass ? pj_old : pj_new;
+					const double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+					const double r2 = ((dx * dx) + dy * dy) + dz * dz;
+					const double ir = fast_rsqrt(r2);
+					double g;
+					const double t = qq * (1.0 - erfc_and_gauss(alpha * (r2 * ir), g)) * ir;
+					acc += pass ? -t : t;
+				}
+			}
+	}
+	acc = wave_sum(acc);
+	if (threadIdx.x == 0) out[0] = acc;
+}
+
+// trial structure factors: sf_trial[k] = sf[k] + sum_moved q (e^{i k.r_new} - e^{i k.r_old}); one wave per k-vector
+__global__ __launch_bounds__(64) void k_delta_recip(AtomsDev at, RecipDev rc, const int *__restrict__ mv_slot, const double4 *__restrict__ mv_new, int m,
+                                                    double4 *__restrict__ sf_trial) {
+	const double4 kv = rc.kvec[blockIdx.x];
+	double re = 0, im = 0, C = 0, S = 0;
+	for (int k = threadIdx.x; k < m; k += 64) {
+		const int si = mv_slot[k];
+		const int fl = at.mf[si].y;
+		const double4 po = at.xyzq[si], pn = mv_new[k];
+		double s0, c0, s1, c1;
+		sincos(((kv.x * po.x) + kv.y * po.y) + kv.z * po.z, &s0, &c0);
+		sincos(((kv.x * pn.x) + kv.y * pn.y) + kv.z * pn.z, &s1, &c1);
+		const double dc = po.w * (c1 - c0), ds = po.w * (s1 - s0);
+		C += dc;
+		S += ds;
+		if (!(fl & (AF_FROZEN | AF_ZERO_Q))) {
+			re += dc;
+			im += ds;
+		}
+	}
+	re = wave_sum(re);
+	im = wave_sum(im);
+	C = wave_sum(C);
+	S = wave_sum(S);
+	if (threadIdx.x == 0) {
+		const double4 o = rc.sf[blockIdx.x];
+		sf_trial[blockIdx.x] = make_double4(o.x + re, o.y + im, o.z + C, o.w + S);
+	}
+}
+
+// sums the per-tile partials, the reciprocal energy of the trial structure factors, into out[0..3] and counts
+__global__ __launch_bounds__(256) void k_delta_finish(const double *__restrict__ block_part, const int *__restrict__ block_cnt, int nb,
+                                                      RecipDev rc, const double4 *__restrict__ sf_trial, Box bx, int do_es,
+                                                      double *__restrict__ out /* dlj, des_real, (dintra at [2]), e_recip_trial at [3] */,
+                                                      long long *__restrict__ dcnt) {
+	__shared__ double sh[4];
+	__shared__ long long shc[256];
+	double s0 = 0, s1 = 0, e = 0;
+	long long c0 = 0, c1 = 0;
+	for (int b = threadIdx.x; b < nb; b += 256) {
+		s0 += block_part[2 * (size_t)b];
+		s1 += block_part[2 * (size_t)b + 1];
+		c0 += block_cnt[2 * (size_t)b];
+		c1 += block_cnt[2 * (size_t)b + 1];
+	}
+	if (do_es)
+		for (int k = threadIdx.x; k < rc.K; k += 256) {
+			const double4 sf = sf_trial[k];
+			e += rc.w_en[k] * (sf.x * sf.x + sf.y * sf.y);
+		}
+	auto bsum = [&](double v) {
+		v = wave_sum(v);
+		__syncthreads();
+		if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+		__syncthreads();
+		return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+	};
+	s0 = bsum(s0);
+	s1 = bsum(s1);
+	e = bsum(e);
+	if (threadIdx.x == 0) {
+		out[0] = s0;
+		out[1] = s1;
+		if (!do_es) out[2] = 0.0; // (k_delta_intra wrote it otherwise)
+		out[3] = e * (4.0 * kPi / bx.volume);
+		out[4] = (double)0;
+	}
+	for (int k = 0; k < 2; ++k) {
+		__syncthreads();
+		shc[threadIdx.x] = k ? c1 : c0;
+		__syncthreads();
+		for (int off = 128; off > 0; off >>= 1) {
+			if (threadIdx.x < off) shc[threadIdx.x] += shc[threadIdx.x + off];
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) dcnt[k] = shc[0];
+	}
+}
+
+// accept: write the trial positions into the resident arrays
+__global__ void k_commit_positions(double4 *__restrict__ xyzq, const int *__restrict__ mv_slot, const double4 *__restrict__ mv_new, int m) {
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < m) xyzq[mv_slot[k]] = mv_new[k];
+}
+// set / clear the moved-atom index map
+__global__ void k_mark_moved(int *__restrict__ moved_idx, const int *__restrict__ mv_slot, int m, int set) {
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < m) moved_idx[mv_slot[k]] = set ? k : -1;
+}
+
+void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc, double alpha, int do_es,
+                  const int *mv_slot, const int *orig_of_mv, const double4 *mv_new, int m, int *moved_idx, double4 *sf_trial,
+                  double *block_part, int *block_cnt, double *out4, long long *dcnt2) {
+	const int nt = at.n_pad / kTile;
+	const bool use_map = (m > 8); // short lists are scanned in the kernels; long ones go through the slot -> list-index map
+	if (use_map) hipLaunchKernelGGL(k_mark_moved, dim3((m + 63) / 64), dim3(64), 0, st, moved_idx, mv_slot, m, 1);
+	else moved_idx = nullptr;
+	if (bx.ortho)
+		hipLaunchKernelGGL(k_delta_pairs<true>, dim3(nt), dim3(kTile), 0, st, at, bx, alpha, do_es, mv_slot, mv_new, m, moved_idx, block_part, block_cnt);
+	else
+		hipLaunchKernelGGL(k_delta_pairs<false>, dim3(nt), dim3(kTile), 0, st, at, bx, alpha, do_es, mv_slot, mv_new, m, moved_idx, block_part, block_cnt);
+	if (do_es) {
+		hipLaunchKernelGGL(k_delta_intra, dim3(1), dim3(64), 0, st, at, slot_of, alpha, orig_of_mv, mv_new, m, moved_idx, out4 + 2);
+		if (rc.K > 0) hipLaunchKernelGGL(k_delta_recip, dim3(rc.K), dim3(64), 0, st, at, rc, mv_slot, mv_new, m, sf_trial);
+	}
+	hipLaunchKernelGGL(k_delta_finish, dim3(1), dim3(256), 0, st, block_part, block_cnt, nt, rc, sf_trial, bx, do_es, out4, dcnt2);
+	if (use_map) hipLaunchKernelGGL(k_mark_moved, dim3((m + 63) / 64), dim3(64), 0, st, moved_idx, mv_slot, m, 0);
+}
+
+void launch_commit_positions(hipStream_t st, double4 *xyzq, const int *mv_slot, const double4 *mv_new, int m) {
+	hipLaunchKernelGGL(k_commit_positions, dim3((m + 63) / 64), dim3(64), 0, st, xyzq, mv_slot, mv_new, m);
+}
+
+} // namespace mpmc

@@ -111,6 +111,10 @@ def lib():
     L.mpmc_synchronize.argtypes = [vp]
     L.mpmc_memory_usage.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.mpmc_get_tile_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.mpmc_trial_begin.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.mpmc_trial_energy.argtypes = [vp, C.POINTER(Result)]
+    L.mpmc_trial_accept.argtypes = [vp]
+    L.mpmc_trial_reject.argtypes = [vp]
     _lib = L
     return L
 
@@ -242,6 +246,26 @@ class System:
         self._check(self._L.mpmc_energy_wait(self._h, C.byref(r)))
         self.observables = r.as_dict()
         return r.energy
+
+    # -- trial moves (reference: per-pair recalculate_energy cache, src/System.cpp:1211-1224) ------------------------------
+    def trial_energy(self, first: int, pos: np.ndarray) -> float:
+        """energy of the configuration in which atoms first.. take the positions `pos`; follow with accept() or reject()."""
+        p = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1)
+        self._check(self._L.mpmc_trial_begin(self._h, int(first), p.size // 3, _dp(p)))
+        r = Result()
+        rc = self._L.mpmc_trial_energy(self._h, C.byref(r))
+        if rc != MPMC_OK:
+            self._L.mpmc_trial_reject(self._h)
+            self._check(rc)
+        self.trial_observables = r.as_dict()
+        return r.energy
+
+    def accept(self):
+        self._check(self._L.mpmc_trial_accept(self._h))
+        self.observables = dict(self.trial_observables)
+
+    def reject(self):
+        self._check(self._L.mpmc_trial_reject(self._h))
 
     def _scalar(self, fn) -> float:
         v = C.c_double()

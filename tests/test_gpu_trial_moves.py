@@ -1,0 +1,88 @@
+"""GPU (MI355X): trial-move (delta) energies against full re-evaluation and the oracle.
+
+A Metropolis-like sequence of molecule displacements: every trial energy must equal a stateless full evaluation of the
+same configuration (fresh context) to rounding, rejected moves must leave no trace, and after the whole sequence the
+accumulated totals must still agree with the oracle at 1e-9."""
+import numpy as np
+import pytest
+
+import util
+from mpmcxx_amd import energy
+
+pytestmark = pytest.mark.gpu
+
+
+def molecules(atoms):
+    ids = atoms["mol_id"]
+    starts = [0] + [i for i in range(1, len(ids)) if ids[i] != ids[i - 1]] + [len(ids)]
+    return [(starts[k], starts[k + 1]) for k in range(len(starts) - 1)]
+
+
+def nonpolar(opts):
+    o = dict(opts)
+    o.update(polarization=0, polar_iterative=0)
+    return o
+
+
+@pytest.mark.parametrize("name,polar", [("lj64", False), ("ion64_es", False), ("water64_polar", False), ("ion216_triclinic", False),
+                                        ("ion216_frozen", False), ("water64_polar", True)])
+def test_trial_moves_track_full_evaluations(name, polar):
+    from oracle import OracleSystem
+
+    atoms, basis, opts = util.load_fixture(name)
+    if not polar:
+        opts = nonpolar(opts)
+    rng = np.random.default_rng(11)
+    S = energy.System(atoms, basis, opts)
+    e_acc = S.energy()
+    pos = atoms["pos"].copy()
+    mols = molecules(atoms)
+    n_steps = 6 if polar else 40
+    n_acc = 0
+    for step in range(n_steps):
+        a, b = mols[rng.integers(len(mols))]
+        trial = pos[a:b] + rng.normal(scale=0.4, size=(b - a, 3))
+        e_trial = S.trial_energy(a, trial)
+        full_pos = pos.copy()
+        full_pos[a:b] = trial
+        at2 = dict(atoms)
+        at2["pos"] = full_pos
+        T = energy.System(at2, basis, opts)
+        e_full = T.energy()
+        for k in ("energy", "rd_energy", "coulombic_energy", "es_real", "es_recip", "lj_pairs"):
+            x, y = S.trial_observables[k], T.observables[k]
+            assert abs(x - y) <= 1e-11 * max(abs(y), abs(T.observables["energy"]) * 1e-3) + 1e-9, (name, step, k, x, y)
+        assert S.trial_observables["n_lj_in_cutoff"] == T.observables["n_lj_in_cutoff"]
+        assert S.trial_observables["n_es_in_cutoff"] == T.observables["n_es_in_cutoff"]
+        assert util.close(e_trial, e_full, 1e-11)
+        T.close()
+        if rng.random() < 0.5:
+            S.accept()
+            pos = full_pos
+            e_acc = e_trial
+            n_acc += 1
+        else:
+            S.reject()
+    assert 0 < n_acc < n_steps
+    # a stateless full evaluation of the final resident state, and the oracle on the same positions
+    e_final = S.energy()
+    at3 = dict(atoms)
+    at3["pos"] = pos
+    ref = OracleSystem(at3, basis, opts).energy()
+    assert util.close(e_final, ref["energy"]) and util.close(e_acc, ref["energy"], 1e-10)
+    S.close()
+
+
+def test_trial_protocol_errors():
+    atoms, basis, opts = util.load_fixture("lj64")
+    S = energy.System(atoms, basis, opts)
+    with pytest.raises(energy.MpmcError):  # no accepted configuration yet
+        S.trial_energy(0, atoms["pos"][0:1])
+    S.energy()
+    S.trial_energy(0, atoms["pos"][0:1] + 0.1)
+    with pytest.raises(energy.MpmcError):  # a trial is already open
+        S.trial_energy(1, atoms["pos"][1:2])
+    S.reject()
+    with pytest.raises(energy.MpmcError):
+        S.reject()
+    S.close()
