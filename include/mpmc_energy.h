@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MPMC_ABI_VERSION 1
+#define MPMC_ABI_VERSION 2
 
 /* ---- status codes -------------------------------------------------------------------------------------- */
 #define MPMC_OK 0
@@ -53,8 +53,8 @@ extern "C" {
 #define MPMC_SOLVER_DENSE 3        /* store the reference's dense 3N x 3N A matrix (thole_amatrix layout)     */
 
 /* ---- out-of-scope reference switches: pass the ones that are ON so the library can refuse them ---------- */
-#define MPMC_FLAG_WOLF (1ull << 0)
-#define MPMC_FLAG_FEYNMAN_HIBBS (1ull << 1)
+#define MPMC_FLAG_WOLF (1ull << 0)          /* (now supported: mpmc_options.wolf; the bit stays for ABI stability) */
+#define MPMC_FLAG_FEYNMAN_HIBBS (1ull << 1) /* (now supported: mpmc_options.feynman_hibbs) */
 #define MPMC_FLAG_RD_CRYSTAL (1ull << 2)
 #define MPMC_FLAG_SPECTRE (1ull << 3)
 #define MPMC_FLAG_GWP (1ull << 4)
@@ -87,13 +87,16 @@ typedef struct mpmc_options {
 	int32_t damp_type;        /* :1308 must be MPMC_DAMPING_EXPONENTIAL when polarization is on             */
 	int32_t ewald_kmax;       /* :1199 (default 7)                                                          */
 	int32_t solver;           /* MPMC_SOLVER_*                                                              */
-	int32_t reserved0;
+	int32_t wolf;             /* :994  Wolf electrostatics instead of Ewald in coulombic() (coulombic_wolf :1420-1462) */
 	double polar_precision;   /* :1298 0 => fixed count; else stop when every |d mu| < precision*DEBYE2SKA  */
 	double polar_gamma;       /* :1288 pre-scaling of the initial dipoles (default 1.0)                     */
 	double polar_damp;        /* :1293 Thole exponential damping length parameter                           */
 	double ewald_alpha;       /* :1192 <= 0 means "unset": 3.5 / cutoff (System.cpp:871-872)                 */
 	double polar_ewald_alpha; /* :1218 <= 0 means "unset": 3.5 / cutoff (System.cpp:873-874)                 */
 	uint64_t unsupported_flags; /* OR of MPMC_FLAG_* that are ON in the caller's System                     */
+	int32_t feynman_hibbs;       /* :1042 Feynman-Hibbs corrections to lj() and coulombic_real() (:1100-1148, :1521-1557) */
+	int32_t feynman_hibbs_order; /* :1067 2 or 4 (anything else: 2, SimulationControl.cpp:2497-2500)           */
+	double temperature;          /* K; needed by Feynman-Hibbs (needs atom masses in mpmc_set_atoms)           */
 } mpmc_options;
 
 /* what energy() leaves in System::observables / nodestats (src/System.h:94-113,151-185) + parity diagnostics */

@@ -113,7 +113,7 @@ inline std::string read_input(const std::string &path, System &s) {
 	std::ifstream f(path);
 	if (!f) throw 1000;
 	static const std::map<std::string, uint64_t> unsupported = {
-	    {"wolf", MPMC_FLAG_WOLF}, {"feynman_hibbs", MPMC_FLAG_FEYNMAN_HIBBS}, {"rd_crystal", MPMC_FLAG_RD_CRYSTAL}, {"spectre", MPMC_FLAG_SPECTRE},
+	    {"rd_crystal", MPMC_FLAG_RD_CRYSTAL}, {"spectre", MPMC_FLAG_SPECTRE},
 	    {"gwp", MPMC_FLAG_GWP}, {"sg", MPMC_FLAG_USE_SG}, {"polarvdw", MPMC_FLAG_POLARVDW}, {"cdvdw", MPMC_FLAG_POLARVDW},
 	    {"polar_ewald_full", MPMC_FLAG_POLAR_EWALD_FULL}, {"polar_wolf", MPMC_FLAG_POLAR_WOLF}, {"polar_wolf_full", MPMC_FLAG_POLAR_WOLF},
 	    {"polar_palmo", MPMC_FLAG_POLAR_PALMO}, {"polar_gs_ranked", MPMC_FLAG_POLAR_GS_RANKED}, {"polar_sor", MPMC_FLAG_POLAR_SOR},
@@ -149,6 +149,10 @@ inline std::string read_input(const std::string &path, System &s) {
 		else if (k == "polar_ewald") { need(1); s.polar_ewald = onoff(t[1]); }
 		else if (k == "polar_gs") { need(1); s.polar_gs = onoff(t[1]); }
 		else if (k == "polar_rrms") { need(1); s.polar_rrms = onoff(t[1]); }
+		else if (k == "wolf") { need(1); s.wolf = onoff(t[1]); }
+		else if (k == "feynman_hibbs") { need(1); s.feynman_hibbs = onoff(t[1]); }
+		else if (k == "feynman_hibbs_order") { need(1); s.feynman_hibbs_order = (int)dval(1); }
+		else if (k == "temperature") { need(1); s.temperature = dval(1); }
 		else if (k == "polar_max_iter") { need(1); s.polar_max_iter = (int)dval(1); }
 		else if (k == "ewald_kmax") { need(1); s.ewald_kmax = (int)dval(1); }
 		else if (k == "polar_precision") { need(1); s.polar_precision = dval(1); }

@@ -73,6 +73,8 @@ public:
 	int polarization = 0, polar_iterative = 0, polar_ewald = 0, polar_max_iter = 10, polar_gs = 0, polar_rrms = 0;
 	int damp_type = DAMPING_EXPONENTIAL;
 	int ewald_kmax = 7;
+	int wolf = 0, feynman_hibbs = 0, feynman_hibbs_order = 0;
+	double temperature = 0;
 	double polar_precision = 0, polar_gamma = 1.0, polar_damp = 0;
 	double ewald_alpha = 0.5, polar_ewald_alpha = 0.5;
 	int ewald_alpha_set = 0, polar_ewald_alpha_set = 0;
@@ -234,6 +236,10 @@ private:
 		o.damp_type = damp_type;
 		o.ewald_kmax = ewald_kmax;
 		o.solver = solver;
+		o.wolf = wolf;
+		o.feynman_hibbs = feynman_hibbs;
+		o.feynman_hibbs_order = feynman_hibbs_order;
+		o.temperature = temperature;
 		o.polar_precision = polar_precision;
 		o.polar_gamma = polar_gamma;
 		o.polar_damp = polar_damp;

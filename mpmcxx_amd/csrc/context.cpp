@@ -57,7 +57,7 @@ struct mpmc_ctx {
 	double4 *d_xyzq = nullptr;
 	double2 *d_lj = nullptr;
 	int2 *d_mf = nullptr;
-	double *d_alpha = nullptr, *d_eps = nullptr;
+	double *d_alpha = nullptr, *d_eps = nullptr, *d_inv_molmass = nullptr;
 
 	// pair kernel
 	int2 *d_tile_pairs = nullptr;
@@ -356,6 +356,7 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	A(dev_alloc(c, &c->d_mf, P));
 	A(dev_alloc(c, &c->d_alpha, P));
 	A(dev_alloc(c, &c->d_eps, P));
+	A(dev_alloc(c, &c->d_inv_molmass, P));
 	A(dev_alloc(c, &c->d_tile_bounds, 6 * (P / kTile)));
 	A(dev_alloc(c, &c->d_slot_of, P));
 	A(dev_alloc(c, &c->d_perm, P));
@@ -387,7 +388,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	for (auto &e : c->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
+	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_inv_molmass, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
 	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out};
@@ -420,6 +421,7 @@ extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *re
 	// squared-distance forms of the reference's cutoff predicates (see pair_math.h Box)
 	c->box.t_lj = bisect_threshold(cut, [cut](double t) { return std::sqrt(t) - kSmallDR < cut; });
 	c->box.t_es = bisect_threshold(cut, [cut](double t) { return !(std::sqrt(t) > cut); });
+	c->box.t_wolf = bisect_threshold(cut, [cut](double t) { return std::sqrt(t) < cut; });
 	c->box.ortho = 1;
 	for (int i = 0; i < 3; i++)
 		for (int j = 0; j < 3; j++)
@@ -433,7 +435,7 @@ extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *re
 
 extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 	if (!c || !o) return MPMC_ERR_ARG;
-	if (o->unsupported_flags) {
+	if (o->unsupported_flags & ~(uint64_t)(MPMC_FLAG_WOLF | MPMC_FLAG_FEYNMAN_HIBBS)) { // (Wolf / Feynman-Hibbs travel in their own option fields)
 		char buf[160];
 		std::snprintf(buf, sizeof buf, "mpmc_set_options: reference option(s) outside the energy hot path are ON (flag mask 0x%llx)",
 		              (unsigned long long)o->unsupported_flags);
@@ -453,6 +455,10 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 			return fail(c, MPMC_ERR_UNSUPPORTED, "mpmc_set_options: the dense 3N x 3N solver is not built; mpmc_thole_amatrix gives the dense matrix, COMPACT stores the same tensors in 16 B/pair");
 	}
 	if (o->ewald_kmax < 0 || o->ewald_kmax > 64) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: ewald_kmax out of range");
+	if (o->feynman_hibbs) {
+		if (!(o->temperature > 0)) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: feynman_hibbs requires positive temperature"); // SimulationControl.cpp:2509
+		if (o->wolf && !o->rd_only) return fail(c, MPMC_ERR_INCOMPATIBLE, "mpmc_set_options: FH + es_wolf is not implemented"); // System.Energy.cpp:1448-1450
+	}
 	c->opts = *o;
 	c->opts_set = true;
 	c->k_dirty = true;
@@ -505,8 +511,17 @@ static int upload_atoms(mpmc_ctx *c) {
 	std::vector<double4> xyzq(np);
 	std::vector<double2> lj(np);
 	std::vector<int2> mf(np);
-	std::vector<double> al(np, 0.0), ep(np, 0.0);
+	std::vector<double> al(np, 0.0), ep(np, 0.0), imm(np, 0.0);
 	std::vector<int32_t> perm(np, -1), slot(np, -1);
+	std::vector<double> molmass(n, 0.0); // Molecule::mass = sum of its atoms' masses (System.cpp:687), per atom
+	if (!c->h_mass.empty())
+		for (int i0 = 0; i0 < n;) {
+			int i1 = i0;
+			double m = 0;
+			while (i1 < n && c->h_mol[i1] == c->h_mol[i0]) m += c->h_mass[i1++];
+			for (int i = i0; i < i1; i++) molmass[i] = m;
+			i0 = i1;
+		}
 	for (int k = 0; k < np; k++) {
 		if (k < n) {
 			const int i = c->perm[k];
@@ -525,6 +540,7 @@ static int upload_atoms(mpmc_ctx *c) {
 			mf[k] = make_int2(c->h_mol[i], fl);
 			al[k] = c->h_alpha[i];
 			ep[k] = c->h_eps[i];
+			imm[k] = (molmass[i] > 0.0) ? 1.0 / molmass[i] : 0.0;
 		} else {
 			xyzq[k] = make_double4(0, 0, 0, 0);
 			lj[k] = make_double2(0, 0);
@@ -536,6 +552,7 @@ static int upload_atoms(mpmc_ctx *c) {
 	HIP_TRY(c, hipMemcpyAsync(c->d_mf, mf.data(), np * sizeof(int2), hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(c, hipMemcpyAsync(c->d_alpha, al.data(), np * sizeof(double), hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(c, hipMemcpyAsync(c->d_eps, ep.data(), np * sizeof(double), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_inv_molmass, imm.data(), np * sizeof(double), hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(c, hipMemcpyAsync(c->d_perm, perm.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(c, hipMemcpyAsync(c->d_slot_of, slot.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
 	// position-independent pair-flag counts (diagnostics of pair_exclusions), once per upload
@@ -546,6 +563,7 @@ static int upload_atoms(mpmc_ctx *c) {
 		at.mf = c->d_mf;
 		at.alpha = c->d_alpha;
 		at.eps = c->d_eps;
+		at.inv_molmass = c->d_inv_molmass;
 		at.n = c->n;
 		at.n_pad = c->n_pad;
 		launch_static_counts(c->stream, at, c->d_tile_pairs, c->n_tile_pairs, c->d_block_cnt, c->d_cnt);
@@ -793,6 +811,8 @@ static int prepare(mpmc_ctx *c) {
 	if (!c->box_set) return fail(c, MPMC_ERR_BOX, "energy: no box set (mpmc_set_box)");
 	if (!c->atoms_set) return fail(c, MPMC_ERR_INVALID_DATUM, "energy: no atoms set (mpmc_set_atoms)");
 	HIP_TRY(c, hipSetDevice(c->device));
+	if (c->opts.feynman_hibbs && c->h_mass.empty())
+		return fail(c, MPMC_ERR_INVALID_DATUM, "energy: feynman_hibbs needs atom masses (mpmc_set_atoms was called without them)");
 	if (c->atoms_dirty) {
 		int rc = upload_atoms(c);
 		if (rc != MPMC_OK) return rc;
@@ -815,6 +835,7 @@ static AtomsDev atoms_view(const mpmc_ctx *c) {
 	a.mf = c->d_mf;
 	a.alpha = c->d_alpha;
 	a.eps = c->d_eps;
+	a.inv_molmass = c->d_inv_molmass;
 	a.n = c->n;
 	a.n_pad = c->n_pad;
 	return a;
@@ -830,7 +851,7 @@ static RecipDev recip_view(const mpmc_ctx *c) {
 }
 
 // which pieces of energy() to run
-enum : unsigned { RUN_PAIR = 1, RUN_PAIR_ES = 2, RUN_RECIP = 4, RUN_ATOMTERMS = 8, RUN_FIELD = 16, RUN_SOLVE = 32 };
+enum : unsigned { RUN_PAIR = 1, RUN_PAIR_ES = 2, RUN_RECIP = 4, RUN_ATOMTERMS = 8, RUN_FIELD = 16, RUN_SOLVE = 32, RUN_WOLF = 64 };
 
 static int enqueue(mpmc_ctx *c, unsigned mask) {
 	int rc = prepare(c);
@@ -885,12 +906,22 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		fp.do_es = ((mask & RUN_PAIR_ES) || (mask & RUN_FIELD)) ? 1 : 0;
 		fp.do_field = (mask & RUN_FIELD) ? (o.polar_ewald ? 1 : 2) : 0;
 		fp.do_thole = compact ? 1 : 0;
+		fp.wolf = (o.wolf && (mask & RUN_WOLF)) ? 1 : 0;
+		fp.fh_order = o.feynman_hibbs ? ((o.feynman_hibbs_order == 4) ? 4 : 2) : 0;
+		fp.fh_c2 = fp.fh_c4 = 0.0;
+		if (fp.fh_order) { // reference constants.h:15-33: M2A2 hBar2 / (24 kB T) and M2A4 hBar4 / (1152 kB2 T^2), reduced mass in kg
+			const double hBar2 = 1.11211999e-68, hBar4 = 1.23681087e-136, kB = 1.3806503e-23, kB2 = 1.90619525e-46, amu = 1.66053873e-27;
+			fp.fh_c2 = 1.0e20 * (hBar2 / (24.0 * kB * o.temperature)) / amu;
+			fp.fh_c4 = 1.0e40 * (hBar4 / (1152.0 * kB2 * o.temperature * o.temperature)) / (amu * amu);
+		}
+		fp.wolf_erfa_over_r = std::erf(c->ewald_alpha * c->box.cutoff) / c->box.cutoff;
+		fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
 		if (compact) launch_build_lists(st, c->d_cls, c->n_tile_pairs, c->d_lists, c->d_lists + 2 * (size_t)c->n_tile_pairs);
 		launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
 		                  compact ? c->d_ab : nullptr);
 		if (mask & RUN_PAIR) {
 			launch_reduce_pairs(st, c->d_block_part, c->d_block_cnt, c->n_tile_pairs, c->d_scal, c->d_cnt);
-			if (mask & RUN_PAIR_ES) launch_intra_terms(st, at, c->d_slot_of, c->ewald_alpha, c->d_scal);
+			if ((mask & RUN_PAIR_ES) && !fp.wolf) launch_intra_terms(st, at, c->d_slot_of, c->ewald_alpha, c->d_scal);
 		}
 	}
 	if (side_work) join_side(c);
@@ -1010,7 +1041,8 @@ static int wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 static unsigned full_mask(const mpmc_ctx *c) {
 	unsigned m = RUN_PAIR | RUN_ATOMTERMS;
 	if (!c->opts.rd_only) {
-		m |= RUN_PAIR_ES | RUN_RECIP;
+		m |= RUN_PAIR_ES;
+		m |= c->opts.wolf ? RUN_WOLF : RUN_RECIP; // coulombic() :1404-1413: Wolf replaces real + reciprocal + self
 		if (c->opts.polarization) m |= RUN_FIELD | RUN_SOLVE;
 	}
 	return m;
@@ -1079,7 +1111,7 @@ extern "C" int mpmc_trial_energy(mpmc_ctx *c, mpmc_result *out) {
 	const mpmc_options &o = c->opts;
 	const bool polar = o.polarization && !o.rd_only;
 	const int m = c->trial_count;
-	if (polar || m > MPMC_TRIAL_MAX_ATOMS) {
+	if (polar || m > MPMC_TRIAL_MAX_ATOMS || o.wolf || o.feynman_hibbs) { // (the delta kernels carry the base LJ + Ewald terms only)
 		// the dipole solve couples every atom: evaluate the trial configuration in full (still on the device)
 		const mpmc_result keep = c->last_full;
 		int rc = mpmc_update_positions(c, c->trial_first, m, c->trial_new.data());
@@ -1168,7 +1200,7 @@ extern "C" int mpmc_trial_reject(mpmc_ctx *c) {
 		c->last_full = keep;
 		c->cache_valid = true;
 		const bool polar = c->opts.polarization && !c->opts.rd_only;
-		if (!polar) { // the resident structure factors are the trial ones: re-base on the restored configuration
+		if (!polar && !c->opts.wolf) { // the resident structure factors are the trial ones: re-base on the restored configuration
 			mpmc_result tmp;
 			if ((rc = mpmc_energy(c, &tmp)) != MPMC_OK) return rc;
 		}
@@ -1208,8 +1240,9 @@ extern "C" int mpmc_coulombic_self(mpmc_ctx *c, double *out) {
 	return rc;
 }
 extern "C" int mpmc_coulombic(mpmc_ctx *c, double *out) {
+	if (!c) return MPMC_ERR_ARG;
 	mpmc_result r;
-	int rc = run_piece(c, RUN_PAIR | RUN_PAIR_ES | RUN_RECIP, &r);
+	int rc = run_piece(c, RUN_PAIR | RUN_PAIR_ES | (c->opts.wolf ? RUN_WOLF : RUN_RECIP), &r);
 	if (rc == MPMC_OK && out) *out = r.coulombic_energy;
 	return rc;
 }

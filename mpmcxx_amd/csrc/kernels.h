@@ -18,6 +18,7 @@ struct AtomsDev {
 	const int2 *mf;      // molecule id, AF_* flags
 	const double *alpha; // polarizability
 	const double *eps;   // epsilon (atom self-LRC term)
+	const double *inv_molmass; // 1 / (mass of the owning molecule, amu): Feynman-Hibbs reduced masses (may be null)
 	int n, n_pad;
 };
 
@@ -81,6 +82,11 @@ struct FusedParams {
 	int do_es;    // electrostatics on
 	int do_field; // 0 none, 1 Ewald real_term, 2 thole_field_nopbc
 	int do_thole; // write the (a,b) tensor store
+	// adjacent physics (extended kernel variant only)
+	int wolf;             // coulombic_wolf instead of the erfc term
+	int fh_order;         // 0 off, 2 or 4: Feynman-Hibbs corrections
+	double fh_c2, fh_c4;  // M2A2 hbar^2 / (24 kB T amu2kg),  M2A4 hbar^4 / (1152 kB^2 T^2 amu2kg^2)
+	double wolf_erfa_over_r, wolf_inv_r2; // erf(alpha R)/R, 1/R^2
 };
 // every unordered pair once: energies + counts (block partials), static-field partials fpart[nt][n_pad][3],
 // Thole store ab[n_tile_pairs][64*64] (double2 = 16 B per pair)

@@ -70,7 +70,9 @@ void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm) {
 //   FIELD : 0 none, 1 Ewald real_term (:2900-2940), 2 thole_field_nopbc (:3300-3333)
 //   THOLE : write the (a,b) tensor store
 // ------------------------------------------------------------------------------------------------------
-template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP>
+//   EXT   : adjacent physics compiled in (Wolf electrostatics, Feynman-Hibbs corrections); the default instantiations
+//           carry none of that code
+template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP, bool EXT = false>
 __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedParams fp, const int2 *__restrict__ tile_pairs,
                                                    const int *__restrict__ cls, double *__restrict__ block_part, int *__restrict__ block_cnt,
                                                    double *__restrict__ fpart /*[nt][n_pad][3]*/, double2 *__restrict__ ab) {
@@ -108,6 +110,12 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 	const double4 pi = at.xyzq[i];
 	const double2 li = at.lj[i];
 	const int2 mi = at.mf[i];
+	__shared__ double s_imm[EXT ? kTile : 1];
+	double imm_i = 0.0;
+	if (EXT && fp.fh_order) {
+		imm_i = at.inv_molmass[i];
+		s_imm[lane] = at.inv_molmass[j0 + lane];
+	}
 	{
 		const double4 pj = at.xyzq[j0 + lane];
 		const double2 lj = at.lj[j0 + lane];
@@ -205,16 +213,50 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 					const double t12 = f.attractive_only ? 0.0 : s6 * s6;
 					e_lj = fma(4.0 * eps, t12 - s6, e_lj);
 					n_lj++;
+					if (EXT && fp.fh_order) { // lj_fh_corr :1100-1148
+						const double imu = imm_i + s_imm[jl];
+						const double ir2 = ir * ir;
+						const double dE = -24.0 * eps * (2.0 * t12 - s6) * ir;
+						const double d2E = 24.0 * eps * (26.0 * t12 - 7.0 * s6) * ir2;
+						double corr = fp.fh_c2 * imu * (d2E + 2.0 * dE * ir);
+						if (fp.fh_order >= 4) {
+							const double ir3 = ir2 * ir;
+							const double d3E = -1344.0 * eps * (6.0 * t12 - s6) * ir3;
+							const double d4E = 12096.0 * eps * (10.0 * t12 - s6) * (ir2 * ir2);
+							corr += fp.fh_c4 * (imu * imu) * (15.0 * dE * ir3 + 4.0 * d3E * ir + d4E);
+						}
+						e_lj += corr;
+					}
 				}
 				if (ES) {
 					const double qq = pi.w * qj;
-					const bool es_pair = in_es && !f.es_excluded; // coulombic_real :1490
+					const bool wolf_on = EXT && fp.wolf;
+					const bool es_pair = in_es && !f.es_excluded && !wolf_on; // coulombic_real :1490
+					if (wolf_on && !f.es_excluded && (ri2 <= bx.t_wolf)) { // coulombic_wolf :1443-1445 (r < R)
+						e_re = fma(qq, ir - fp.wolf_erfa_over_r - fp.wolf_inv_r2 * (bx.cutoff - r), e_re);
+						n_es++;
+					}
 					const bool fld_pair = (FIELD == 1) && in_es && (ri2 != 0.0) && !(pi.w == 0.0 && qj == 0.0); // real_term :2916-2917
 					double erfc_a = 0.0, gauss_a = 0.0;
 					if (es_pair || (fld_pair && same_alpha)) erfc_a = erfc_and_gauss(fp.ewald_alpha * r, gauss_a); // the ONE erfc of this pair
 					if (es_pair) {
 						e_re = fma(qq * erfc_a, ir, e_re);
 						n_es++;
+						if (EXT && fp.fh_order) { // coulombic_real_FH :1521-1557 (added WITHOUT the charge product, as the reference does :1499-1500)
+							const double al = fp.ewald_alpha, a2 = al * al, a3 = a2 * al;
+							const double imu = imm_i + s_imm[jl];
+							const double ir2 = ir * ir, ir3 = ir2 * ir, ir4 = ir2 * ir2;
+							const double isp = kOneOverSqrtPi;
+							const double du = -2.0 * al * gauss_a * ir * isp - erfc_a * ir2;
+							const double d2u = 4.0 * isp * gauss_a * (a3 + ir2) + 2.0 * erfc_a * ir3;
+							double corr = fp.fh_c2 * imu * (d2u + 2.0 * du * ir);
+							if (fp.fh_order >= 4) {
+								const double d3u = gauss_a * isp * (-8.0 * (a3 * a2) * r - 8.0 * a3 * ir - 12.0 * al * ir3) - 6.0 * erfc_a * ir4;
+								const double d4u = gauss_a * isp * (8.0 * a3 * a2 + 16.0 * a3 * (a3 * al) * ri2 + 32.0 * a3 * ir2 + 48.0 * ir4) + 24.0 * erfc_a * (ir4 * ir);
+								corr += fp.fh_c4 * (imu * imu) * (15.0 * du * ir3 + 4.0 * d3u * ir + d4u);
+							}
+							e_re += corr;
+						}
 					} // (the intramolecular charge-to-screen term, :1503-1504, is summed by k_intra_terms)
 					if (FIELD == 1 && fld_pair) { // real_term :2919-2934: erfc form, or erf form (= 1 - erfc) for es_excluded pairs
 						const double ap = fp.polar_ewald_alpha;
@@ -290,6 +332,13 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 template <bool ORTHO, bool ES, int FIELD, bool THOLE>
 static void launch_fused_t(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, const int *cls,
                            int ntp, double *bpart, int *bcnt, double *fpart, double2 *ab) {
+	if ((ES && fp.wolf) || fp.fh_order) { // extended variant (Wolf / Feynman-Hibbs): DPP rotation only when the self-test allows it
+		if (dpp)
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+		else
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+		return;
+	}
 	if (dpp)
 		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
 	else

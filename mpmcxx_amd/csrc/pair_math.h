@@ -50,6 +50,7 @@ struct Box {
 	//   ri2 <= t_lj   <=>   sqrt(ri2) - 1e-12 < cutoff      (lj :934, thole_field_nopbc :3319)
 	//   ri2 <= t_es   <=>   !(sqrt(ri2) > cutoff)           (coulombic_real :1490, real_term :2917)
 	double t_lj, t_es;
+	double t_wolf; //   ri2 <= t_wolf <=>   sqrt(ri2) < cutoff              (coulombic_wolf :1443)
 	int ortho;     // 1 when basis (and therefore reciprocal) is diagonal
 };
 

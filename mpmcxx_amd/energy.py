@@ -40,9 +40,10 @@ class Options(C.Structure):
     _fields_ = [
         ("rd_only", C.c_int32), ("rd_lrc", C.c_int32), ("polarization", C.c_int32), ("polar_iterative", C.c_int32),
         ("polar_ewald", C.c_int32), ("polar_max_iter", C.c_int32), ("polar_gs", C.c_int32), ("polar_rrms", C.c_int32),
-        ("damp_type", C.c_int32), ("ewald_kmax", C.c_int32), ("solver", C.c_int32), ("reserved0", C.c_int32),
+        ("damp_type", C.c_int32), ("ewald_kmax", C.c_int32), ("solver", C.c_int32), ("wolf", C.c_int32),
         ("polar_precision", C.c_double), ("polar_gamma", C.c_double), ("polar_damp", C.c_double),
         ("ewald_alpha", C.c_double), ("polar_ewald_alpha", C.c_double), ("unsupported_flags", C.c_uint64),
+        ("feynman_hibbs", C.c_int32), ("feynman_hibbs_order", C.c_int32), ("temperature", C.c_double),
     ]
 
 
@@ -147,10 +148,11 @@ def pbc_compute(basis: np.ndarray):
 def make_options(opts: Dict[str, object]) -> Options:
     o = Options()
     lib().mpmc_default_options(C.byref(o))
-    for k in ("rd_only", "rd_lrc", "polarization", "polar_iterative", "polar_ewald", "polar_max_iter", "polar_gs", "polar_rrms", "ewald_kmax"):
+    for k in ("rd_only", "rd_lrc", "polarization", "polar_iterative", "polar_ewald", "polar_max_iter", "polar_gs", "polar_rrms", "ewald_kmax",
+              "wolf", "feynman_hibbs", "feynman_hibbs_order"):
         if k in opts and opts[k] is not None:
             setattr(o, k, int(opts[k]))
-    for k in ("polar_precision", "polar_gamma", "polar_damp"):
+    for k in ("polar_precision", "polar_gamma", "polar_damp", "temperature"):
         if k in opts and opts[k] is not None:
             setattr(o, k, float(opts[k]))
     for k in ("ewald_alpha", "polar_ewald_alpha"):

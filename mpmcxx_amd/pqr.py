@@ -21,7 +21,7 @@ E2REDUCED = 408.7816  # reference src/constants.h:35
 
 # keywords that select physics outside SURVEY §8 -- the replacement must refuse them (§8a note 7)
 UNSUPPORTED_ON = [
-    "wolf", "feynman_hibbs", "rd_crystal", "spectre", "gwp", "sg", "polarvdw", "cdvdw", "polar_ewald_full",
+    "rd_crystal", "spectre", "gwp", "sg", "polarvdw", "cdvdw", "polar_ewald_full",
     "polar_wolf", "polar_wolf_full", "polar_palmo", "polar_gs_ranked", "polar_sor", "polar_esor", "polar_zodid",
     "waldmanhagler", "halgren_mixing", "c6_mixing", "dreiding", "lj_buffered_14_7", "disp_expansion",
     "axilrod_teller", "rd_anharmonic", "cavity_autoreject", "cavity_autoreject_absolute", "cuda", "opencl",
@@ -97,6 +97,7 @@ def read_input(path: str) -> Dict[str, object]:
         "rd_only": 0, "rd_lrc": 1, "polarization": 0, "polar_iterative": 0, "polar_ewald": 0, "polar_max_iter": 10,
         "polar_gs": 0, "polar_rrms": 0, "ewald_kmax": 7, "polar_precision": 0.0, "polar_gamma": 1.0, "polar_damp": 0.0,
         "damp_type": None, "ewald_alpha": None, "polar_ewald_alpha": None,
+        "wolf": 0, "feynman_hibbs": 0, "feynman_hibbs_order": 0, "temperature": 0.0,
     }
     basis = np.zeros((3, 3), dtype=np.float64)
     pqr = None
@@ -115,11 +116,11 @@ def read_input(path: str) -> Dict[str, object]:
                 pqr = v[0]
             elif k == "ensemble":
                 ensemble = v[0].lower()
-            elif k in ("rd_only", "rd_lrc", "polarization", "polar_iterative", "polar_ewald", "polar_gs", "polar_rrms"):
+            elif k in ("rd_only", "rd_lrc", "polarization", "polar_iterative", "polar_ewald", "polar_gs", "polar_rrms", "wolf", "feynman_hibbs"):
                 opts[k] = _onoff(v[0])
-            elif k in ("polar_max_iter", "ewald_kmax"):
+            elif k in ("polar_max_iter", "ewald_kmax", "feynman_hibbs_order"):
                 opts[k] = int(v[0])
-            elif k in ("polar_precision", "polar_gamma", "polar_damp", "ewald_alpha", "polar_ewald_alpha"):
+            elif k in ("polar_precision", "polar_gamma", "polar_damp", "ewald_alpha", "polar_ewald_alpha", "temperature"):
                 opts[k] = float(v[0])
             elif k == "polar_damp_type":
                 opts["damp_type"] = v[0].lower()

@@ -244,6 +244,16 @@ def fixture(name: str):
         return lattice_box(216, 24.0, 7), cubic(24.0), o
     if name == "water64_polar":  # SURVEY §4 molecular fixture: exclusions, intramolecular erf, quirk 2
         return molecular_box(64, 14.0, 5), cubic(14.0), dict(POLAR_OPTS)
+    if name == "ion216_wolf":  # Wolf electrostatics instead of Ewald (coulombic_wolf)
+        return lattice_box(216, 24.0, 7), cubic(24.0), {"wolf": "on"}
+    if name == "water64_fh2":  # Feynman-Hibbs second-order corrections to LJ and real-space Coulomb
+        return molecular_box(64, 14.0, 5), cubic(14.0), {"feynman_hibbs": "on", "feynman_hibbs_order": 2, "temperature": 77.0}
+    if name == "water64_fh4":
+        return molecular_box(64, 14.0, 5), cubic(14.0), {"feynman_hibbs": "on", "feynman_hibbs_order": 4, "temperature": 40.0}
+    if name == "ion216_fh4_polar":
+        o = dict(POLAR_OPTS)
+        o.update({"feynman_hibbs": "on", "feynman_hibbs_order": 4, "temperature": 30.0})
+        return lattice_box(216, 24.0, 7), cubic(24.0), o
     if name == "lj1000":  # BASELINE config 2
         return lattice_box(1000, 40.0, 11, charged=False, alpha=0.0), cubic(40.0), {"rd_only": "on"}
     if name == "ion1000_polar":
@@ -258,6 +268,7 @@ def fixture(name: str):
 SMALL_FIXTURES = [
     "ar2", "lj64", "ion64_es", "ion216_polar", "ion216_polar_nopbc", "ion216_triclinic", "ion216_frozen",
     "ion216_precision", "ion216_gamma", "ion216_alpha", "water64_polar", "lj1000", "ion1000_polar",
+    "ion216_wolf", "water64_fh2", "water64_fh4", "ion216_fh4_polar",
 ]
 LARGE_FIXTURES = ["ion10k_es", "ion10k_polar"]
 

@@ -19,6 +19,53 @@ static const double ORC_MAXVALUE = 1.0e40;   /* constants.h:53 */
 static const double ORC_SMALL_DR = 1.0e-12;  /* constants.h:54 */
 static const double ORC_MAX_ITER = 128;      /* constants.h:52 */
 static const double ORC_DEBYE2SKA = 85.10597636; /* constants.h:41 */
+/* Feynman-Hibbs constants, constants.h:17-37 */
+static const double ORC_HBAR2 = 1.11211999e-68, ORC_HBAR4 = 1.23681087e-136, ORC_KB = 1.3806503e-23, ORC_KB2 = 1.90619525e-46;
+static const double ORC_M2A2 = 1.0e20, ORC_M2A4 = 1.0e40, ORC_AMU2KG = 1.66053873e-27;
+
+/* mass of the molecule that owns atom i (molecules are contiguous runs; Molecule::mass accumulates atom masses, System.cpp:687) */
+static double molecule_mass(const orc_system *s, int i) {
+	double m = 0;
+	int a = i, b = i;
+	while (a > 0 && s->mol_id[a - 1] == s->mol_id[i]) a--;
+	while (b + 1 < s->n && s->mol_id[b + 1] == s->mol_id[i]) b++;
+	for (int k = a; k <= b; k++) m += s->mass[k];
+	return m;
+}
+static double reduced_mass(const orc_system *s, int i, int j) {
+	double mi = molecule_mass(s, i), mj = molecule_mass(s, j);
+	return ORC_AMU2KG * mi * mj / (mi + mj);
+}
+/* lj_fh_corr, System.Energy.cpp:1100-1148 */
+static double lj_fh_corr(const orc_system *s, int i, int j, double epsilon, double rimg, double term12, double term6) {
+	double ir = 1.0 / rimg, ir2 = ir * ir, ir3 = ir2 * ir, ir4 = ir3 * ir;
+	double mu = reduced_mass(s, i, j), T = s->temperature;
+	double dE = -24.0 * epsilon * (2.0 * term12 - term6) * ir;
+	double d2E = 24.0 * epsilon * (26.0 * term12 - 7.0 * term6) * ir2;
+	double corr = ORC_M2A2 * (ORC_HBAR2 / (24.0 * ORC_KB * T * mu)) * (d2E + 2.0 * dE / rimg);
+	if (s->feynman_hibbs_order >= 4) {
+		double d3E = -1344.0 * epsilon * (6.0 * term12 - term6) * ir3;
+		double d4E = 12096.0 * epsilon * (10.0 * term12 - term6) * ir4;
+		corr += ORC_M2A4 * (ORC_HBAR4 / (1152.0 * ORC_KB2 * T * T * mu * mu)) * (15.0 * dE * ir3 + 4.0 * d3E * ir + d4E);
+	}
+	return corr;
+}
+/* coulombic_real_FH, System.Energy.cpp:1521-1557 */
+static double coulombic_real_fh(const orc_system *s, int i, int j, double r, double gaussian_term, double erfc_term) {
+	double rr = r * r, ir = 1.0 / r, ir2 = ir * ir, ir3 = ir * ir2, ir4 = ir2 * ir2;
+	double alpha = s->ewald_alpha, a2 = alpha * alpha, a3 = a2 * alpha, a4 = a3 * alpha;
+	double mu = reduced_mass(s, i, j), T = s->temperature;
+	double du = -2.0 * alpha * gaussian_term / (r * sqrt(ORC_PI)) - erfc_term * ir2;
+	double d2u = (4.0 / sqrt(ORC_PI)) * gaussian_term * (a3 + 1.0 * ir2) + 2.0 * erfc_term * ir3;
+	double fh2 = ORC_M2A2 * (ORC_HBAR2 / (24.0 * ORC_KB * T * mu)) * (d2u + 2.0 * du / r);
+	double fh4 = 0.0;
+	if (s->feynman_hibbs_order >= 4) {
+		double d3u = (gaussian_term / sqrt(ORC_PI)) * (-8.0 * (a3 * a2) * r - 8.0 * a3 / r - 12.0 * alpha * ir3) - 6.0 * erfc(alpha * r) * ir4;
+		double d4u = (gaussian_term / sqrt(ORC_PI)) * (8.0 * a3 * a2 + 16.0 * a3 * a4 * rr + 32.0 * a3 * ir2 + 48.0 * ir4) + 24.0 * erfc_term * (ir4 * ir);
+		fh4 = ORC_M2A4 * (ORC_HBAR4 / (1152.0 * (ORC_KB * ORC_KB * T * T * mu * mu))) * (15.0 * du * ir3 + 4.0 * d3u / r + d4u);
+	}
+	return fh2 + fh4;
+}
 
 /* ---------------------------------------------------------------------------------------------
  * PeriodicBoundary::compute_volume :71-79, compute_cutoff :40-66, compute_reciprocal :83-101
@@ -164,6 +211,7 @@ double orc_lj(const orc_system *s, orc_result *out) {
 				double sor12 = sor6 * sor6;
 				double term12 = pp.attractive_only ? 0 : sor12;
 				rd += 4.0 * pp.epsilon * (term12 - sor6); /* :993 */
+				if (s->feynman_hibbs) rd += lj_fh_corr(s, i, j, pp.epsilon, rimg, term12, sor6); /* :998-999 */
 				n_in++;
 			}
 			potential += rd + lrc; /* :1011 */
@@ -208,7 +256,10 @@ double orc_coulombic_real(const orc_system *s, orc_result *out) {
 				double r = orc_minimum_image(s, i, j, dimg, &rr);
 				if (!((r > s->cutoff) || pp.es_excluded)) { /* :1490 */
 					double erfc_term = erfc(alpha * r);
+					double gaussian_term = exp(-alpha * alpha * r * r);
 					es_real = s->charge[i] * s->charge[j] * erfc_term / r; /* :1495 */
+					/* the FH term is NOT multiplied by the charges in the reference (:1499-1500 adds the bare derivative expression) */
+					if (s->feynman_hibbs) es_real += coulombic_real_fh(s, i, j, r, gaussian_term, erfc_term);
 					n_in++;
 				} else if (pp.es_excluded) /* :1503-1504, plain (non-image) r */
 					es_self_intra = s->charge[i] * s->charge[j] * erf(alpha * rr) / rr;
@@ -218,6 +269,25 @@ double orc_coulombic_real(const orc_system *s, orc_result *out) {
 	}
 	if (out) out->n_es_in_cutoff = n_in;
 	return potential;
+}
+
+/* coulombic_wolf, System.Energy.cpp:1420-1462 */
+double orc_coulombic_wolf(const orc_system *s) {
+	double pot = 0, alpha = s->ewald_alpha, R = s->cutoff, iR = 1.0 / R, erfaRoverR = erf(alpha * R) / R;
+	for (int i = 0; i < s->n; i++)
+		for (int j = i + 1; j < s->n; j++) {
+			pair_par pp;
+			double dimg[3], rr;
+			pair_params(s, i, j, &pp);
+			double es = 0;
+			if (!pp.frozen || s->polarization) {
+				double r = orc_minimum_image(s, i, j, dimg, &rr);
+				double ir = 1.0 / r;
+				if (!pp.frozen && !pp.es_excluded && (r < R)) es = s->charge[i] * s->charge[j] * (ir - erfaRoverR - iR * iR * (R - r));
+			}
+			pot += es;
+		}
+	return pot;
 }
 
 /* hemisphere enumeration shared by coulombic_reciprocal :1577-1583 and recip_term :2849-2854 */
@@ -556,10 +626,14 @@ int orc_energy(const orc_system *s, orc_result *out, double *ef_static, double *
 	memset(out, 0, sizeof(*out));
 	double rd = 0, es = 0, pol = 0, vdw = 0, three = 0;
 	if (!s->rd_only) {
-		out->es_real = orc_coulombic_real(s, out);
-		out->es_recip = orc_coulombic_reciprocal(s);
-		out->es_self = orc_coulombic_self(s);
-		es = out->es_real + out->es_recip + out->es_self; /* :1412 */
+		if (s->wolf) { /* coulombic() :1404-1405 */
+			es = orc_coulombic_wolf(s);
+		} else {
+			out->es_real = orc_coulombic_real(s, out);
+			out->es_recip = orc_coulombic_reciprocal(s);
+			out->es_self = orc_coulombic_self(s);
+			es = out->es_real + out->es_recip + out->es_self; /* :1412 */
+		}
 		if (s->polarization) pol = orc_polar(s, out, ef_static, mu, ef_induced);
 	}
 	rd = orc_lj(s, out);

@@ -35,6 +35,11 @@ typedef struct orc_system {
 	int ewald_kmax;
 	double polar_precision, polar_gamma, polar_damp;
 	double ewald_alpha, polar_ewald_alpha;
+	/* adjacent physics: Wolf electrostatics (coulombic_wolf :1420-1462) and Feynman-Hibbs corrections
+	 * (lj_fh_corr :1100-1148, coulombic_real_FH :1521-1557) */
+	int wolf, feynman_hibbs, feynman_hibbs_order;
+	double temperature;
+	const double *mass; /* [n] atom masses (amu); molecule mass = sum over the molecule (System.cpp:687) */
 } orc_system;
 
 typedef struct orc_result {
@@ -61,6 +66,7 @@ double orc_lj(const orc_system *s, orc_result *out);
 double orc_coulombic_real(const orc_system *s, orc_result *out);
 double orc_coulombic_reciprocal(const orc_system *s);
 double orc_coulombic_self(const orc_system *s);
+double orc_coulombic_wolf(const orc_system *s);
 void orc_thole_field(const orc_system *s, double *ef_static);
 /* one 3x3 block A[3i..][3j..] of thole_amatrix (System.Energy.cpp:2661-2770) */
 void orc_thole_amatrix_block(const orc_system *s, int i, int j, double block[9]);

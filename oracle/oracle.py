@@ -45,6 +45,11 @@ class OrcSystem(C.Structure):
         ("polar_damp", C.c_double),
         ("ewald_alpha", C.c_double),
         ("polar_ewald_alpha", C.c_double),
+        ("wolf", C.c_int),
+        ("feynman_hibbs", C.c_int),
+        ("feynman_hibbs_order", C.c_int),
+        ("temperature", C.c_double),
+        ("mass", C.POINTER(C.c_double)),
     ]
 
 
@@ -134,6 +139,7 @@ class OracleSystem:
             "mol_id": np.ascontiguousarray(atoms["mol_id"], dtype=np.int32),
             "frozen": np.ascontiguousarray(atoms["frozen"], dtype=np.int32),
             "has_disp": np.ascontiguousarray(atoms.get("has_disp", np.zeros(self.n, dtype=np.int32)), dtype=np.int32),
+            "mass": np.ascontiguousarray(atoms.get("mass", np.ones(self.n)), dtype=np.float64),
         }
         s = OrcSystem()
         s.n = self.n
@@ -160,6 +166,12 @@ class OracleSystem:
         # update_pbc defaults (reference System.cpp:871-874)
         s.ewald_alpha = float(ea) if ea is not None else 3.5 / cut
         s.polar_ewald_alpha = float(pea) if pea is not None else 3.5 / cut
+        s.wolf = int(o.get("wolf", 0))
+        s.feynman_hibbs = int(o.get("feynman_hibbs", 0))
+        fo = int(o.get("feynman_hibbs_order", 0) or 0)
+        s.feynman_hibbs_order = fo if fo in (2, 4) else 2  # check_feynman_hibbs_options defaults to 2 (SimulationControl.cpp:2497-2500)
+        s.temperature = float(o.get("temperature", 0.0) or 0.0)
+        s.mass = _dp(k["mass"])
         self.s = s
         self.recip, self.volume, self.cutoff = R, vol, cut
 

@@ -56,8 +56,6 @@ int device_for(System *s) {
 
 uint64_t unsupported_mask(System *s) {
 	uint64_t m = 0;
-	if (s->wolf) m |= MPMC_FLAG_WOLF;
-	if (s->feynman_hibbs) m |= MPMC_FLAG_FEYNMAN_HIBBS;
 	if (s->rd_crystal) m |= MPMC_FLAG_RD_CRYSTAL;
 	if (s->spectre) m |= MPMC_FLAG_SPECTRE;
 	if (s->gwp) m |= MPMC_FLAG_GWP;
@@ -144,6 +142,10 @@ extern "C" double __wrap__ZN6System6energyEv(System *s) {
 	o.polar_rrms = s->polar_rrms;
 	o.damp_type = s->damp_type;
 	o.ewald_kmax = s->ewald_kmax;
+	o.wolf = s->wolf;
+	o.feynman_hibbs = s->feynman_hibbs;
+	o.feynman_hibbs_order = s->feynman_hibbs_order;
+	o.temperature = s->temperature;
 	o.polar_precision = s->polar_precision;
 	o.polar_gamma = s->polar_gamma;
 	o.polar_damp = s->polar_damp;

@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(syms) >= 30
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, missing
-    assert L.mpmc_abi_version() == 1
+    assert L.mpmc_abi_version() == 2
 
 
 def test_code_object_is_gfx950():
@@ -38,7 +38,7 @@ def test_code_object_is_gfx950():
 
 def test_struct_layouts_match_header():
     # sizes the C side compiled with (guards the ctypes mirrors in mpmcxx_amd/energy.py)
-    assert ctypes.sizeof(energy.Options) == 12 * 4 + 5 * 8 + 8
+    assert ctypes.sizeof(energy.Options) == 12 * 4 + 5 * 8 + 8 + 2 * 4 + 8
     assert ctypes.sizeof(energy.Result) == 16 * 8 + 7 * 8 + 2 * 4
     assert ctypes.sizeof(energy.Timings) == 7 * 8 + 7 * 8
 

@@ -56,11 +56,11 @@ def test_write_pqr_roundtrips(cli, tmp_path):
 
 
 def test_out_of_scope_keyword_sets_the_refusal_flag(cli, tmp_path):
-    src = open(os.path.join(util.GOLDEN, "lj64.in")).read() + "wolf on\nfeynman_hibbs on\n"
+    src = open(os.path.join(util.GOLDEN, "lj64.in")).read() + "spectre on\nrd_crystal on\n"
     p = tmp_path / "x.in"
     p.write_text(src.replace("lj64.pqr", os.path.join(util.GOLDEN, "lj64.pqr")))
     out = subprocess.run([cli, str(p), "--parse"], stdout=subprocess.PIPE, text=True, check=True)
-    assert json.loads(out.stdout)["unsupported"] == 3  # MPMC_FLAG_WOLF | MPMC_FLAG_FEYNMAN_HIBBS
+    assert json.loads(out.stdout)["unsupported"] == 4 + 8  # MPMC_FLAG_RD_CRYSTAL | MPMC_FLAG_SPECTRE
 
 
 @pytest.mark.gpu
