@@ -113,10 +113,20 @@ def test_unsupported_options_are_refused():
         energy.System(atoms, basis, bad)
     assert ei.value.code == energy.ERR_UNSUPPORTED
     bad = dict(opts)
-    bad["unsupported_flags"] = 1  # wolf
+    bad["unsupported_flags"] = 1 << 2  # rd_crystal
     with pytest.raises(energy.MpmcError) as ei:
         energy.System(atoms, basis, bad)
     assert ei.value.code == energy.ERR_UNSUPPORTED
+    bad = dict(opts)
+    bad.update(feynman_hibbs=1, temperature=0.0)  # SimulationControl.cpp:2509: feynman_hibbs requires positive temperature
+    with pytest.raises(energy.MpmcError) as ei:
+        energy.System(atoms, basis, bad)
+    assert ei.value.code == energy.ERR_INVALID_SETTING
+    bad = dict(opts)
+    bad.update(feynman_hibbs=1, temperature=77.0, wolf=1)  # System.Energy.cpp:1448-1450: FH + es_wolf is not implemented
+    with pytest.raises(energy.MpmcError) as ei:
+        energy.System(atoms, basis, bad)
+    assert ei.value.code == 4002  # incompatible_settings
     bad = dict(opts)
     bad["polar_max_iter"] = 0
     with pytest.raises(energy.MpmcError) as ei:
