@@ -2,9 +2,13 @@
 //   energy_cli INPUT.in            one JSON line: energy components (%.17g), counts, first dipole
 //   energy_cli INPUT.in --parse    parse only (no GPU): n, basis, options and per-atom arrays, for checking the readers
 //   energy_cli INPUT.in --write OUT.pqr   re-write the geometry in the reference's PQR row layout
+//   energy_cli INPUT.in --pi B0.pqr B1.pqr ...          path-integral energy estimator over the P bead geometries given
+//   energy_cli INPUT.in --pi-kinetic B0.pqr B1.pqr ...  kinetic part only (host arithmetic, no GPU)
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <vector>
 
 #include "mpmc_io.hpp"
 
@@ -14,6 +18,31 @@ int main(int argc, char **argv) {
 		return 2;
 	}
 	try {
+		if (argc > 3 && !std::strncmp(argv[2], "--pi", 4)) {
+			const bool kinetic_only = !std::strcmp(argv[2], "--pi-kinetic");
+			std::vector<std::unique_ptr<mpmc::System>> beads;
+			mpmc::PathIntegralEnsemble pi;
+			for (int b = 3; b < argc; b++) {
+				beads.emplace_back(new mpmc::System());
+				mpmc::read_input(argv[1], *beads.back());
+				mpmc::read_pqr(argv[b], *beads.back());
+				beads.back()->update_pbc();
+				pi.systems.push_back(beads.back().get());
+			}
+			pi.nSys = (int)beads.size();
+			pi.temperature = beads[0]->temperature;
+			const mpmc::observables_t &o = pi.sys_observables;
+			if (kinetic_only) {
+				const double k = pi.PI_calculate_kinetic();
+				std::printf("{\"P\": %d, \"N\": %.17g, \"kinetic\": %.17g, \"chain_mass_len2\": %.17g, \"chain0\": %.17g}\n", pi.nSys, o.N, k,
+				            pi.PI_chain_mass_length2_ENTIRE_SYSTEM(), pi.PI_chain_mass_length2(0));
+				return 0;
+			}
+			const double e = pi.PI_calculate_energy();
+			std::printf("{\"P\": %d, \"N\": %.17g, \"energy\": %.17g, \"kinetic\": %.17g, \"rd\": %.17g, \"es\": %.17g, \"polar\": %.17g}\n", pi.nSys,
+			            o.N, e, o.kinetic_energy, o.rd_energy, o.coulombic_energy, o.polarization_energy);
+			return 0;
+		}
 		mpmc::System s;
 		mpmc::load_system(argv[1], s);
 		if (argc > 3 && !std::strcmp(argv[2], "--write")) {

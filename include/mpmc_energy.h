@@ -221,6 +221,16 @@ int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sums4[4], mpmc
 /* obs = sums / P ; returns V = rd + coulombic + vdw + polarization (:786-804) */
 double mpmc_pi_finish(const double sums4_global[4], int P, double obs4[4]);
 
+/* ---- SimulationControl::PI_calculate_kinetic (PathIntegral.cpp:806-824) and its chain measure (:851-965) ----
+ * Host-side O(P * n_molecules); no device work.  com: centres of mass [P][n_molecules][3] of the P images of every
+ * molecule (Molecule::update_COM, src/Molecule.cpp:259-281; mpmc_update_com returns one bead's block),
+ * mol_mass[n_molecules] = Molecule::mass of image 0, movable[m] != 0 iff image 0 of molecule m is neither frozen,
+ * adiabatic nor target (:881).  Returns sum_m M_m * AMU2KG * 1e-20 * sum_i |com_i - com_{(i+1)%P}|^2  [kg m^2]. */
+double mpmc_pi_chain_mass_length2(int P, int n_molecules, const double *com, const double *mol_mass, const int32_t *movable);
+/* K [Kelvin] = (1/kB) * (0.5*3*N*kB*T*P - 0.5*omega2*chain_mass_len2), omega2 = P / (beta^2 hBar2)  (Tuckerman 12.5.12);
+ * N = System::countN() of image 0. */
+double mpmc_pi_kinetic(double chain_mass_len2, double orient_mu_len2, double N, int P, double temperature);
+
 /* ---- measurement ------------------------------------------------------------------------------------- */
 int mpmc_set_profiling(mpmc_ctx *ctx, int enabled); /* HIP-event timing of each kernel class on ctx's stream */
 int mpmc_get_timings(mpmc_ctx *ctx, mpmc_timings *out, int reset);

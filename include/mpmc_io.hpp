@@ -72,8 +72,8 @@ inline void read_pqr(const std::string &path, System &s) {
 		if (t.empty()) continue;
 		if (lower(t[0]).compare(0, 3, "end") == 0) break;
 		if (lower(t[0]) != "atom") continue;
+		if (t.size() > 3 && lower(t[3]) == "box") continue; // box-corner pseudo atoms carry a short row
 		if (t.size() < 16) throw 6000; // missing_required_datum
-		if (lower(t[3]) == "box") continue;
 		double v[11];
 		const int idx[11] = {6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 5};
 		for (int k = 0; k < 11; k++)

@@ -107,6 +107,33 @@ public:
 		box_dirty_ = true;
 	}
 	int countNatoms() const { return (int)atoms.size(); }
+	// System::countN, src/System.cpp:909-931: molecules that are not frozen (the flag of a molecule is that of its
+	// first atom, src/System.cpp:684; adiabatic / target molecules are refused by the readers)
+	unsigned int countN() {
+		unsigned int count = 0;
+		for (size_t i = 0; i < atoms.size(); i++)
+			if ((i == 0 || atoms[i].molecule != atoms[i - 1].molecule) && !atoms[i].frozen) count++;
+		observables->N = count;
+		return count;
+	}
+	// Molecule::update_COM for every molecule (src/Molecule.cpp:259-281): com [n_molecules][3], mass, movable flag
+	void molecule_coms(std::vector<double> &com, std::vector<double> &mol_mass, std::vector<int32_t> &movable) const {
+		com.clear();
+		mol_mass.clear();
+		movable.clear();
+		for (size_t a0 = 0; a0 < atoms.size();) {
+			size_t a1 = a0;
+			double m = 0, c[3] = {0, 0, 0};
+			for (; a1 < atoms.size() && atoms[a1].molecule == atoms[a0].molecule; a1++) {
+				m += atoms[a1].mass;
+				for (int d = 0; d < 3; d++) c[d] += atoms[a1].mass * atoms[a1].pos[d];
+			}
+			for (int d = 0; d < 3; d++) com.push_back(c[d] / m);
+			mol_mass.push_back(m);
+			movable.push_back(atoms[a0].frozen ? 0 : 1);
+			a0 = a1;
+		}
+	}
 
 	// call after changing atom parameters or the number of atoms (positions alone: move_atoms)
 	void atoms_changed() { atoms_dirty_ = true; }
@@ -311,14 +338,74 @@ public:
 // SimulationControl's multi-System part for ensemble pi_nvt (src/SimulationControl.h:60, PathIntegral.cpp:752-805).
 // `systems` holds the beads owned by THIS process; `nSys` is the Trotter number P over all processes.
 // The cross-process exchange of 4 doubles per bead (MPI_Allgather x4 in the reference) is delegated to
-// `allgather`: it receives this process's per-bead values (n_local x 4, local order) and must return all P x 4
+// `allgather`: it receives this process's per-bead values (n_local x stride, local order; stride = 4 for the
+// potential, 3 * n_molecules for the centres of mass of the kinetic estimator) and must return all P x stride
 // values in bead order.  With one process it may be left empty.
+// (The reference keeps all P images on every MPI rank, so its kinetic estimator needs no exchange; with the beads
+// sharded over ranks the ring of adjacent images crosses ranks and the centres of mass are gathered once per call.)
 class PathIntegralEnsemble {
 public:
 	std::vector<System *> systems;
 	int nSys = 0;
+	double temperature = 0;        // sys.temperature
 	observables_t sys_observables; // the aggregate "sys.observables" of the reference
 	std::function<std::vector<double>(const std::vector<double> &)> allgather;
+
+	// SimulationControl::PI_calculate_energy, PathIntegral.cpp:734-749
+	double PI_calculate_energy() {
+		const double kinetic = PI_calculate_kinetic();
+		const double potential = PI_calculate_potential();
+		sys_observables.energy = kinetic + potential;
+		return sys_observables.energy;
+	}
+
+	// SimulationControl::PI_calculate_kinetic, PathIntegral.cpp:806-824
+	double PI_calculate_kinetic() {
+		const double N = (double)systems.at(0)->countN();
+		const int P = nSys ? nSys : (int)systems.size();
+		const double chain_mass_len2 = PI_chain_mass_length2_ENTIRE_SYSTEM();
+		const double orient_mu_len2 = PI_orientational_mu_length2_ENTIRE_SYSTEM();
+		sys_observables.N = N;
+		sys_observables.kinetic_energy = mpmc_pi_kinetic(chain_mass_len2, orient_mu_len2, N, P, temperature);
+		return sys_observables.kinetic_energy;
+	}
+
+	// SimulationControl::PI_chain_mass_length2_ENTIRE_SYSTEM, PathIntegral.cpp:851-896
+	double PI_chain_mass_length2_ENTIRE_SYSTEM() {
+		std::vector<double> com, mass;
+		std::vector<int32_t> movable;
+		const int nmol = gather_coms(com, mass, movable);
+		const int P = nSys ? nSys : (int)systems.size();
+		return mpmc_pi_chain_mass_length2(P, nmol, com.data(), mass.data(), movable.data());
+	}
+	// SimulationControl::PI_chain_mass_length2() for one chain, PathIntegral.cpp:897-965 (`molecule` plays the part of
+	// checkpoint->molecule_altered: the index of the molecule whose bead chain was perturbed)
+	double PI_chain_mass_length2(int molecule) {
+		std::vector<double> com, mass;
+		std::vector<int32_t> movable;
+		const int nmol = gather_coms(com, mass, movable);
+		if (molecule < 0 || molecule >= nmol) throw (int)MPMC_ERR_ARG;
+		const int P = nSys ? nSys : (int)systems.size();
+		std::vector<double> one(3 * (size_t)P);
+		for (int s = 0; s < P; s++)
+			for (int d = 0; d < 3; d++) one[3 * s + d] = com[3 * ((size_t)s * nmol + molecule) + d];
+		return mpmc_pi_chain_mass_length2(P, 1, one.data(), &mass[molecule], nullptr);
+	}
+	double PI_orientational_mu_length2_ENTIRE_SYSTEM() { return 0.0; } // PathIntegral.cpp:970-972
+
+private:
+	int gather_coms(std::vector<double> &com, std::vector<double> &mass, std::vector<int32_t> &movable) {
+		std::vector<double> mine, c, m0;
+		std::vector<int32_t> mv;
+		for (size_t b = 0; b < systems.size(); b++) {
+			systems[b]->molecule_coms(c, b == 0 ? mass : m0, b == 0 ? movable : mv);
+			mine.insert(mine.end(), c.begin(), c.end());
+		}
+		com = allgather ? allgather(mine) : mine;
+		return (int)mass.size();
+	}
+
+public:
 
 	double PI_calculate_potential() {
 		const int n_local = (int)systems.size();

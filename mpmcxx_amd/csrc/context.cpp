@@ -1386,6 +1386,36 @@ extern "C" double mpmc_pi_finish(const double s[4], int P, double obs4[4]) {
 	return o[0] + o[1] + o[3] + o[2]; // rd + coulombic + vdw + polarization, :803-804
 }
 
+// PI_chain_mass_length2_ENTIRE_SYSTEM / PI_chain_mass_length2(vector<Molecule*>&), PathIntegral.cpp:851-965
+extern "C" double mpmc_pi_chain_mass_length2(int P, int nmol, const double *com, const double *mol_mass, const int32_t *movable) {
+	const double AMU2KG = 1.66053873e-27, ANGSTROM2METER = 1.0e-10; // src/constants.h:31,40
+	double sum = 0;
+	for (int m = 0; m < nmol; m++) {
+		if (movable && !movable[m]) continue; // :881
+		double len2 = 0;
+		for (int i = 0; i < P; i++) { // closed loop over adjacent images, :956-960
+			const int j = (i + 1) % P;
+			const double *a = com + 3 * ((size_t)i * nmol + m), *b = com + 3 * ((size_t)j * nmol + m);
+			const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+			len2 += dx * dx + dy * dy + dz * dz;
+		}
+		len2 *= (mol_mass[m] * AMU2KG) * (ANGSTROM2METER * ANGSTROM2METER); // :961
+		sum += len2;
+	}
+	return sum;
+}
+// PI_calculate_kinetic, PathIntegral.cpp:806-824
+extern "C" double mpmc_pi_kinetic(double chain_mass_len2, double orient_mu_len2, double N, int nP, double T) {
+	const double kB = 1.3806503e-23, hBar2 = 1.11211999e-68; // src/constants.h:17,20
+	(void)orient_mu_len2; // computed but not used by the reference's estimator (:815)
+	const double d = 3.0, P = (double)nP;
+	const double beta = 1.0 / (kB * T);
+	const double omega2 = P / (beta * beta * hBar2);
+	const double t1 = 0.5 * d * N * kB * T * P;
+	const double t2 = 0.5 * omega2 * chain_mass_len2;
+	return (1.0 / kB) * (t1 - t2);
+}
+
 // ---- measurement -----------------------------------------------------------------------------------------
 extern "C" int mpmc_set_profiling(mpmc_ctx *c, int enabled) {
 	if (!c) return MPMC_ERR_ARG;

@@ -106,6 +106,10 @@ def lib():
     L.mpmc_update_com.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_int)]
     L.mpmc_pi_potential_local.argtypes = [C.POINTER(vp), C.c_int, dp, C.POINTER(Result), C.POINTER(C.c_int)]
     L.mpmc_pi_finish.argtypes = [dp, C.c_int, dp]
+    L.mpmc_pi_chain_mass_length2.argtypes = [C.c_int, C.c_int, dp, dp, ip]
+    L.mpmc_pi_chain_mass_length2.restype = C.c_double
+    L.mpmc_pi_kinetic.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
+    L.mpmc_pi_kinetic.restype = C.c_double
     L.mpmc_pi_finish.restype = C.c_double
     L.mpmc_set_profiling.argtypes = [vp, C.c_int]
     L.mpmc_get_timings.argtypes = [vp, C.POINTER(Timings), C.c_int]
@@ -366,3 +370,18 @@ def pi_finish(sums4_global: np.ndarray, P: int):
     obs = np.zeros(4)
     v = lib().mpmc_pi_finish(_dp(s), int(P), _dp(obs))
     return v, obs
+
+
+def pi_chain_mass_length2(coms: np.ndarray, mol_mass: np.ndarray, movable: Optional[np.ndarray] = None) -> float:
+    """SimulationControl::PI_chain_mass_length2_ENTIRE_SYSTEM (reference PathIntegral.cpp:851-965).
+    coms: (P, n_molecules, 3) centres of mass of the P images; host arithmetic inside libmpmc_energy.so."""
+    c = np.ascontiguousarray(coms, dtype=np.float64)
+    P, nmol, _ = c.shape
+    m = np.ascontiguousarray(mol_mass, dtype=np.float64)
+    mv = None if movable is None else np.ascontiguousarray(movable, dtype=np.int32)
+    return float(lib().mpmc_pi_chain_mass_length2(P, nmol, _dp(c), _dp(m), _ip(mv)))
+
+
+def pi_kinetic(chain_mass_len2: float, N: float, P: int, temperature: float, orient_mu_len2: float = 0.0) -> float:
+    """SimulationControl::PI_calculate_kinetic (reference PathIntegral.cpp:806-824), Kelvin."""
+    return float(lib().mpmc_pi_kinetic(float(chain_mass_len2), float(orient_mu_len2), float(N), int(P), float(temperature)))

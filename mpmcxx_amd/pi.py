@@ -7,6 +7,10 @@ divides by P (:786-801).  Here the beads are independent device contexts sharded
 ``s % world``, local slot ``s // world``); the exchange is ONE collective of 4 fp64 per bead over
 ``torch.distributed`` (backend nccl == RCCL over xGMI on the GPU node, gloo in the CPU tests).
 
+The kinetic half of the estimator (``PI_calculate_kinetic``, :806-824) needs the centres of mass of ADJACENT images of
+every molecule (``PI_chain_mass_length2``, :908-965).  The reference keeps all P images on every MPI rank; here the ring
+of images crosses ranks, so ``pi_calculate_kinetic`` all-gathers 3 fp64 per molecule and bead once per call.
+
 ``mode="gather"`` (default) all-gathers the per-bead values and sums them in bead order, which reproduces the
 reference's summation order bit for bit on every rank; ``mode="reduce"`` all-reduces the rank-local partial sums
 (one 32-byte message, order differs in the last bit).
@@ -65,3 +69,57 @@ def pi_calculate_potential(local_eval: Callable[[], np.ndarray], P: int, rank: i
                            mode: str = "gather", device: Optional[str] = None) -> Tuple[float, np.ndarray]:
     """local_eval() -> (n_local, 4) per-bead energies of this rank (HIP path: energy.pi_potential_local)."""
     return combine(local_eval(), P, rank, world, group, mode, device)
+
+
+def molecule_coms(pos: np.ndarray, mass: np.ndarray, mol_id: np.ndarray, frozen: np.ndarray):
+    """Molecule::update_COM for every molecule of one image (reference src/Molecule.cpp:259-281), accumulated in atom
+    order like the reference's list walk.  Returns (com (n_molecules, 3), mol_mass, movable): movable[m] = image 0's
+    molecule m counts in System::countN (src/System.cpp:909-931), i.e. its first atom is not frozen (:684)."""
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 3)
+    mass = np.asarray(mass, dtype=np.float64)
+    mol_id = np.asarray(mol_id)
+    n = len(mass)
+    first = np.flatnonzero(np.r_[True, mol_id[1:] != mol_id[:-1]]) if n else np.zeros(0, dtype=int)
+    seg = np.cumsum(np.r_[True, mol_id[1:] != mol_id[:-1]]) - 1 if n else np.zeros(0, dtype=int)
+    nmol = len(first)
+    m = np.zeros(nmol)
+    c = np.zeros((nmol, 3))
+    np.add.at(m, seg, mass)  # unbuffered, in atom order
+    np.add.at(c, seg, mass[:, None] * pos)
+    return c / m[:, None], m, (np.asarray(frozen)[first] == 0).astype(np.int32)
+
+
+def gather_beads(local: np.ndarray, P: int, rank: int = 0, world: int = 1, group=None, device: Optional[str] = None) -> np.ndarray:
+    """local: (n_local, ...) values of this rank's beads in local-slot order -> (P, ...) in bead order (bead = slot * world + rank)."""
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    if world == 1:
+        return local
+    import torch
+    import torch.distributed as dist
+
+    n_local = local.shape[0]
+    if P % world or n_local != P // world:
+        raise ValueError("every rank must own P / world beads")
+    dev = device or "cpu"
+    mine = torch.from_numpy(local.reshape(n_local, -1).copy()).to(dev)
+    gathered = torch.empty((world * n_local, mine.shape[1]), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    g = gathered.cpu().numpy().reshape((world, n_local) + local.shape[1:])
+    return np.ascontiguousarray(np.swapaxes(g, 0, 1).reshape((P,) + local.shape[1:]))
+
+
+def pi_calculate_kinetic(local_coms: np.ndarray, mol_mass: np.ndarray, movable: np.ndarray, P: int, temperature: float,
+                         rank: int = 0, world: int = 1, group=None, device: Optional[str] = None) -> Tuple[float, float]:
+    """SimulationControl::PI_calculate_kinetic (reference PathIntegral.cpp:806-824).  local_coms: (n_local, n_molecules, 3)
+    from `molecule_coms` of this rank's beads.  Returns (K [Kelvin], chain_mass_len2 [kg m^2])."""
+    from . import energy as _e
+
+    coms = gather_beads(local_coms, P, rank, world, group, device)
+    chain = _e.pi_chain_mass_length2(coms, mol_mass, movable)
+    N = float(np.count_nonzero(movable))
+    return _e.pi_kinetic(chain, N, P, temperature), chain
+
+
+def pi_calculate_energy(kinetic: float, potential: float) -> float:
+    """SimulationControl::PI_calculate_energy (PathIntegral.cpp:734-749): estimator = kinetic + potential."""
+    return kinetic + potential

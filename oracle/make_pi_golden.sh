@@ -1,0 +1,25 @@
+#!/bin/bash
+# oracle/make_pi_golden.sh -- regenerates the stock-binary path-integral goldens under tests/golden/{pi001,pi_ion27}
+# by running the UNMODIFIED reference executable (oracle/_ref/mpmcxx, built in place by `make -C oracle ref`) on the
+# committed inputs.  Test infrastructure; needs /root/reference (container only).  Outputs are data: the energy / dipole /
+# field traces, the final averages block and the final bead geometries ("long_output on" = %.6f coordinates).
+set -euo pipefail
+here=$(cd "$(dirname "$0")" && pwd)
+G=$here/../tests/golden
+BIN=$here/_ref/mpmcxx
+run_case() { # dir input P job
+	local d
+	d=$(mktemp -d)
+	cp "$G/$1"/*.in "$G/$1"/*.pqr "$d"/
+	rm -f "$d"/golden_*
+	(cd "$d" && "$BIN" -P "$3" "$2" >stock.log 2>&1)
+	grep -v '^#' "$d/$4.energy.dat" >/dev/null
+	cp "$d/$4.energy.dat" "$G/$1/golden_energy.dat"
+	for f in "$d/$4".final-*.pqr; do cp "$f" "$G/$1/golden_${f##*/$4.}"; done
+	for k in dipole field; do [ -s "$d/$4.$k.dat" ] && cp "$d/$4.$k.dat" "$G/$1/golden_$k.dat"; done
+	grep -E '^OUTPUT: (AR =|total energy|kinetic energy|polarization energy)' "$d/stock.log" | tail -12 >"$G/$1/golden_final_averages.txt"
+	echo "$1: $(grep -vc '^#' "$G/$1/golden_energy.dat") energy rows"
+	rm -rf "$d"
+}
+run_case pi001 equilibrate.in 8 ArAr2K
+run_case pi_ion27 input.in 4 ion27

@@ -658,6 +658,55 @@ double orc_pi_aggregate(int P, const double *rd, const double *es, const double 
 	return o[0] + o[1] + o[3] + o[2]; /* rd + coulombic + vdw + polarization (:803-804) */
 }
 
+/* PI_calculate_kinetic, SimulationControl.PathIntegral.cpp:806-824, with PI_chain_mass_length2_ENTIRE_SYSTEM (:851-896),
+ * PI_chain_mass_length2(vector<Molecule*>&) (:908-965) and Molecule::update_COM (src/Molecule.cpp:259-281) restated on
+ * flat arrays: pos [P][n][3] (image-major), mass[n], mol[n] (consecutive equal ids = one molecule), frozen[n] (the
+ * molecule flag is that of its first atom, src/System.cpp:684).  Returns K in Kelvin; *chain_out = chain_mass_len2. */
+double orc_pi_kinetic(int P, int n, const double *pos, const double *mass, const int *mol, const int *frozen, double T, double *chain_out) {
+	const double kB = 1.3806503e-23, hBar2 = 1.11211999e-68, AMU2KG = 1.66053873e-27, A2M = 1.0e-10; /* constants.h */
+	double sum = 0, N = 0;
+	double *cx = (double *)malloc(sizeof(double) * 3 * (size_t)P);
+	for (int a0 = 0; a0 < n;) {
+		int a1 = a0;
+		while (a1 < n && mol[a1] == mol[a0]) a1++;
+		if (!frozen[a0]) { /* :881 (adiabatic / target molecules are outside the hot path) */
+			double M = 0;
+			N += 1.0; /* System::countN, src/System.cpp:909-931 */
+			for (int s = 0; s < P; s++) {
+				const double *p = pos + 3 * (size_t)s * n;
+				double m = 0, c0 = 0, c1 = 0, c2 = 0;
+				for (int a = a0; a < a1; a++) {
+					m += mass[a];
+					c0 += mass[a] * p[3 * a + 0];
+					c1 += mass[a] * p[3 * a + 1];
+					c2 += mass[a] * p[3 * a + 2];
+				}
+				cx[3 * s + 0] = c0 / m;
+				cx[3 * s + 1] = c1 / m;
+				cx[3 * s + 2] = c2 / m;
+				if (s == 0) M = m;
+			}
+			double len2 = 0;
+			for (int i = 0; i < P; i++) {
+				const int j = (i + 1) % P;
+				const double dx = cx[3 * i] - cx[3 * j], dy = cx[3 * i + 1] - cx[3 * j + 1], dz = cx[3 * i + 2] - cx[3 * j + 2];
+				len2 += dx * dx + dy * dy + dz * dz;
+			}
+			len2 *= (M * AMU2KG) * (A2M * A2M);
+			sum += len2;
+		}
+		a0 = a1;
+	}
+	free(cx);
+	if (chain_out) *chain_out = sum;
+	const double d = 3.0, Pd = (double)P;
+	const double beta = 1.0 / (kB * T);
+	const double omega2 = Pd / (beta * beta * hBar2);
+	const double t1 = 0.5 * d * N * kB * T * Pd;
+	const double t2 = 0.5 * omega2 * sum;
+	return (1.0 / kB) * (t1 - t2);
+}
+
 /* ---------------------------------------------------------------------------------------------
  * CPU-baseline timing on a BOUNDED SAMPLE of one evaluation (bench.py cpu_baseline leg only).
  * Every O(N^2) stage of energy() is executed for the rows i = 0, stride, 2*stride, ... only, with exactly the

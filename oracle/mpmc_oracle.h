@@ -76,6 +76,8 @@ double orc_polar(const orc_system *s, orc_result *out, double *ef_static, double
 /* PI_calculate_potential aggregate (SimulationControl.PathIntegral.cpp:786-804):
  * ordered sum over beads s=0..P-1, divided by P.  out4 = {rd, coulombic, polarization, vdw}; returns V */
 double orc_pi_aggregate(int P, const double *rd, const double *es, const double *pol, const double *vdw, double out4[4]);
+/* PI_calculate_kinetic (PathIntegral.cpp:806-824) over P images: pos [P][n][3]; returns Kelvin, *chain_out = chain_mass_len2 */
+double orc_pi_kinetic(int P, int n, const double *pos, const double *mass, const int *mol, const int *frozen, double T, double *chain_out);
 
 /* bench.py cpu_baseline leg: time every stage of ONE evaluation on the rows i = 0, stride, 2 stride, ... and
  * scale each stage by its exact work ratio; out_sec[6] = estimated seconds of one full evaluation. */

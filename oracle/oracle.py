@@ -104,6 +104,8 @@ def lib():
         L.orc_time_sample.restype = C.c_double
         L.orc_pi_aggregate.argtypes = [C.c_int, dp, dp, dp, dp, dp]
         L.orc_pi_aggregate.restype = C.c_double
+        L.orc_pi_kinetic.argtypes = [C.c_int, C.c_int, dp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_double, dp]
+        L.orc_pi_kinetic.restype = C.c_double
         _lib = L
     return _lib
 
@@ -219,3 +221,16 @@ def pi_aggregate(rd, es, pol, vdw=None):
     out = np.zeros(4)
     v = lib().orc_pi_aggregate(len(rd), _dp(rd), _dp(es), _dp(pol), _dp(vdw), _dp(out))
     return v, out
+
+
+def pi_kinetic(pos_beads, mass, mol_id, frozen, temperature):
+    """PI_calculate_kinetic restated (oracle/mpmc_oracle.c: orc_pi_kinetic).  pos_beads: (P, n, 3).  Returns (K [Kelvin], chain_mass_len2)."""
+    pos = np.ascontiguousarray(pos_beads, dtype=np.float64)
+    P, n, _ = pos.shape
+    mass = np.ascontiguousarray(mass, dtype=np.float64)
+    mol = np.ascontiguousarray(mol_id, dtype=np.int32)
+    fr = np.ascontiguousarray(frozen, dtype=np.int32)
+    chain = C.c_double()
+    ip = C.POINTER(C.c_int)
+    k = lib().orc_pi_kinetic(P, n, _dp(pos), _dp(mass), mol.ctypes.data_as(ip), fr.ctypes.data_as(ip), float(temperature), C.byref(chain))
+    return k, chain.value
