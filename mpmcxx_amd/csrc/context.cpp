@@ -34,7 +34,7 @@ struct mpmc_ctx {
 	hipStream_t stream2 = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	bool two_streams = true; // MPMC_ONE_STREAM=1 disables the fork/join
-	int jacc = 0; // j-side accumulation of the hybrid Jacobi kernel: 0 DPP rotation, 1 bpermute, 2 LDS ds_add_f64 (MPMC_JACC)
+	int jacc = 0; // hybrid Jacobi kernel variant (MPMC_JACC): 0 DPP rotation, 1 bpermute, 2 LDS ds_add_f64, 3 DPP with two waves per tile pair
 	bool jacobi_hybrid = true; // one launch per Jacobi iteration over all tile pairs; MPMC_JACOBI=split: two kernels (stream / far)
 	int max_atoms = 0, max_pad = 0;
 	int n = 0, n_pad = 0, n_tiles = 0, n_tile_pairs = 0, n_split = 1;
@@ -65,7 +65,9 @@ struct mpmc_ctx {
 	int *d_block_cnt = nullptr;     // [ntp][4] (2 used by the pair kernel, 4 by the static-count kernel)
 	int *d_cls = nullptr;           // tile-pair classes (CLS_*), recomputed every evaluation
 	int *d_lists = nullptr;         // [2 ntp] work lists of the two Jacobi kernels + [2] their lengths (at the end)
-	double *d_tile_bounds = nullptr; // [n_tiles][6]
+	double *d_tile_bounds = nullptr; // [n_tiles][12]: wrapped fractional lo/hi, raw Cartesian lo/hi
+	double4 *d_tp_shift = nullptr;   // [n_tile_pairs] lattice vector of the common image index (CLS_UNIFORM_IMG)
+	bool no_uniform = false;         // MPMC_NO_UNI=1
 	size_t cap_tile_pairs = 0;
 	long long static_cnt[4] = {0, 0, 0, 0}; // n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent)
 
@@ -350,6 +352,7 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	if (const char *e = std::getenv("MPMC_JACOBI")) c->jacobi_hybrid = (e[0] != 's');
 	c->jacc = c->use_dpp ? 0 : 1;
 	if (const char *e = std::getenv("MPMC_JACC")) c->jacc = std::atoi(e);
+	if (const char *e = std::getenv("MPMC_NO_UNI")) c->no_uniform = (e[0] == '1');
 	const size_t P = (size_t)c->max_pad;
 	A(dev_alloc(c, &c->d_xyzq, P));
 	A(dev_alloc(c, &c->d_lj, P));
@@ -357,7 +360,7 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	A(dev_alloc(c, &c->d_alpha, P));
 	A(dev_alloc(c, &c->d_eps, P));
 	A(dev_alloc(c, &c->d_inv_molmass, P));
-	A(dev_alloc(c, &c->d_tile_bounds, 6 * (P / kTile)));
+	A(dev_alloc(c, &c->d_tile_bounds, 12 * (P / kTile)));
 	A(dev_alloc(c, &c->d_slot_of, P));
 	A(dev_alloc(c, &c->d_perm, P));
 	A(dev_alloc(c, &c->d_scal, (size_t)S_COUNT));
@@ -390,7 +393,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_inv_molmass, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -636,12 +639,14 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 		dev_free(c, &c->d_block_part, 2 * c->cap_tile_pairs);
 		dev_free(c, &c->d_block_cnt, 4 * c->cap_tile_pairs);
 		dev_free(c, &c->d_cls, c->cap_tile_pairs);
+		dev_free(c, &c->d_tp_shift, c->cap_tile_pairs);
 		dev_free(c, &c->d_lists, 2 * c->cap_tile_pairs + 2);
 		c->cap_tile_pairs = 0;
 		if ((rc = dev_alloc(c, &c->d_tile_pairs, ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_block_part, 2 * ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_block_cnt, 4 * ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_cls, ntp)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_tp_shift, ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_lists, 2 * ntp + 2)) != MPMC_OK) return rc;
 		HIP_TRY(c, hipMemset(c->d_cls, 0, ntp * sizeof(int)));
 		c->cap_tile_pairs = ntp;
@@ -897,7 +902,7 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		// tile-pair classes from this configuration's tile bounding boxes (orthorhombic cells; all "near" otherwise)
 		if (c->no_classes) HIP_TRY(c, hipMemsetAsync(c->d_cls, 0, (size_t)c->n_tile_pairs * sizeof(int), st));
 		else launch_tile_classes(st, at, c->box, c->d_tile_pairs, c->n_tile_pairs, (o.polarization && !o.rd_only) ? o.polar_damp : 0.0,
-		                         c->d_tile_bounds, c->d_cls);
+		                         c->d_tile_bounds, c->d_cls, c->no_uniform ? nullptr : c->d_tp_shift);
 		FusedParams fp;
 		fp.ewald_alpha = c->ewald_alpha;
 		fp.polar_ewald_alpha = c->polar_ewald_alpha;
@@ -952,7 +957,8 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 			if (by_precision) HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
 			if (compact && c->jacobi_hybrid) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
-				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_ab, c->d_part);
+				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
+				                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part);
 			} else if (compact) {
 				const int *counts = c->d_lists + 2 * (size_t)c->n_tile_pairs;
 				hipStream_t s2 = fork_side(c); // the fp64-bound far-field kernel runs beside the HBM-bound streaming kernel

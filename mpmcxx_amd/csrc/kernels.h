@@ -34,7 +34,8 @@ enum : int { C_LJ_IN = 0, C_ES_IN, C_INTRA, C_RDX, C_ESX, C_FROZEN, C_COUNT = 8 
 // distance between the two tiles' bounding boxes
 enum : int {
 	CLS_BEYOND_CUTOFF = 1, // > cutoff: no pair of the tile pair passes any cutoff predicate
-	CLS_THOLE_FAR = 2      // lambda*r > 40 for every pair: exponential damping is below 1e-13, T is the bare dipole tensor
+	CLS_THOLE_FAR = 2,     // lambda*r > 40 for every pair: exponential damping is below 1e-13, T is the bare dipole tensor
+	CLS_UNIFORM_IMG = 4    // one periodic image index serves all 4096 pairs (tp_shift holds the lattice vector B img)
 };
 constexpr double kTholeFarX = 40.0; // exp(-40)*(40^3/6) = 4.5e-14
 
@@ -100,7 +101,7 @@ void launch_static_counts(hipStream_t st, const AtomsDev &at, const int2 *tile_p
 void launch_intra_terms(hipStream_t st, const AtomsDev &at, const int *slot_of, double ewald_alpha, double *scal);
 // per-tile bounding boxes (wrapped fractional coordinates) and tile-pair classes (CLS_*)
 void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, const int2 *tile_pairs, int n_tile_pairs, double polar_damp,
-                         double *tile_bounds /*[nt][6]*/, int *cls);
+                         double *tile_bounds /*[nt][12]*/, int *cls, double4 *tp_shift /*[ntp], may be null*/);
 // work lists of the two Jacobi kernels from the class array: lists[0..ntp) stored tile pairs, lists[ntp..2ntp) far ones
 void launch_build_lists(hipStream_t st, const int *cls, int n_tile_pairs, int *lists /*[2 ntp]*/, int *counts /*[2]*/);
 // one Jacobi contraction = these two launches (each partial slot is written by exactly one of them): part[nt][n_pad][3]
@@ -111,7 +112,8 @@ void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const 
 // single-launch alternative (all tile pairs, class read per block)
 // jacc: 0 DPP lane rotation, 1 ds_bpermute rotation, 2 ds_add_f64 into an LDS image of the j-atoms
 void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                               const int *cls, int n_tile_pairs, const double2 *ab, double *part);
+                               const int *cls, const double4 *tp_shift /*null: no uniform-image fast path*/, int n_tile_pairs,
+                               const double2 *ab, double *part);
 // lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
 void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm);
 

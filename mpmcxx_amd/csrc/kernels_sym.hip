@@ -408,33 +408,37 @@ void launch_intra_terms(hipStream_t st, const AtomsDev &at, const int *slot_of, 
 // ------------------------------------------------------------------------------------------------------
 // tile bounding boxes in wrapped fractional coordinates and tile-pair classes (orthorhombic cells only)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_tile_bounds(AtomsDev at, Box bx, double *__restrict__ tb /*[nt][6]*/) {
+__global__ __launch_bounds__(64) void k_tile_bounds(AtomsDev at, Box bx, double *__restrict__ tb /*[nt][12]*/) {
 	const int lane = threadIdx.x;
 	const int k = blockIdx.x * kTile + lane;
 	const double4 p = at.xyzq[k];
 	const bool real = !(at.mf[k].y & AF_PAD);
-	double lo[3], hi[3];
+	double lo[6], hi[6]; // 0..2 wrapped fractional coordinates, 3..5 raw Cartesian coordinates
 	const double pos[3] = {p.x, p.y, p.z};
 	for (int d = 0; d < 3; ++d) {
 		double f = bx.r[4 * d] * pos[d]; // diagonal cell: fractional coordinate
 		f -= floor(f);
 		lo[d] = real ? f : 2.0;
 		hi[d] = real ? f : -1.0;
+		lo[3 + d] = real ? pos[d] : 1e300;
+		hi[3 + d] = real ? pos[d] : -1e300;
 	}
 	for (int off = 32; off > 0; off >>= 1)
-		for (int d = 0; d < 3; ++d) {
+		for (int d = 0; d < 6; ++d) {
 			lo[d] = fmin(lo[d], __shfl_down(lo[d], off, 64));
 			hi[d] = fmax(hi[d], __shfl_down(hi[d], off, 64));
 		}
 	if (lane == 0)
 		for (int d = 0; d < 3; ++d) {
-			tb[6 * (size_t)blockIdx.x + d] = lo[d];
-			tb[6 * (size_t)blockIdx.x + 3 + d] = hi[d];
+			tb[12 * (size_t)blockIdx.x + d] = lo[d];
+			tb[12 * (size_t)blockIdx.x + 3 + d] = hi[d];
+			tb[12 * (size_t)blockIdx.x + 6 + d] = lo[3 + d];
+			tb[12 * (size_t)blockIdx.x + 9 + d] = hi[3 + d];
 		}
 }
 
 __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb, const int2 *__restrict__ tile_pairs, int ntp, Box bx,
-                                                  double thr_cut2, double thr_far2, int *__restrict__ cls) {
+                                                  double thr_cut2, double thr_far2, int *__restrict__ cls, double4 *__restrict__ tp_shift) {
 	const int t = blockIdx.x * 256 + threadIdx.x;
 	if (t >= ntp) return;
 	const int2 IJ = tile_pairs[t];
@@ -442,8 +446,8 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 	if (IJ.x != IJ.y) {
 		double d2 = 0;
 		for (int d = 0; d < 3; ++d) {
-			const double a0 = tb[6 * (size_t)IJ.x + d], a1 = tb[6 * (size_t)IJ.x + 3 + d];
-			const double b0 = tb[6 * (size_t)IJ.y + d], b1 = tb[6 * (size_t)IJ.y + 3 + d];
+			const double a0 = tb[12 * (size_t)IJ.x + d], a1 = tb[12 * (size_t)IJ.x + 3 + d];
+			const double b0 = tb[12 * (size_t)IJ.y + d], b1 = tb[12 * (size_t)IJ.y + 3 + d];
 			double gap = 0.0; // distance between the two intervals on the unit circle
 			if (a1 < b0) gap = fmin(b0 - a1, a0 + 1.0 - b1);
 			else if (b1 < a0) gap = fmin(a0 - b1, b0 + 1.0 - a1);
@@ -454,11 +458,27 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 		if (d2 > thr_cut2) c |= CLS_BEYOND_CUTOFF;
 		if (thr_far2 > 0.0 && d2 > thr_far2) c |= CLS_THOLE_FAR;
 	}
+	if (tp_shift) {
+		// Is the periodic image index rint(R (x_i - x_j)) the same for every atom pair of the tile pair?  x_i - x_j, the
+		// product and rint are all monotone in their argument (also after rounding), so it suffices that the two extreme
+		// displacements of the RAW coordinate ranges round to the same integer.  Then d_img = (x_i - B img) - x_j.
+		double sh[3];
+		bool uni = true;
+		for (int d = 0; d < 3; ++d) {
+			const double ilo = tb[12 * (size_t)IJ.x + 6 + d], ihi = tb[12 * (size_t)IJ.x + 9 + d];
+			const double jlo = tb[12 * (size_t)IJ.y + 6 + d], jhi = tb[12 * (size_t)IJ.y + 9 + d];
+			const double m0 = rint(bx.r[4 * d] * (ilo - jhi)), m1 = rint(bx.r[4 * d] * (ihi - jlo));
+			uni = uni && (m0 == m1) && (ihi >= ilo) && (jhi >= jlo);
+			sh[d] = bx.b[4 * d] * m0;
+		}
+		if (uni) c |= CLS_UNIFORM_IMG;
+		tp_shift[t] = make_double4(sh[0], sh[1], sh[2], 0.0);
+	}
 	cls[t] = c;
 }
 
 void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, const int2 *tile_pairs, int n_tile_pairs, double polar_damp,
-                         double *tile_bounds, int *cls) {
+                         double *tile_bounds, int *cls, double4 *tp_shift) {
 	if (!bx.ortho) {
 		(void)hipMemsetAsync(cls, 0, (size_t)n_tile_pairs * sizeof(int), st);
 		return;
@@ -472,7 +492,7 @@ void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, cons
 	}
 	hipLaunchKernelGGL(k_tile_bounds, dim3(at.n_pad / kTile), dim3(kTile), 0, st, at, bx, tile_bounds);
 	hipLaunchKernelGGL(k_classify, dim3((n_tile_pairs + 255) / 256), dim3(256), 0, st, tile_bounds, tile_pairs, n_tile_pairs, bx, thr_cut2,
-	                   thr_far2, cls);
+	                   thr_far2, cls, tp_shift);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -733,13 +753,119 @@ void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const 
 //        conflicts, no contention) and a wave's LDS operations execute in program order, so the sum order is fixed;
 //        the adds run in the LDS unit and cost no VALU issue.
 // ------------------------------------------------------------------------------------------------------
-template <bool ORTHO, int JACC>
-__global__ __launch_bounds__(64) void k_dipole_iter_hybrid(AtomsDev at, Box bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
-                                                            const int *__restrict__ cls, const double2 *__restrict__ ab,
-                                                            double *__restrict__ part /*[nt][n_pad][3]*/) {
-	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_mx[kTile], s_my[kTile], s_mz[kTile], s_v[kTile];
-	__shared__ double s_gx[kTile], s_gy[kTile], s_gz[kTile];
-	const int lane = threadIdx.x;
+// FAR / UNI are wave-uniform properties of the tile pair: the walk is instantiated for each combination so that the
+// inner loop carries no branch.  UNI: the periodic image index is the same for all 4096 atom pairs (k_classify), the
+// caller has already moved the i-atom by that lattice vector and the displacement is one subtraction per component.
+struct HybLds {
+	const double *j; // ONE array [7][2 * kTile]: x, y, z, mu_x, mu_y, mu_z, valid -- one base register, compile-time offsets
+	double *gx, *gy, *gz;
+};
+constexpr int kJ2 = 2 * kTile;
+struct HybAcc {
+	double fx, fy, fz, gx, gy, gz;
+};
+
+// one pair step: lane l against j = (l + s) & 63.  The LDS images of the j-tile hold every value twice (slots k and k + 64),
+// so the slot is jl = l + s with no wrap and, inside an unrolled round, a compile-time offset from one base address.
+// ROT: rotate the j-side accumulators afterwards (not after the last step).
+template <bool ORTHO, int JACC, bool FAR, bool UNI, bool ROT>
+__device__ __forceinline__ void hyb_step(const Box &bx, const HybLds &L, const int jl, const int src4, const double pix, const double piy,
+                                         const double piz, const double mix, const double miy, const double miz, double2 t, const double padi,
+                                         HybAcc &A) {
+	double ox, oy, oz;
+	const double xj = L.j[jl + 0 * kJ2], yj = L.j[jl + 1 * kJ2], zj = L.j[jl + 2 * kJ2];
+	if (UNI) {
+		ox = pix - xj;
+		oy = piy - yj;
+		oz = piz - zj;
+	} else {
+		image_vec<ORTHO>(bx, pix - xj, piy - yj, piz - zj, ox, oy, oz);
+	}
+	if (FAR) { // undamped dipole tensor: a = 1/r^3, b = 3/r^5 (damping < 1e-13 beyond lambda r = 40)
+		const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
+		const double ir = fast_rsqrt_1(r2);
+		const double ir2 = ir * ir;
+		t.x = ir2 * ir;
+		if (padi >= 0.0) t.x *= padi * L.j[jl + 6 * kJ2]; // wave-uniform: only tile pairs that touch the padded last tile
+		t.y = 3.0 * t.x * ir2;
+	}
+	const double mjx = L.j[jl + 3 * kJ2], mjy = L.j[jl + 4 * kJ2], mjz = L.j[jl + 5 * kJ2];
+	const double dj = t.y * fma(oz, mjz, fma(oy, mjy, ox * mjx));
+	const double di = t.y * fma(oz, miz, fma(oy, miy, ox * mix));
+	A.fx = fma(-t.x, mjx, fma(dj, ox, A.fx));
+	A.fy = fma(-t.x, mjy, fma(dj, oy, A.fy));
+	A.fz = fma(-t.x, mjz, fma(dj, oz, A.fz));
+	if (JACC == 2) {
+		atomicAdd(&L.gx[jl & 63], fma(di, ox, -(t.x * mix)));
+		atomicAdd(&L.gy[jl & 63], fma(di, oy, -(t.x * miy)));
+		atomicAdd(&L.gz[jl & 63], fma(di, oz, -(t.x * miz)));
+	} else {
+		A.gx = fma(-t.x, mix, fma(di, ox, A.gx));
+		A.gy = fma(-t.x, miy, fma(di, oy, A.gy));
+		A.gz = fma(-t.x, miz, fma(di, oz, A.gz));
+		if (ROT) {
+			A.gx = rot_from_next<JACC == 0>(A.gx, src4);
+			A.gy = rot_from_next<JACC == 0>(A.gy, src4);
+			A.gz = rot_from_next<JACC == 0>(A.gz, src4);
+		}
+	}
+}
+
+template <bool ORTHO, int JACC, int PIPE, bool FAR, bool UNI>
+__device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const double pix, const double piy, const double piz, const double mix,
+                                         const double miy, const double miz, const double2 *__restrict__ abt, const int s_first,
+                                         const int n_steps, const int lane, const int src4, const double padi, HybAcc &A) {
+	int jb = lane + s_first; // LDS slot of the round's first step
+	if (FAR) {
+		for (int kc = 0; kc < n_steps - 4; kc += 4, jb += 4) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u) hyb_step<ORTHO, JACC, true, UNI, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
+		}
+#pragma unroll
+		for (int u = 0; u < 3; ++u) hyb_step<ORTHO, JACC, true, UNI, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
+		hyb_step<ORTHO, JACC, true, UNI, false>(bx, L, jb + 3, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
+		return;
+	}
+	// rolling prefetch ring: the (a,b) of step k + PIPE is requested as soon as the registers of step k are consumed, so PIPE
+	// loads of 1 KiB per wave stay in flight all the time (latency x bandwidth of HBM needs > 16 MB in flight chip-wide).
+	// All rounds but the last prefetch unconditionally (no branch => the ring registers are reused in place); the addresses
+	// are one running pointer per round plus compile-time offsets.
+	double2 buf[PIPE];
+	const double2 *__restrict__ pn = abt + s_first * kTile;
+#pragma unroll
+	for (int u = 0; u < PIPE; ++u) buf[u] = ld_stream<true>(pn + u * kTile);
+	for (int kc = 0; kc < n_steps - PIPE; kc += PIPE, jb += PIPE) {
+		pn += PIPE * kTile;
+#pragma unroll
+		for (int u = 0; u < PIPE; ++u) {
+			const double2 t = buf[u];
+			buf[u] = ld_stream<true>(pn + u * kTile);
+			hyb_step<ORTHO, JACC, false, UNI, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, t, padi, A);
+			__builtin_amdgcn_sched_barrier(0); // keep the steps in program order (no hoisting of all LDS reads to the top)
+		}
+	}
+#pragma unroll
+	for (int u = 0; u < PIPE; ++u) {
+		if (u != PIPE - 1) hyb_step<ORTHO, JACC, false, UNI, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
+		else hyb_step<ORTHO, JACC, false, UNI, false>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+}
+
+// W waves share one tile pair: wave w walks the steps [w n/W, (w+1) n/W) of the same 64 i-atoms, so a tile pair is W short
+// waves on W SIMDs instead of one long one (12 403 long waves on 1024 SIMDs left a quarter of the CU-time idle in the
+// tail of the launch).  The W partial sums of every atom meet in LDS and are added in wave order (fixed => reproducible).
+template <bool ORTHO, int JACC, int PIPE = 8, int W = 1>
+__global__ __launch_bounds__(64 * W) void k_dipole_iter_hybrid(AtomsDev at, Box bx, const double *__restrict__ mu,
+                                                                const int2 *__restrict__ tile_pairs, const int *__restrict__ cls,
+                                                                const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab,
+                                                                double *__restrict__ part /*[nt][n_pad][3]*/) {
+	static_assert(JACC != 2 || W == 1, "LDS-atomic accumulation is ordered only within one wave");
+	static_assert((32 / W) % PIPE == 0, "a wave's share of a diagonal tile (32 / W steps) must be whole rounds of PIPE");
+	__shared__ double s_j[7 * kJ2];
+	__shared__ double s_g[W][3][kTile];
+	__shared__ double s_f[W][3][kTile];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int tp = blockIdx.x;
 	const int2 IJ = tile_pairs[tp];
 	const bool diag = (IJ.x == IJ.y);
@@ -749,117 +875,94 @@ __global__ __launch_bounds__(64) void k_dipole_iter_hybrid(AtomsDev at, Box bx, 
 
 	const double4 pi = at.xyzq[i];
 	const double mix = mu[3 * (size_t)i], miy = mu[3 * (size_t)i + 1], miz = mu[3 * (size_t)i + 2];
-	{
+	if (w == 0) {
 		const double4 pj = at.xyzq[j0 + lane];
-		s_x[lane] = pj.x;
-		s_y[lane] = pj.y;
-		s_z[lane] = pj.z;
-		s_mx[lane] = mu[3 * (size_t)(j0 + lane)];
-		s_my[lane] = mu[3 * (size_t)(j0 + lane) + 1];
-		s_mz[lane] = mu[3 * (size_t)(j0 + lane) + 2];
-		s_v[lane] = (at.mf[j0 + lane].y & AF_PAD) ? 0.0 : 1.0;
-		if (JACC == 2) s_gx[lane] = s_gy[lane] = s_gz[lane] = 0.0;
+		const double vals[7] = {pj.x, pj.y, pj.z, mu[3 * (size_t)(j0 + lane)], mu[3 * (size_t)(j0 + lane) + 1], mu[3 * (size_t)(j0 + lane) + 2],
+		                        (at.mf[j0 + lane].y & AF_PAD) ? 0.0 : 1.0};
+#pragma unroll
+		for (int c = 0; c < 7; ++c) s_j[c * kJ2 + lane] = s_j[c * kJ2 + lane + kTile] = vals[c]; // twice: slot l + s never wraps (hyb_step)
+		if (JACC == 2) s_g[0][0][lane] = s_g[0][1][lane] = s_g[0][2][lane] = 0.0;
 	}
 	__syncthreads();
-	const bool far = (cls[tp] & CLS_THOLE_FAR) != 0; // wave-uniform: beyond the damping range, nothing was stored
+	const int c = cls[tp];
+	const bool far = (c & CLS_THOLE_FAR) != 0; // wave-uniform: beyond the damping range, nothing was stored
+	const bool uni = ORTHO && tp_shift && (c & CLS_UNIFORM_IMG) != 0;
 	const double vi = (at.mf[i].y & AF_PAD) ? 0.0 : 1.0;
 	const bool has_pad = (at.n != at.n_pad) && (IJ.y == at.n_pad / kTile - 1); // only the last tile holds padding slots (I <= J)
 
 	const double2 *__restrict__ abt = ab + (size_t)tp * (kTile * kTile) + lane;
-	double fx = 0, fy = 0, fz = 0, gx = 0, gy = 0, gz = 0;
-	// 64 steps (off-diagonal, staggered start) or 32 steps (diagonal, s = 1..32): always whole chunks of 4
-	const int s_first = diag ? 1 : stagger_start(tp), n_steps = diag ? 32 : 64;
-	// software pipeline: the (a,b) of the NEXT 4 steps are in flight while the current 4 are applied
-	double2 cur[4], nxt[4];
+	HybAcc A = {0, 0, 0, 0, 0, 0};
+	const HybLds L = {s_j, &s_g[0][0][0], &s_g[0][1][0], &s_g[0][2][0]};
+	const double padi = has_pad ? vi : -1.0;
+	// 64 steps (off-diagonal, s = 0..63) or 32 steps (diagonal, s = 1..32), W equal shares of whole PIPE rounds
+	const int n_steps = (diag ? 32 : 64) / W;
+	const int s_first = (diag ? 1 : 0) + w * n_steps;
+#define MPMC_WALK(F, U, X, Y, Z) hyb_walk<ORTHO, JACC, PIPE, F, U>(bx, L, X, Y, Z, mix, miy, miz, abt, s_first, n_steps, lane, src4, padi, A)
+	if (uni) {
+		const double4 sh = tp_shift[tp];
+		const double qx = pi.x - sh.x, qy = pi.y - sh.y, qz = pi.z - sh.z;
+		if (far) MPMC_WALK(true, true, qx, qy, qz);
+		else MPMC_WALK(false, true, qx, qy, qz);
+	} else {
+		if (far) MPMC_WALK(true, false, pi.x, pi.y, pi.z);
+		else MPMC_WALK(false, false, pi.x, pi.y, pi.z);
+	}
+#undef MPMC_WALK
+	if (JACC != 2) { // park the rotated accumulators at their atoms' LDS slots
+		const int jl_last = (lane + s_first + n_steps - 1) & 63;
+		s_g[w][0][jl_last] = A.gx;
+		s_g[w][1][jl_last] = A.gy;
+		s_g[w][2][jl_last] = A.gz;
+	}
+	if (W > 1) {
+		s_f[w][0][lane] = A.fx;
+		s_f[w][1][lane] = A.fy;
+		s_f[w][2][lane] = A.fz;
+	}
+	__syncthreads();
+	if (w != 0) return;
+	double f[3] = {A.fx, A.fy, A.fz}, g[3];
 #pragma unroll
-	for (int u = 0; u < 4; ++u) cur[u] = far ? make_double2(0.0, 0.0) : ld_stream<true>(abt + (diag ? (s_first + u) : ((s_first + u) & 63)) * kTile);
-	for (int kc = 0; kc < n_steps; kc += 4) {
-		const bool more = !far && (kc + 4 < n_steps);
-		if (more) {
+	for (int d = 0; d < 3; ++d) {
+		g[d] = s_g[0][d][lane];
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const int sn = diag ? (s_first + kc + 4 + u) : ((s_first + kc + 4 + u) & 63);
-				nxt[u] = ld_stream<true>(abt + sn * kTile);
-			}
-		}
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const int s = diag ? (s_first + kc + u) : ((s_first + kc + u) & 63);
-			const int jl = (lane + s) & 63;
-			double2 t = cur[u];
-			double ox, oy, oz;
-			image_vec<ORTHO>(bx, pi.x - s_x[jl], pi.y - s_y[jl], pi.z - s_z[jl], ox, oy, oz);
-			if (far) { // undamped dipole tensor: a = 1/r^3, b = 3/r^5 (damping < 1e-13 beyond lambda r = 40)
-				const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
-				const double ir = fast_rsqrt_1(r2);
-				const double ir2 = ir * ir;
-				t.x = ir2 * ir;
-				if (has_pad) t.x *= vi * s_v[jl];
-				t.y = 3.0 * t.x * ir2;
-			}
-			const double mjx = s_mx[jl], mjy = s_my[jl], mjz = s_mz[jl];
-			const double dj = t.y * fma(oz, mjz, fma(oy, mjy, ox * mjx));
-			const double di = t.y * fma(oz, miz, fma(oy, miy, ox * mix));
-			fx = fma(-t.x, mjx, fma(dj, ox, fx));
-			fy = fma(-t.x, mjy, fma(dj, oy, fy));
-			fz = fma(-t.x, mjz, fma(dj, oz, fz));
-			if (JACC == 2) {
-				atomicAdd(&s_gx[jl], fma(di, ox, -(t.x * mix)));
-				atomicAdd(&s_gy[jl], fma(di, oy, -(t.x * miy)));
-				atomicAdd(&s_gz[jl], fma(di, oz, -(t.x * miz)));
-			} else {
-				gx = fma(-t.x, mix, fma(di, ox, gx));
-				gy = fma(-t.x, miy, fma(di, oy, gy));
-				gz = fma(-t.x, miz, fma(di, oz, gz));
-				if (kc + u != n_steps - 1) {
-					gx = rot_from_next<JACC == 0>(gx, src4);
-					gy = rot_from_next<JACC == 0>(gy, src4);
-					gz = rot_from_next<JACC == 0>(gz, src4);
-				}
-			}
-		}
-		if (more) {
-#pragma unroll
-			for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+		for (int k = 1; k < W; ++k) {
+			f[d] += s_f[k][d][lane];
+			g[d] += s_g[k][d][lane];
 		}
 	}
 	const int nt_pad3 = at.n_pad * 3;
-	if (JACC != 2) { // park the rotated accumulators at their atoms' LDS slots
-		const int jl_last = (lane + s_first + n_steps - 1) & 63;
-		s_gx[jl_last] = gx;
-		s_gy[jl_last] = gy;
-		s_gz[jl_last] = gz;
-	}
-	__syncthreads();
 	if (diag) {
 		double *o = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)i;
-		o[0] = fx + s_gx[lane];
-		o[1] = fy + s_gy[lane];
-		o[2] = fz + s_gz[lane];
+		o[0] = f[0] + g[0];
+		o[1] = f[1] + g[1];
+		o[2] = f[2] + g[2];
 	} else {
 		double *oi = part + (size_t)IJ.y * nt_pad3 + 3 * (size_t)i;
-		oi[0] = fx;
-		oi[1] = fy;
-		oi[2] = fz;
+		oi[0] = f[0];
+		oi[1] = f[1];
+		oi[2] = f[2];
 		double *oj = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + lane);
-		oj[0] = s_gx[lane];
-		oj[1] = s_gy[lane];
-		oj[2] = s_gz[lane];
+		oj[0] = g[0];
+		oj[1] = g[1];
+		oj[2] = g[2];
 	}
 }
 
 void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                               const int *cls, int n_tile_pairs, const double2 *ab, double *part) {
-	dim3 grid(n_tile_pairs), block(kTile);
-#define MPMC_LAUNCH_HYB(O, J) hipLaunchKernelGGL((k_dipole_iter_hybrid<O, J>), grid, block, 0, st, at, bx, mu, tile_pairs, cls, ab, part)
+                               const int *cls, const double4 *tp_shift, int n_tile_pairs, const double2 *ab, double *part) {
+	dim3 grid(n_tile_pairs);
+#define MPMC_LAUNCH_HYB(O, J, P, W) \
+	hipLaunchKernelGGL((k_dipole_iter_hybrid<O, J, P, W>), grid, dim3(kTile * W), 0, st, at, bx, mu, tile_pairs, cls, tp_shift, ab, part)
 	if (bx.ortho) {
-		if (jacc == 2) MPMC_LAUNCH_HYB(true, 2);
-		else if (jacc == 1) MPMC_LAUNCH_HYB(true, 1);
-		else MPMC_LAUNCH_HYB(true, 0);
+		if (jacc == 2) MPMC_LAUNCH_HYB(true, 2, 8, 1);
+		else if (jacc == 1) MPMC_LAUNCH_HYB(true, 1, 8, 1);
+		else if (jacc == 3) MPMC_LAUNCH_HYB(true, 0, 8, 2); // two waves per tile pair (measured equal to one: kept as a tuning knob)
+		else MPMC_LAUNCH_HYB(true, 0, 8, 1);
 	} else {
-		if (jacc == 2) MPMC_LAUNCH_HYB(false, 2);
-		else if (jacc == 1) MPMC_LAUNCH_HYB(false, 1);
-		else MPMC_LAUNCH_HYB(false, 0);
+		if (jacc == 2) MPMC_LAUNCH_HYB(false, 2, 8, 1);
+		else if (jacc == 1) MPMC_LAUNCH_HYB(false, 1, 8, 1);
+		else MPMC_LAUNCH_HYB(false, 0, 8, 1);
 	}
 #undef MPMC_LAUNCH_HYB
 }

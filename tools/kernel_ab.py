@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Same-process A/B of kernel variants on ONE bead of the benchmark box (10 000 polarizable atoms).
+
+usage: python tools/kernel_ab.py "label:ENV=v,ENV=v" ...        (an empty env list = defaults)
+
+Each variant gets a fresh context created under its environment (the library reads its MPMC_* toggles at
+mpmc_ctx_create), 2 warm-up evaluations, then `reps` profiled evaluations; prints HIP-event ms per launch of every
+kernel class, the evaluation wall time and the total energy (must be identical to ~1e-12 between variants).
+The list is run twice (A B A B) so that drift of the box shows up.
+"""
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import bench  # noqa: E402
+from mpmcxx_amd import energy  # noqa: E402
+
+reps = int(os.environ.get("KAB_REPS", "5"))
+natoms = int(os.environ.get("KAB_NATOMS", "10000"))
+atoms, basis, opts = bench.build_case(natoms, tempfile.mkdtemp())
+specs = sys.argv[1:] or ["default:"]
+for rnd in (1, 2):
+    for spec in specs:
+        label, _, envs = spec.partition(":")
+        added = []
+        for kv in filter(None, envs.split(",")):
+            k, _, v = kv.partition("=")
+            os.environ[k] = v
+            added.append(k)
+        S = energy.System(atoms, basis, opts)
+        for _ in range(2):
+            e = S.energy()
+        S.set_profiling(True)
+        S.timings(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            e = S.energy()
+        wall = (time.perf_counter() - t0) / reps
+        t = S.timings(reset=True)
+        S.close()
+        for k in added:
+            del os.environ[k]
+        cls = "  ".join(f"{k} {v['ms'] / max(v['launches'], 1):.4f}x{v['launches'] // reps}" for k, v in t.items() if v["launches"])
+        print(f"r{rnd} {label:>12s}: eval {wall * 1e3:.3f} ms  E {e:.12e} | {cls}", flush=True)
