@@ -82,7 +82,7 @@ typedef struct mpmc_options {
 	int32_t polar_iterative;  /* :1240 (required when polarization is on)                                   */
 	int32_t polar_ewald;      /* :718/:1210 static field by Ewald (recip_term + real_term) instead of nopbc */
 	int32_t polar_max_iter;   /* :1303 fixed iteration count when polar_precision == 0                      */
-	int32_t polar_gs;         /* :1256 Gauss-Seidel -- refused (MPMC_ERR_UNSUPPORTED), Jacobi only          */
+	int32_t polar_gs;         /* :1256 Gauss-Seidel: in-place sweeps in atom order (serial over 64-atom tiles)  */
 	int32_t polar_rrms;       /* :1320 compute per-atom dipole RRMS every iteration                         */
 	int32_t damp_type;        /* :1308 must be MPMC_DAMPING_EXPONENTIAL when polarization is on             */
 	int32_t ewald_kmax;       /* :1199 (default 7)                                                          */

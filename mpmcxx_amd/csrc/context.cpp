@@ -449,7 +449,6 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 			return fail(c, MPMC_ERR_UNSUPPORTED, "mpmc_set_options: polarization by matrix inversion (polar_iterative off) is not supported");
 		if (o->damp_type != MPMC_DAMPING_EXPONENTIAL)
 			return fail(c, MPMC_ERR_UNSUPPORTED, "mpmc_set_options: only polar_damp_type exponential is supported");
-		if (o->polar_gs) return fail(c, MPMC_ERR_UNSUPPORTED, "mpmc_set_options: polar_gs (Gauss-Seidel) is not supported; Jacobi only");
 		if (o->polar_precision == 0.0 && o->polar_max_iter < 1)
 			return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: polar_max_iter must be >= 1 when polar_precision is 0 (the reference never terminates)");
 		if (o->polar_precision < 0.0) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: polar_precision < 0");
@@ -462,6 +461,7 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 		if (!(o->temperature > 0)) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: feynman_hibbs requires positive temperature"); // SimulationControl.cpp:2509
 		if (o->wolf && !o->rd_only) return fail(c, MPMC_ERR_INCOMPATIBLE, "mpmc_set_options: FH + es_wolf is not implemented"); // System.Energy.cpp:1448-1450
 	}
+	if (c->opts_set && (c->opts.polar_gs != 0) != (o->polar_gs != 0)) c->atoms_dirty = true; // Gauss-Seidel sweeps need the reference's atom order
 	c->opts = *o;
 	c->opts_set = true;
 	c->k_dirty = true;
@@ -478,6 +478,7 @@ static void compute_spatial_order(mpmc_ctx *c) {
 	c->slot_of.resize(n);
 	for (int i = 0; i < n; i++) c->perm[i] = i;
 	bool enable = c->box_set && n > 2 * kTile;
+	if (c->opts_set && c->opts.polar_gs && c->opts.polarization && !c->opts.rd_only) enable = false; // the sweep order IS the atom order (:3569)
 	if (const char *e = std::getenv("MPMC_NO_SORT")) if (e[0] == '1') enable = false;
 	if (enable) {
 		std::vector<double> f(3 * (size_t)n);
@@ -790,6 +791,7 @@ static int ensure_polar_buffers(mpmc_ctx *c) {
 static int resolve_solver(mpmc_ctx *c) {
 	const size_t need = (size_t)c->n_tile_pairs * (kTile * kTile); // double2 elements, 16 B each
 	int want = c->opts.solver;
+	if (c->opts.polar_gs) want = MPMC_SOLVER_MATRIX_FREE; // Gauss-Seidel sweeps rebuild the tensors row block by row block (kernels_gs.hip)
 	if (want == MPMC_SOLVER_AUTO) {
 		size_t budget_mb = 4096;
 		if (const char *e = std::getenv("MPMC_TENSOR_BUDGET_MB")) budget_mb = (size_t)std::strtoull(e, nullptr, 10);
@@ -955,6 +957,26 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 				break;
 			}
 			if (by_precision) HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
+			if (o.polar_gs) { // in-place sweep in atom order; old_mu is kept only when rrms / precision need it (:3503-3507)
+				double *mu = c->d_mu[c->mu_cur], *mu_old = c->d_mu[1 - c->mu_cur];
+				if (want_rrms) HIP_TRY(c, hipMemcpyAsync(mu_old, mu, 3 * (size_t)at.n_pad * sizeof(double), hipMemcpyDeviceToDevice, st));
+				{
+					ProfScope p(c, MPMC_K_DIPOLE_ITER);
+					launch_gs_sweep(st, at, c->box, o.polar_damp, c->d_e_static, mu, c->d_e_induced, c->d_part);
+				}
+				if (want_rrms) {
+					ProfScope p(c, MPMC_K_REDUCE);
+					launch_gs_finish(st, at, mu_old, mu, want_rrms, c->d_rrms, allowed, c->d_flag);
+				}
+				if (by_precision) {
+					HIP_TRY(c, hipMemcpyAsync(c->h_flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+					HIP_TRY(c, hipStreamSynchronize(st));
+					keep = (*c->h_flag != 0);
+				} else {
+					keep = (it != o.polar_max_iter);
+				}
+				continue;
+			}
 			if (compact && c->jacobi_hybrid) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
 				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,

@@ -117,6 +117,13 @@ void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, con
 // lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
 void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm);
 
+// ---- Gauss-Seidel sweeps (kernels_gs.hip): `polar_gs on`, identity atom order, matrix-free ---------------------------
+// one sweep over all tiles in atom order: mu is updated in place, e_induced receives each atom's induced field; part [nt][64][3]
+void launch_gs_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, const double *e_static, double *mu, double *e_induced,
+                     double *part);
+void launch_gs_finish(hipStream_t st, const AtomsDev &at, const double *mu_old, const double *mu_new, int want_rrms, double *rrms_atom,
+                      double allowed_sqerr, int *not_done_flag);
+
 // ---- trial moves (kernels_delta.hip) ----------------------------------------------------------------------
 // out4 = { d lj_pairs, d es_real(erfc part), d intramolecular term, E_recip of the trial structure factors }, dcnt2 = { d n_lj, d n_es }
 void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc, double alpha, int do_es,

@@ -254,6 +254,23 @@ def fixture(name: str):
         o = dict(POLAR_OPTS)
         o.update({"feynman_hibbs": "on", "feynman_hibbs_order": 4, "temperature": 30.0})
         return lattice_box(216, 24.0, 7), cubic(24.0), o
+    if name == "ion216_gs":  # Gauss-Seidel sweeps (polar_gs): in-place dipole updates in atom order
+        o = dict(POLAR_OPTS)
+        o["polar_gs"] = "on"
+        o["polar_max_iter"] = 6
+        return lattice_box(216, 24.0, 7), cubic(24.0), o
+    if name == "water64_gs_precision":  # Gauss-Seidel, precision-terminated, molecular box (non-polarizable sites, exclusions)
+        o = dict(POLAR_OPTS)
+        del o["polar_max_iter"]
+        o["polar_gs"] = "on"
+        o["polar_precision"] = 1e-8
+        o["polar_rrms"] = "on"
+        return molecular_box(64, 14.0, 5), cubic(14.0), o
+    if name == "ion1000_gs":  # 16 tiles: the blocked sweep crosses many tile boundaries
+        o = dict(POLAR_OPTS)
+        o["polar_gs"] = "on"
+        o["polar_max_iter"] = 4
+        return lattice_box(1000, 40.0, 11), cubic(40.0), o
     if name == "lj1000":  # BASELINE config 2
         return lattice_box(1000, 40.0, 11, charged=False, alpha=0.0), cubic(40.0), {"rd_only": "on"}
     if name == "ion1000_polar":
@@ -268,7 +285,7 @@ def fixture(name: str):
 SMALL_FIXTURES = [
     "ar2", "lj64", "ion64_es", "ion216_polar", "ion216_polar_nopbc", "ion216_triclinic", "ion216_frozen",
     "ion216_precision", "ion216_gamma", "ion216_alpha", "water64_polar", "lj1000", "ion1000_polar",
-    "ion216_wolf", "water64_fh2", "water64_fh4", "ion216_fh4_polar",
+    "ion216_wolf", "water64_fh2", "water64_fh4", "ion216_fh4_polar", "ion216_gs", "water64_gs_precision", "ion1000_gs",
 ]
 LARGE_FIXTURES = ["ion10k_es", "ion10k_polar"]
 

@@ -93,7 +93,7 @@ int main(int argc, char **argv) {
 			u.rd_only = 0;
 			u.polarization = 1;
 			u.polar_iterative = 1;
-			u.polar_gs = 1;
+			u.damp_type = mpmc::DAMPING_LINEAR;
 			u.energy();
 		} catch (int code) {
 			thrown = code;

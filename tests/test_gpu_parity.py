@@ -108,7 +108,7 @@ def test_run_to_run_determinism():
 def test_unsupported_options_are_refused():
     atoms, basis, opts = util.load_fixture("ion216_polar")
     bad = dict(opts)
-    bad["polar_gs"] = 1
+    bad["damp_type"] = "linear"  # only the exponential Thole damping is on the path
     with pytest.raises(energy.MpmcError) as ei:
         energy.System(atoms, basis, bad)
     assert ei.value.code == energy.ERR_UNSUPPORTED

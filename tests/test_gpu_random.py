@@ -184,3 +184,19 @@ def test_input_validation():
     with pytest.raises(energy.MpmcError):
         S.set_atoms(big)
     S.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_systems_gauss_seidel(seed):
+    """polar_gs: in-place sweeps in atom order (the spatial sort is off for this solver); ragged sizes, mixed molecules, frozen and
+    non-polarizable sites, fixed-count and precision-terminated solves."""
+    rng = np.random.default_rng(7000 + seed)
+    n = [3, 64, 65, 130, 200, 321, 129, 17][seed]
+    cell = ["cubic", "ortho", "triclinic"][seed % 3]
+    atoms, basis = random_system(rng, n, cell)
+    opts = random_options(rng)
+    opts.update(rd_only=0, polarization=1, polar_iterative=1, polar_gs=1, polar_damp=float(rng.uniform(1.5, 2.6)), polar_ewald=int(seed % 2 == 0),
+                polar_max_iter=int(rng.integers(1, 5)), polar_rrms=int(seed % 3 == 0))
+    if seed >= 5:
+        opts.update(polar_precision=1e-4, polar_max_iter=10)
+    check(atoms, basis, opts, f"gs seed {seed} n {n} {cell} {opts}")
