@@ -343,9 +343,10 @@ public:
 // values in bead order.  With one process it may be left empty.
 // (The reference keeps all P images on every MPI rank, so its kinetic estimator needs no exchange; with the beads
 // sharded over ranks the ring of adjacent images crosses ranks and the centres of mass are gathered once per call.)
-class PathIntegralEnsemble {
+template <class SystemT>
+class PathIntegralEnsembleT {
 public:
-	std::vector<System *> systems;
+	std::vector<SystemT *> systems;
 	int nSys = 0;
 	double temperature = 0;        // sys.temperature
 	observables_t sys_observables; // the aggregate "sys.observables" of the reference
@@ -409,7 +410,7 @@ public:
 
 	double PI_calculate_potential() {
 		const int n_local = (int)systems.size();
-		for (System *s : systems) s->energy_async(); // every bead enqueued on its own stream before the first wait
+		for (SystemT *s : systems) s->energy_async(); // every bead enqueued on its own stream before the first wait
 		std::vector<double> mine(4 * (size_t)n_local);
 		for (int b = 0; b < n_local; b++) {
 			systems[b]->energy_wait();
@@ -432,5 +433,6 @@ public:
 		return acc[0] + acc[1] + acc[3] + acc[2]; // :803-804
 	}
 };
+using PathIntegralEnsemble = PathIntegralEnsembleT<System>;
 
 } // namespace mpmc
