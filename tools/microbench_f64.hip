@@ -19,7 +19,7 @@
 	} while (0)
 
 constexpr int NCHAIN = 8;
-constexpr int ITER = 2048;
+constexpr int ITER = 16384;
 
 enum Op { FMA, MUL, ADD, RNDNE, RSQ, DPP_ROL, FMA_SGPR, MIX_STEP };
 
