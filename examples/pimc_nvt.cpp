@@ -1,5 +1,5 @@
 // examples/pimc_nvt.cpp -- path-integral NVT Monte Carlo of a reference input file on the HIP energy path.
-//   pimc_nvt INPUT.in -P 8 [-o OUTDIR] [--steps N]
+//   pimc_nvt INPUT.in -P 8 [-o OUTDIR] [--steps N] [--trial]
 // Reads the reference's own input / PQR formats (include/mpmc_io.hpp), runs the driver of include/mpmc_pimc.hpp with one device
 // context per image (images are spread round-robin over the visible GPUs) and writes OUTDIR/JOB.energy.dat (same rows as the
 // reference's energy output) and OUTDIR/JOB.final-%04d.pqr; prints one JSON line with acceptance rates and throughput.
@@ -20,11 +20,13 @@ int main(int argc, char **argv) {
 	}
 	int P = 0;
 	long steps_override = -1;
+	bool trial = false; // per-move delta energies instead of full evaluations
 	std::string outdir = ".";
 	for (int k = 2; k < argc; k++) {
 		if (!std::strcmp(argv[k], "-P") && k + 1 < argc) P = std::atoi(argv[++k]);
 		else if (!std::strcmp(argv[k], "-o") && k + 1 < argc) outdir = argv[++k];
 		else if (!std::strcmp(argv[k], "--steps") && k + 1 < argc) steps_override = std::atol(argv[++k]);
+		else if (!std::strcmp(argv[k], "--trial")) trial = true;
 	}
 	try {
 		mpmc::PathIntegralNVT<mpmc::System> mc;
@@ -53,6 +55,7 @@ int main(int argc, char **argv) {
 			mc.systems.push_back(&s);
 		}
 		mc.init();
+		mc.use_trial_moves = trial;
 		const std::string base = outdir + "/" + mc.cfg.job_name;
 		FILE *fp = std::fopen((base + ".energy.dat").c_str(), "w");
 		if (!fp) throw 1001; // fopen_fail_write
@@ -67,11 +70,11 @@ int main(int argc, char **argv) {
 		}
 		const mpmc::observables_t &o = mc.pi.sys_observables;
 		std::printf("{\"P\": %d, \"natoms\": %d, \"steps\": %u, \"AR\": %.5f, \"AR_displace\": %.5f, \"AR_bead\": %.5f, \"energy\": %.17g, \"kinetic\": %.17g, "
-		            "\"seconds\": %.3f, \"steps_per_s\": %.2f, \"energy_evals_per_s\": %.1f, \"devices\": %d}\n",
+		            "\"seconds\": %.3f, \"steps_per_s\": %.2f, \"energy_evals_per_s\": %.1f, \"devices\": %d, \"trial_moves\": %d}\n",
 		            P, (int)beads[0]->atoms.size(), mc.step, mc.acceptance_rate(),
 		            (mc.accept_displace + mc.reject_displace) ? (double)mc.accept_displace / (double)(mc.accept_displace + mc.reject_displace) : 0.0,
 		            (mc.accept_bead + mc.reject_bead) ? (double)mc.accept_bead / (double)(mc.accept_bead + mc.reject_bead) : 0.0, o.energy, o.kinetic_energy,
-		            sec, mc.cfg.numsteps / sec, mc.energy_calls / sec, ndev < P ? ndev : P);
+		            sec, mc.cfg.numsteps / sec, mc.energy_calls / sec, ndev < P ? ndev : P, trial ? 1 : 0);
 	} catch (int code) {
 		std::printf("{\"error\": %d}\n", code);
 		return 1;

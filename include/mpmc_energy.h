@@ -191,6 +191,9 @@ int mpmc_energy_wait(mpmc_ctx *ctx, mpmc_result *out);
 #define MPMC_TRIAL_MAX_ATOMS 256
 int mpmc_trial_begin(mpmc_ctx *ctx, int first, int count, const double *new_pos /*[count][3]*/);
 int mpmc_trial_energy(mpmc_ctx *ctx, mpmc_result *out);
+/* the same in two halves (enqueue on the context's stream / wait): the P images of one path-integral move overlap on the device */
+int mpmc_trial_energy_async(mpmc_ctx *ctx);
+int mpmc_trial_energy_wait(mpmc_ctx *ctx, mpmc_result *out);
 int mpmc_trial_accept(mpmc_ctx *ctx);
 int mpmc_trial_reject(mpmc_ctx *ctx);
 

@@ -99,8 +99,11 @@ public:
 	unsigned int step = 0;
 	// acceptance bookkeeping (System::register_accept / register_reject, src/System.MonteCarlo.cpp:1475-1760)
 	long accept = 0, reject = 0, accept_displace = 0, reject_displace = 0, accept_bead = 0, reject_bead = 0;
-	long energy_calls = 0; // evaluations of System::energy() issued so far
+	long energy_calls = 0; // evaluations of System::energy() (or per-move delta evaluations) issued so far
 	double boltzmann_factor = 0;
+	// per-move delta energies instead of full evaluations: the images keep the accepted configuration resident and
+	// evaluate only the pairs of the moved molecule (LJ / Ewald boxes; polarizable boxes run a full evaluation behind the same calls)
+	bool use_trial_moves = false;
 
 	void init() {
 		nSys = (int)systems.size();
@@ -154,27 +157,40 @@ public:
 		for (step = 1; step <= cfg.numsteps; step++) {
 			const double potential_init = potential_current;
 			const double chain_init = (move == MOVETYPE_PERTURB_BEADS) ? PI_chain_mass_length2() : 0;
-			PI_make_move(move);
-			double potential_trial = PI_calculate_potential();
+			PI_make_move(move, !use_trial_moves);
 			const double chain_trial = (move == MOVETYPE_PERTURB_BEADS) ? PI_chain_mass_length2() : 0;
+			double potential_trial = use_trial_moves ? PI_trial_potential() : PI_calculate_potential();
+			const int failed = use_trial_moves ? systems[0]->trial_result().iterator_failed : systems[0]->iterator_failed;
 			if (!std::isfinite(potential_trial)) { // a bad contact is a reject (:128-131)
 				potential_trial = obs.energy = kMaxValue;
 				boltzmann_factor = 0;
 			} else {
 				boltzmann_factor = PI_NVT_boltzmann_factor(move, potential_trial - potential_init, chain_trial - chain_init);
 			}
-			if ((rng.rand() < boltzmann_factor) && (systems[0]->iterator_failed == 0)) {
+			if ((rng.rand() < boltzmann_factor) && (failed == 0)) {
 				register_move(move, true);
 				potential_current = potential_trial;
-				PI_calculate_energy(false); // same geometry: the potential of the trial evaluation stands, the kinetic part is new
+				if (use_trial_moves)
+					for (SystemT *s : systems) s->accept_trial();
+				// same geometry: the potential of the trial evaluation stands, the kinetic part is new.  It is a pure function of
+				// the geometry (O(P N) host work), so the delta-energy mode computes it when a row is written instead of per accept.
+				if (!use_trial_moves) PI_calculate_energy(false);
 				backup_observables_ALL_SYSTEMS();
 			} else {
-				restore_PI_systems();
+				if (use_trial_moves) {
+					for (SystemT *s : systems) {
+						s->reject_trial();
+						s->iterator_failed = 0;
+					}
+				} else {
+					restore_PI_systems();
+				}
 				obs = checkpoint_sys_obs;
 				register_move(move, false);
 			}
 			move = PI_pick_NVT_move();
 			if (!(step % cfg.corrtime) || (step == cfg.numsteps)) {
+				if (use_trial_moves) PI_calculate_energy(false);
 				refresh_aggregate();
 				if (fp_energy) write_observables(fp_energy);
 				if (on_sample) on_sample(*this, user);
@@ -207,12 +223,31 @@ public:
 		return movetype;
 	}
 
-	void PI_make_move(int mv) { // :1121-1160
+	void PI_make_move(int mv, bool upload = true) { // :1121-1160
 		if (mv == MOVETYPE_DISPLACE) PI_displace();
 		else if (mv == MOVETYPE_PERTURB_BEADS) PI_perturb_bead_COMs(cfg.PI_trial_chain_length); // orientations: no data, no draws (:1565)
 		else throw 12000; // invalid_monte_carlo_move
+		if (!upload) return;
 		const int first = mol_first[target], count = mol_first[target + 1] - first;
 		for (SystemT *s : systems) s->move_atoms(first, count);
+	}
+
+	// the potential of the configuration PI_make_move just produced, through the per-move delta path: the new positions of the
+	// altered molecule go to the images as a TRIAL (their atoms[] return to the accepted configuration until accept_trial())
+	double PI_trial_potential() {
+		const int first = mol_first[target], count = mol_first[target + 1] - first;
+		std::vector<std::vector<double>> trial(nSys, std::vector<double>(3 * (size_t)count));
+		for (int s = 0; s < nSys; s++)
+			for (int k = 0; k < count; k++)
+				for (int d = 0; d < 3; d++) {
+					trial[s][3 * k + d] = systems[s]->atoms[first + k].pos[d];
+					systems[s]->atoms[first + k].pos[d] = backup_pos[s][3 * k + d];
+				}
+		energy_calls += nSys;
+		const double v = pi.PI_trial_potential(first, count, trial);
+		// the rest of the step (chain measures were taken before; an accepted move re-reads atoms[]) sees the trial geometry only
+		// after accept_trial(), which is what the estimator needs
+		return v;
 	}
 
 	// SimulationControl::PI_displace, :1320-1387

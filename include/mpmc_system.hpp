@@ -182,6 +182,29 @@ public:
 		trial_result_ = r;
 		return r.energy;
 	}
+	// the same in two halves, so that a driver can put the trials of many Systems in flight before the first wait
+	void energy_trial_async(int first, int count, const double *new_pos) {
+		sync_state();
+		check(mpmc_trial_begin(ctx_, first, count, new_pos), "mpmc_trial_begin");
+		int rc = mpmc_trial_energy_async(ctx_);
+		if (rc != MPMC_OK) {
+			mpmc_trial_reject(ctx_);
+			check(rc, "mpmc_trial_energy_async");
+		}
+		trial_first_ = first;
+		trial_pos_.assign(new_pos, new_pos + 3 * (size_t)count);
+	}
+	double energy_trial_wait() {
+		mpmc_result r;
+		int rc = mpmc_trial_energy_wait(ctx_, &r);
+		if (rc != MPMC_OK) {
+			mpmc_trial_reject(ctx_);
+			check(rc, "mpmc_trial_energy_wait");
+		}
+		trial_result_ = r;
+		return r.energy;
+	}
+	const mpmc_result &trial_result() const { return trial_result_; } // the trial configuration's totals (observables keep the accepted ones)
 	void accept_trial() {
 		check(mpmc_trial_accept(ctx_), "mpmc_trial_accept");
 		for (size_t k = 0; k < trial_pos_.size() / 3; k++)
@@ -351,6 +374,34 @@ public:
 	double temperature = 0;        // sys.temperature
 	observables_t sys_observables; // the aggregate "sys.observables" of the reference
 	std::function<std::vector<double>(const std::vector<double> &)> allgather;
+
+	// PI_calculate_potential for a TRIAL configuration in which atoms [first, first+count) of every image sit at new_pos[image]:
+	// per-move delta energies behind the same aggregate (every image enqueued before the first wait); the Systems keep the accepted
+	// configuration until accept_trial() / reject_trial()
+	double PI_trial_potential(int first, int count, const std::vector<std::vector<double>> &new_pos) {
+		const int n_local = (int)systems.size();
+		for (int b = 0; b < n_local; b++) systems[b]->energy_trial_async(first, count, new_pos[b].data());
+		std::vector<double> mine(4 * (size_t)n_local);
+		for (int b = 0; b < n_local; b++) {
+			systems[b]->energy_trial_wait();
+			const mpmc_result &r = systems[b]->trial_result();
+			mine[4 * b + 0] = r.rd_energy;
+			mine[4 * b + 1] = r.coulombic_energy;
+			mine[4 * b + 2] = r.polarization_energy;
+			mine[4 * b + 3] = r.vdw_energy;
+		}
+		const std::vector<double> all = allgather ? allgather(mine) : mine;
+		const int P = nSys ? nSys : n_local;
+		double acc[4] = {0, 0, 0, 0};
+		for (int s = 0; s < P; s++)
+			for (int k = 0; k < 4; k++) acc[k] += all[4 * (size_t)s + k];
+		for (int k = 0; k < 4; k++) acc[k] /= P;
+		sys_observables.rd_energy = acc[0];
+		sys_observables.coulombic_energy = acc[1];
+		sys_observables.polarization_energy = acc[2];
+		sys_observables.vdw_energy = acc[3];
+		return acc[0] + acc[1] + acc[3] + acc[2];
+	}
 
 	// SimulationControl::PI_calculate_energy, PathIntegral.cpp:734-749
 	double PI_calculate_energy() {

@@ -114,7 +114,8 @@ struct mpmc_ctx {
 	bool cache_valid = false;   // last_full = totals of the accepted configuration, d_sf = its structure factors
 	mpmc_result last_full{};
 	mpmc_result trial_res{};
-	bool trial_open = false, trial_evaluated = false, trial_was_full = false;
+	bool trial_open = false, trial_evaluated = false, trial_was_full = false, trial_enqueued = false;
+	mpmc_result trial_keep{}; // accepted totals while a full-evaluation trial is in flight
 	int trial_first = 0, trial_count = 0;
 	std::vector<double> trial_new, trial_old;
 	int *d_mv_slot = nullptr, *d_mv_orig = nullptr, *d_moved_idx = nullptr; // d_mv_slot/d_mv_orig/d_mv_new live in ONE allocation (d_mv_blob)
@@ -461,6 +462,7 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 		if (!(o->temperature > 0)) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: feynman_hibbs requires positive temperature"); // SimulationControl.cpp:2509
 		if (o->wolf && !o->rd_only) return fail(c, MPMC_ERR_INCOMPATIBLE, "mpmc_set_options: FH + es_wolf is not implemented"); // System.Energy.cpp:1448-1450
 	}
+	if (c->opts_set && std::memcmp(&c->opts, o, sizeof(mpmc_options)) == 0) return MPMC_OK; // unchanged: keep the accepted configuration's totals
 	if (c->opts_set && (c->opts.polar_gs != 0) != (o->polar_gs != 0)) c->atoms_dirty = true; // Gauss-Seidel sweeps need the reference's atom order
 	c->opts = *o;
 	c->opts_set = true;
@@ -1130,26 +1132,27 @@ extern "C" int mpmc_trial_begin(mpmc_ctx *c, int first, int count, const double 
 	c->trial_old.assign(c->h_pos.begin() + 3 * (size_t)first, c->h_pos.begin() + 3 * (size_t)(first + count));
 	c->trial_open = true;
 	c->trial_evaluated = false;
+	c->trial_enqueued = false;
 	return MPMC_OK;
 }
 
-extern "C" int mpmc_trial_energy(mpmc_ctx *c, mpmc_result *out) {
-	if (!c || !out) return MPMC_ERR_ARG;
+// the two halves of mpmc_trial_energy: everything up to the last enqueue, then the wait + host arithmetic (P images of a
+// path-integral move overlap on the device when a driver enqueues all of them before the first wait)
+extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
+	if (!c) return MPMC_ERR_ARG;
 	if (!c->trial_open) return fail(c, MPMC_ERR_ARG, "mpmc_trial_energy: no trial move is open");
+	if (c->trial_enqueued) return fail(c, MPMC_ERR_ARG, "mpmc_trial_energy_async: already enqueued");
 	const mpmc_options &o = c->opts;
 	const bool polar = o.polarization && !o.rd_only;
 	const int m = c->trial_count;
 	if (polar || m > MPMC_TRIAL_MAX_ATOMS || o.wolf || o.feynman_hibbs) { // (the delta kernels carry the base LJ + Ewald terms only)
 		// the dipole solve couples every atom: evaluate the trial configuration in full (still on the device)
-		const mpmc_result keep = c->last_full;
+		c->trial_keep = c->last_full;
 		int rc = mpmc_update_positions(c, c->trial_first, m, c->trial_new.data());
 		if (rc != MPMC_OK) return rc;
-		rc = mpmc_energy(c, out);
-		if (rc != MPMC_OK) return rc;
-		c->trial_res = *out;
-		c->last_full = keep; // still the ACCEPTED configuration's totals until mpmc_trial_accept
+		if ((rc = mpmc_energy_async(c)) != MPMC_OK) return rc;
 		c->trial_was_full = true;
-		c->trial_evaluated = true;
+		c->trial_enqueued = true;
 		return MPMC_OK;
 	}
 	int rc = prepare(c);
@@ -1176,8 +1179,27 @@ extern "C" int mpmc_trial_energy(mpmc_ctx *c, mpmc_result *out) {
 	}
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipMemcpyAsync(c->h_delta_out, c->d_delta_out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-	HIP_TRY(c, hipStreamSynchronize(st));
+	c->trial_was_full = false;
+	c->trial_enqueued = true;
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_trial_energy_wait(mpmc_ctx *c, mpmc_result *out) {
+	if (!c || !out) return MPMC_ERR_ARG;
+	if (!c->trial_open || !c->trial_enqueued) return fail(c, MPMC_ERR_ARG, "mpmc_trial_energy_wait: nothing enqueued");
+	c->trial_enqueued = false;
+	if (c->trial_was_full) {
+		int rc = mpmc_energy_wait(c, out);
+		if (rc != MPMC_OK) return rc;
+		c->trial_res = *out;
+		c->last_full = c->trial_keep; // still the ACCEPTED configuration's totals until mpmc_trial_accept
+		c->trial_evaluated = true;
+		return MPMC_OK;
+	}
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	prof_harvest(c);
+	const int do_es = c->opts.rd_only ? 0 : 1;
 	const mpmc_result &a = c->last_full;
 	mpmc_result r = a;
 	r.lj_pairs = a.lj_pairs + c->h_delta_out[0];
@@ -1192,10 +1214,16 @@ extern "C" int mpmc_trial_energy(mpmc_ctx *c, mpmc_result *out) {
 	r.energy = r.rd_energy + r.coulombic_energy + r.polarization_energy + r.vdw_energy + r.three_body_energy;
 	r.NU = r.N * r.energy;
 	c->trial_res = r;
-	c->trial_was_full = false;
 	c->trial_evaluated = true;
 	*out = r;
 	return MPMC_OK;
+}
+
+extern "C" int mpmc_trial_energy(mpmc_ctx *c, mpmc_result *out) {
+	if (!c || !out) return MPMC_ERR_ARG;
+	int rc = mpmc_trial_energy_async(c);
+	if (rc != MPMC_OK) return rc;
+	return mpmc_trial_energy_wait(c, out);
 }
 
 extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
@@ -1220,6 +1248,11 @@ extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
 extern "C" int mpmc_trial_reject(mpmc_ctx *c) {
 	if (!c) return MPMC_ERR_ARG;
 	if (!c->trial_open) return fail(c, MPMC_ERR_ARG, "mpmc_trial_reject: no trial move is open");
+	if (c->trial_enqueued) { // enqueued but never waited for: drain it first
+		mpmc_result drop;
+		int rc = mpmc_trial_energy_wait(c, &drop);
+		if (rc != MPMC_OK) return rc;
+	}
 	c->trial_open = false;
 	if (c->trial_evaluated && c->trial_was_full) { // the resident configuration is the trial one: put the old positions back
 		const mpmc_result keep = c->last_full;

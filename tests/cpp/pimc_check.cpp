@@ -2,7 +2,7 @@
 // evaluator (test infrastructure: links oracle/libmpmc_oracle.so; the product never does).  It pins the driver's host logic --
 // random-number stream, move generation, Boltzmann factors, accept / restore, estimator bookkeeping -- against the rows the stock
 // reference binary wrote for the same input (tests/golden/pi001, pi_ion27) without needing a GPU.
-//   pimc_check INPUT.in P OUT_DIR      writes OUT_DIR/energy.dat and OUT_DIR/final-%04d.pqr, prints a JSON summary
+//   pimc_check INPUT.in P OUT_DIR [--trial]     writes OUT_DIR/energy.dat and OUT_DIR/final-%04d.pqr, prints a JSON summary
 #include <cstdio>
 #include <memory>
 #include <string>
@@ -51,6 +51,48 @@ public:
 			a0 = a1;
 		}
 	}
+	// trial moves behind the facade's names: the oracle has no delta path, the trial configuration is evaluated in full
+	mpmc_result trial_{};
+	int trial_first_ = 0;
+	std::vector<double> trial_pos_;
+	mpmc::observables_t trial_obs_;
+	void energy_trial_async(int first, int count, const double *new_pos) {
+		trial_first_ = first;
+		trial_pos_.assign(new_pos, new_pos + 3 * (size_t)count);
+	}
+	double energy_trial_wait() {
+		const mpmc::observables_t keep = *observables;
+		const int keep_failed = iterator_failed;
+		std::vector<double> old(trial_pos_.size());
+		for (size_t k = 0; k < trial_pos_.size() / 3; k++)
+			for (int d = 0; d < 3; d++) {
+				old[3 * k + d] = atoms[trial_first_ + k].pos[d];
+				atoms[trial_first_ + k].pos[d] = trial_pos_[3 * k + d];
+			}
+		const double e = energy();
+		trial_obs_ = *observables;
+		trial_ = mpmc_result{};
+		trial_.energy = e;
+		trial_.rd_energy = observables->rd_energy;
+		trial_.coulombic_energy = observables->coulombic_energy;
+		trial_.polarization_energy = observables->polarization_energy;
+		trial_.vdw_energy = observables->vdw_energy;
+		trial_.iterator_failed = iterator_failed;
+		for (size_t k = 0; k < trial_pos_.size() / 3; k++)
+			for (int d = 0; d < 3; d++) atoms[trial_first_ + k].pos[d] = old[3 * k + d];
+		*observables = keep;
+		iterator_failed = keep_failed;
+		return e;
+	}
+	const mpmc_result &trial_result() const { return trial_; }
+	void accept_trial() {
+		for (size_t k = 0; k < trial_pos_.size() / 3; k++)
+			for (int d = 0; d < 3; d++) atoms[trial_first_ + k].pos[d] = trial_pos_[3 * k + d];
+		*observables = trial_obs_;
+		iterator_failed = trial_.iterator_failed;
+	}
+	void reject_trial() {}
+
 	double energy() {
 		const int n = (int)atoms.size();
 		std::vector<double> pos(3 * (size_t)n), q(n), al(n), ep(n), sg(n), ms(n);
@@ -89,6 +131,7 @@ public:
 
 int main(int argc, char **argv) {
 	if (argc < 4) return 2;
+	const bool trial = argc > 4 && std::string(argv[4]) == "--trial";
 	try {
 		const int P = std::atoi(argv[2]);
 		const std::string outdir = argv[3];
@@ -110,6 +153,7 @@ int main(int argc, char **argv) {
 			mc.systems.push_back(&o);
 		}
 		mc.init();
+		mc.use_trial_moves = trial;
 		FILE *fp = std::fopen((outdir + "/energy.dat").c_str(), "w");
 		if (!fp) return 3;
 		mc.run(fp);

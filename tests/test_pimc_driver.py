@@ -50,10 +50,12 @@ def pimc_check(tmp_path_factory):
     return exe
 
 
+@pytest.mark.parametrize("trial", [False, True], ids=["full", "trial_moves"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_driver_with_oracle_evaluator_reproduces_the_stock_binary(pimc_check, name, tmp_path):
+def test_driver_with_oracle_evaluator_reproduces_the_stock_binary(pimc_check, name, trial, tmp_path):
     inp, P, job = CASES[name]
-    out = subprocess.run([pimc_check, os.path.join(util.GOLDEN, name, inp), str(P), str(tmp_path)], stdout=subprocess.PIPE, text=True, check=True)
+    out = subprocess.run([pimc_check, os.path.join(util.GOLDEN, name, inp), str(P), str(tmp_path)] + (["--trial"] if trial else []),
+                         stdout=subprocess.PIPE, text=True, check=True)
     r = json.loads(out.stdout)
     ours, gold = rows(os.path.join(tmp_path, "energy.dat")), rows(os.path.join(util.GOLDEN, name, "golden_energy.dat"))
     assert ours == gold  # every printed digit of every row
@@ -96,11 +98,14 @@ def pimc_nvt(tmp_path_factory):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("trial", [False, True], ids=["full", "trial_moves"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_pimc_on_the_hip_path_reproduces_the_stock_binary(pimc_nvt, name, tmp_path):
+def test_pimc_on_the_hip_path_reproduces_the_stock_binary(pimc_nvt, name, trial, tmp_path):
+    """trial_moves: every move goes through mpmc_trial_* (per-move delta energies for the LJ dimer, a full evaluation behind the same
+    calls for the polarizable box): same trajectory, same rows."""
     inp, P, job = CASES[name]
-    out = subprocess.run([pimc_nvt, os.path.join(util.GOLDEN, name, inp), "-P", str(P), "-o", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                         text=True, timeout=600)
+    out = subprocess.run([pimc_nvt, os.path.join(util.GOLDEN, name, inp), "-P", str(P), "-o", str(tmp_path)] + (["--trial"] if trial else []),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     r = json.loads(out.stdout.strip().splitlines()[-1])
     ours, gold = rows(os.path.join(tmp_path, f"{job}.energy.dat")), rows(os.path.join(util.GOLDEN, name, "golden_energy.dat"))
