@@ -105,6 +105,9 @@ def main():
                     help="async: all local beads enqueued on their own streams before the first wait; serial: one bead at a time")
     ap.add_argument("--cpu-baseline", choices=["port", "reference", "none"], default="port")
     ap.add_argument("--combine", choices=["gather", "reduce"], default="gather")
+    ap.add_argument("--host-positions", action="store_true",
+                    help="also re-upload every bead's positions from host buffers inside each timed step (the PCIe-inclusive rate "
+                         "noted in DESIGN.md §6; never the headline value)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the multi-rank path on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this device")
@@ -150,7 +153,12 @@ def main():
         a["pos"] = bead_positions(atoms["pos"], b)
         beads.append(energy.System(a, basis, opts, device=local_rank))
 
+    host_pos = [np.ascontiguousarray(bead_positions(atoms["pos"], b)) for b in mine] if args.host_positions else None
+
     def local_eval():
+        if host_pos is not None:  # the boundary as the reference's adapter uses it: positions arrive in host memory every call
+            for s, hp in zip(beads, host_pos):
+                s.update_positions(0, hp)
         if args.concurrency == "async":
             _, per, failed = energy.pi_potential_local(beads)
         else:
@@ -329,6 +337,8 @@ def main():
             "device_bytes_per_bead": mem_total,
             "roofline": roof,
         }
+        if args.host_positions:
+            out["note_host_positions"] = "positions of every bead re-uploaded from host memory inside every timed step (PCIe-inclusive rate, not the headline)"
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

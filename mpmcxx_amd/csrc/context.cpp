@@ -67,6 +67,8 @@ struct mpmc_ctx {
 	int *d_lists = nullptr;         // [2 ntp] work lists of the two Jacobi kernels + [2] their lengths (at the end)
 	double *d_tile_bounds = nullptr; // [n_tiles][12]: wrapped fractional lo/hi, raw Cartesian lo/hi
 	double4 *d_tp_shift = nullptr;   // [n_tile_pairs] lattice vector of the common image index (CLS_UNIFORM_IMG)
+	std::vector<double4> h_xyzq;     // host mirror of d_xyzq (slot order), for bulk position updates
+	std::vector<double> h_pos_sorted; // positions at the time of the last spatial sort
 	bool no_uniform = false;         // MPMC_NO_UNI=1
 	size_t cap_tile_pairs = 0;
 	long long static_cnt[4] = {0, 0, 0, 0}; // n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent)
@@ -474,6 +476,7 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 // ---- atoms -----------------------------------------------------------------------------------------------
 // nested bisection sort of the wrapped fractional coordinates: nx slabs in x, ny strips in y per slab, z order inside a
 // strip; consecutive groups of 64 slots (tiles) are then roughly cubic cells.  Pure host code, O(N log N).
+constexpr double kResortDrift = 2.0; // Angstrom; a tile is ~16 A wide at liquid density
 static void compute_spatial_order(mpmc_ctx *c) {
 	const int n = c->n;
 	c->perm.resize(n);
@@ -577,6 +580,8 @@ static int upload_atoms(mpmc_ctx *c) {
 		HIP_TRY(c, hipMemcpyAsync(c->static_cnt, c->d_cnt, 4 * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
 	}
 	HIP_TRY(c, hipStreamSynchronize(c->stream)); // staging vectors die here
+	c->h_xyzq.swap(xyzq);          // slot-ordered mirror for bulk position updates
+	c->h_pos_sorted = c->h_pos;    // where every atom stood when this order was made
 	c->atoms_dirty = false;
 	return MPMC_OK;
 }
@@ -687,8 +692,30 @@ extern "C" int mpmc_update_positions(mpmc_ctx *c, int first, int count, const do
 	}
 	c->cache_valid = false; // the accepted totals no longer describe the resident configuration
 	if (c->atoms_dirty) return MPMC_OK; // a full (re-sorted) upload is pending anyway
-	if (count > 256) { // large updates: one full re-upload (also refreshes the spatial order)
-		c->atoms_dirty = true;
+	if (count > 256) { // bulk update (typically: all positions handed over in host memory for every evaluation)
+		// The atoms keep their slots -- the spatial order only matters for speed, the tile classes are recomputed from the actual
+		// bounding boxes every evaluation -- and the whole position array goes up in ONE copy.  The order is refreshed (full upload)
+		// once some atom has drifted further than kResortDrift from where it stood at the last sort.
+		double worst = 0.0;
+		for (int t = 0; t < count; t++) {
+			const int i = first + t;
+			double d2 = 0;
+			for (int p = 0; p < 3; p++) {
+				const double d = pos[3 * t + p] - c->h_pos_sorted[3 * (size_t)i + p];
+				d2 += d * d;
+			}
+			if (d2 > worst) worst = d2;
+		}
+		if (c->h_pos_sorted.empty() || !(worst <= kResortDrift * kResortDrift)) {
+			c->atoms_dirty = true;
+			return MPMC_OK;
+		}
+		for (int t = 0; t < count; t++) {
+			const int i = first + t;
+			c->h_xyzq[c->slot_of[i]] = make_double4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], c->h_q[i]);
+		}
+		HIP_TRY(c, hipMemcpyAsync(c->d_xyzq, c->h_xyzq.data(), (size_t)c->n_pad * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		return MPMC_OK;
 	}
 	for (int t = 0; t < count; t++) { // the moved atoms keep their slots (the order only matters for speed)

@@ -98,6 +98,29 @@ def test_update_positions_equals_fresh_context():
     T.close()
 
 
+def test_bulk_position_update_from_host_buffers():
+    """all positions handed over in host memory (count > 256): the atoms keep their slots and go up in one copy while they stay
+    within 2 A of where the spatial order was made; a larger drift re-sorts.  Either way the energy is that of a fresh context."""
+    S, atoms, basis, opts = make("ion1000_polar")
+    S.energy()
+    rng = np.random.default_rng(11)
+    for scale in (0.05, 0.2, 3.0):  # the last one moves atoms beyond the re-sort threshold
+        newpos = atoms["pos"] + rng.normal(scale=scale, size=atoms["pos"].shape)
+        S.update_positions(0, newpos)
+        e1 = S.energy()
+        r1 = dict(S.observables)
+        a2 = dict(atoms)
+        a2["pos"] = newpos
+        T = energy.System(a2, basis, opts)
+        e2 = T.energy()
+        assert util.close(e1, e2, 1e-11), (scale, e1, e2)
+        for k in ("rd_energy", "coulombic_energy", "polarization_energy"):
+            assert util.close(r1[k], T.observables[k], 1e-10), (scale, k)
+        assert int(r1["n_lj_in_cutoff"]) == int(T.observables["n_lj_in_cutoff"]) and int(r1["n_es_in_cutoff"]) == int(T.observables["n_es_in_cutoff"])
+        T.close()
+    S.close()
+
+
 def test_run_to_run_determinism():
     S, *_ = make("ion1000_polar")
     vals = [S.energy() for _ in range(3)]
