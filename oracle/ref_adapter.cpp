@@ -41,6 +41,13 @@ struct Binding {
 	mpmc_ctx *ctx = nullptr;
 	int capacity = 0;
 };
+// what was last handed to mpmc_set_atoms for a System: while the atom list itself is unchanged (the normal case between two Monte
+// Carlo moves) only the positions travel, through mpmc_update_positions
+struct AtomsSeen {
+	std::vector<double> q, alpha, eps, sig, mass;
+	std::vector<int32_t> mol, frozen, disp;
+};
+std::unordered_map<System *, AtomsSeen> g_seen;
 std::mutex g_mu;
 std::unordered_map<System *, Binding> g_ctx;
 long g_calls = 0;
@@ -118,7 +125,9 @@ extern "C" double __wrap__ZN6System6energyEv(System *s) {
 		auto it = g_ctx.find(s);
 		if (it != g_ctx.end()) b = it->second;
 	}
+	bool fresh_ctx = false;
 	if (!b.ctx || b.capacity < n) {
+		fresh_ctx = true;
 		if (b.ctx) mpmc_ctx_destroy(b.ctx);
 		b.capacity = n + n / 4 + 64; // uVT head-room
 		int rc = mpmc_ctx_create(device_for(s), b.capacity, &b.ctx);
@@ -154,9 +163,23 @@ extern "C" double __wrap__ZN6System6energyEv(System *s) {
 	o.unsupported_flags = unsupported_mask(s);
 	if (!s->polarization) o.damp_type = MPMC_DAMPING_EXPONENTIAL; // damp_type has no initializer in the reference (System.h:705)
 	if ((rc = mpmc_set_options(c, &o)) != MPMC_OK) die(s, c, rc, "mpmc_set_options");
-	if ((rc = mpmc_set_atoms(c, n, pos.data(), q.data(), alpha.data(), eps.data(), sig.data(), mol.data(), frozen.data(), disp.data(), mass.data())) !=
-	    MPMC_OK)
-		die(s, c, rc, "mpmc_set_atoms");
+	{
+		std::unique_lock<std::mutex> lk(g_mu);
+		AtomsSeen &seen = g_seen[s];
+		const bool same = !fresh_ctx && seen.q == q && seen.alpha == alpha && seen.eps == eps && seen.sig == sig && seen.mass == mass && seen.mol == mol &&
+		                  seen.frozen == frozen && seen.disp == disp;
+		if (!same) {
+			seen.q = q, seen.alpha = alpha, seen.eps = eps, seen.sig = sig, seen.mass = mass;
+			seen.mol = mol, seen.frozen = frozen, seen.disp = disp;
+		}
+		lk.unlock();
+		if (same) {
+			if ((rc = mpmc_update_positions(c, 0, n, pos.data())) != MPMC_OK) die(s, c, rc, "mpmc_update_positions");
+		} else if ((rc = mpmc_set_atoms(c, n, pos.data(), q.data(), alpha.data(), eps.data(), sig.data(), mol.data(), frozen.data(), disp.data(),
+		                                mass.data())) != MPMC_OK) {
+			die(s, c, rc, "mpmc_set_atoms");
+		}
+	}
 	mpmc_result r;
 	if ((rc = mpmc_energy(c, &r)) != MPMC_OK) die(s, c, rc, "mpmc_energy");
 
