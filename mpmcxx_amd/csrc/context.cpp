@@ -84,6 +84,10 @@ struct mpmc_ctx {
 	// reciprocal tables
 	int K = 0, cap_K = 0;
 	double4 *d_kvec = nullptr, *d_kw = nullptr, *d_sf = nullptr;
+	int4 *d_lvec = nullptr;       // integer l-vectors of the k table
+	double4 *d_sf_part = nullptr; // [n_tiles][K] per-tile structure-factor partials (factorised phases)
+	size_t cap_sf_part = 0;
+	bool no_recip_tab = false;    // MPMC_NO_RECIP_TAB=1: one sincos per (k, atom)
 	double *d_w_en = nullptr;
 
 	// polarization work
@@ -356,6 +360,7 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	c->jacc = c->use_dpp ? 0 : 1;
 	if (const char *e = std::getenv("MPMC_JACC")) c->jacc = std::atoi(e);
 	if (const char *e = std::getenv("MPMC_NO_UNI")) c->no_uniform = (e[0] == '1');
+	if (const char *e = std::getenv("MPMC_NO_RECIP_TAB")) c->no_recip_tab = (e[0] == '1');
 	const size_t P = (size_t)c->max_pad;
 	A(dev_alloc(c, &c->d_xyzq, P));
 	A(dev_alloc(c, &c->d_lj, P));
@@ -396,7 +401,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_inv_molmass, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -749,6 +754,7 @@ static int build_k_tables(mpmc_ctx *c) {
 	const double alpha = c->ewald_alpha, ea = c->polar_ewald_alpha;
 	std::vector<double4> kvec, kw;
 	std::vector<double> wen;
+	std::vector<int4> lvec;
 	int l[3];
 	for (l[0] = 0; l[0] <= kmax; l[0]++)
 		for (l[1] = (!l[0] ? 0 : -kmax); l[1] <= kmax; l[1]++)
@@ -761,6 +767,7 @@ static int build_k_tables(mpmc_ctx *c) {
 				}
 				const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
 				kvec.push_back(make_double4(k[0], k[1], k[2], k2));
+				lvec.push_back(make_int4(l[0], l[1], l[2], 0));
 				wen.push_back(std::exp(-k2 / (4.0 * alpha * alpha)) / k2);
 				const double g = std::exp(-k2 / (4.0 * ea * ea));
 				kw.push_back(make_double4(k[0] / k2 * g, k[1] / k2 * g, k[2] / k2 * g, 0.0));
@@ -769,12 +776,14 @@ static int build_k_tables(mpmc_ctx *c) {
 	if (K > c->cap_K) {
 		dev_free(c, &c->d_kvec, (size_t)c->cap_K);
 		dev_free(c, &c->d_kw, (size_t)c->cap_K);
+		dev_free(c, &c->d_lvec, (size_t)c->cap_K);
 		dev_free(c, &c->d_sf, (size_t)c->cap_K);
 		dev_free(c, &c->d_w_en, (size_t)c->cap_K);
 		c->cap_K = 0;
 		int rc;
 		if ((rc = dev_alloc(c, &c->d_kvec, (size_t)K)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_kw, (size_t)K)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_lvec, (size_t)K)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_sf, (size_t)K)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_w_en, (size_t)K)) != MPMC_OK) return rc;
 		c->cap_K = K;
@@ -782,6 +791,7 @@ static int build_k_tables(mpmc_ctx *c) {
 	if (K > 0) {
 		HIP_TRY(c, hipMemcpy(c->d_kvec, kvec.data(), K * sizeof(double4), hipMemcpyHostToDevice));
 		HIP_TRY(c, hipMemcpy(c->d_kw, kw.data(), K * sizeof(double4), hipMemcpyHostToDevice));
+		HIP_TRY(c, hipMemcpy(c->d_lvec, lvec.data(), K * sizeof(int4), hipMemcpyHostToDevice));
 		HIP_TRY(c, hipMemcpy(c->d_w_en, wen.data(), K * sizeof(double), hipMemcpyHostToDevice));
 	}
 	c->K = K;
@@ -881,6 +891,7 @@ static RecipDev recip_view(const mpmc_ctx *c) {
 	r.kvec = c->d_kvec;
 	r.w_en = c->d_w_en;
 	r.kw = c->d_kw;
+	r.lvec = c->no_recip_tab ? nullptr : c->d_lvec;
 	r.sf = c->d_sf;
 	r.K = c->K;
 	return r;
@@ -917,13 +928,22 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		hipStream_t s2 = fork_side(c);
 		{
 			ProfScope p(c, MPMC_K_RECIP, s2);
-			if (need_sf) launch_recip_sf(s2, at, rcp);
+			if (need_sf) {
+				const size_t need_part = (size_t)c->n_tiles * (size_t)c->K;
+				if (rcp.lvec && o.ewald_kmax <= kRecipTabMaxK && need_part > c->cap_sf_part) {
+					dev_free(c, &c->d_sf_part, c->cap_sf_part);
+					c->cap_sf_part = 0;
+					if ((rc = dev_alloc(c, &c->d_sf_part, need_part)) != MPMC_OK) return rc;
+					c->cap_sf_part = need_part;
+				}
+				launch_recip_sf(s2, at, c->box, rcp, o.ewald_kmax, c->d_sf_part);
+			}
 			if (mask & (RUN_RECIP | RUN_ATOMTERMS))
 				launch_atom_terms(s2, at, rcp, c->box, c->ewald_alpha, (mask & RUN_ATOMTERMS) ? o.rd_lrc : 0, (mask & RUN_RECIP) ? 1 : 0, c->d_scal);
 		}
 		if ((mask & RUN_FIELD) && o.polar_ewald) {
 			ProfScope p(c, MPMC_K_FIELD, s2);
-			launch_field_recip(s2, at, rcp, c->d_e_recip_part);
+			launch_field_recip(s2, at, c->box, rcp, o.ewald_kmax, c->d_e_recip_part);
 		}
 	}
 

@@ -44,17 +44,20 @@ struct RecipDev {
 	const double4 *kvec; // kx, ky, kz, k^2            [K]
 	const double *w_en;  // exp(-k^2/4a^2)/k^2         [K]
 	const double4 *kw;   // k_p/k^2 exp(-k^2/4ap^2), _ [K]
+	const int4 *lvec;    // integer l of k = 2 pi R l       [K] (null: one sincos per (k, atom))
 	double4 *sf;         // SF_re, SF_im (energy: non-frozen, q != 0), C_k, S_k (field: all atoms)  [K]
 	int K;
 };
-void launch_recip_sf(hipStream_t st, const AtomsDev &at, const RecipDev &rc);
+constexpr int kRecipTabMaxK = 15; // phase tables of 3 x 64 x (kmax+1) complex numbers must fit 64 KiB of LDS
+// sf_part: [n_tiles][K] scratch of the factorised form (may be null: direct sincos form)
+void launch_recip_sf(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double4 *sf_part);
 // reciprocal energy + O(N) atom terms: coulombic_self, lj_lrc_self, and the PAIR long-range correction summed in O(N)
 // through moments of (sqrt(eps), |sigma|) (Lorentz-Berthelot makes the pair term a polynomial in sigma_i + sigma_j)
 void launch_atom_terms(hipStream_t st, const AtomsDev &at, const RecipDev &rc, const Box &bx, double ewald_alpha, int rd_lrc,
                        int do_es, double *scal);
 
 // static field
-void launch_field_recip(hipStream_t st, const AtomsDev &at, const RecipDev &rc, double *e_recip /*[n_pad][3]*/);
+void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double *e_recip /*[kKSplit][n_pad][3]*/);
 // E0 = recip*(8 pi/V) + sum_s part ; mu0 = gamma * alpha * E0
 void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip,
                            const double *part, int n_split, double gamma, double *e_static, double *mu);

@@ -227,8 +227,104 @@ __global__ __launch_bounds__(256) void k_atom_terms(AtomsDev at, RecipDev rc, Bo
 	}
 }
 
-void launch_recip_sf(hipStream_t st, const AtomsDev &at, const RecipDev &rc) {
-	if (rc.K > 0) hipLaunchKernelGGL(k_recip_sf, dim3(rc.K), dim3(256), 0, st, at, rc);
+// ---- the same sums without one sincos per (k, atom) ------------------------------------------------------------------------
+// k = 2 pi R l (l integer, :1586-1590), so exp(i k.r) = prod_q exp(2 pi i g_q)^{l_q} with g_q = sum_p R[p][q] r_p: three sincos per
+// atom, the powers m = 0..kmax by complex multiplication, and every (k, atom) term is two complex products of table entries
+// (the classic Ewald factorisation; relative deviation from sincos(k.r) ~ kmax x 1e-16).
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 phase_base(const Box &bx, const double4 &p, int q) {
+	const double g = (bx.r[q] * p.x + bx.r[3 + q] * p.y) + bx.r[6 + q] * p.z;
+	double s, c;
+	sincos(2.0 * kPi * g, &s, &c);
+	return make_double2(c, s);
+}
+
+// structure factors: block (atom tile, chunk of 256 k-vectors), thread = k-vector, table [dir][atom][m] in LDS (a wave's reads of one
+// atom fall into one 16 (kmax+1)-byte row: distinct banks, equal m broadcast).  part[tile][k] = this tile's share of (re, im, C, S).
+__global__ __launch_bounds__(256) void k_recip_sf_tab(AtomsDev at, Box bx, RecipDev rc, int kmax, double4 *__restrict__ part) {
+	extern __shared__ double2 tab[];
+	__shared__ double s_q[kTile], s_qe[kTile];
+	const int KM1 = kmax + 1;
+	const int tile = blockIdx.x, tid = threadIdx.x;
+	for (int idx = tid; idx < 3 * kTile; idx += 256) {
+		const int a = idx & 63, q = idx >> 6;
+		const double2 base = phase_base(bx, at.xyzq[tile * kTile + a], q);
+		double2 *row = tab + (size_t)(q * kTile + a) * KM1;
+		double2 v = make_double2(1.0, 0.0);
+		row[0] = v;
+		for (int m = 1; m <= kmax; ++m) {
+			v = cmul(v, base);
+			row[m] = v;
+		}
+	}
+	if (tid < kTile) {
+		const int i = tile * kTile + tid;
+		const int fl = at.mf[i].y;
+		const double q = (fl & AF_PAD) ? 0.0 : at.xyzq[i].w;
+		s_q[tid] = q;                                                   // recip_term sums over ALL atoms (:2868-2872)
+		s_qe[tid] = (fl & (AF_FROZEN | AF_ZERO_Q | AF_PAD)) ? 0.0 : q;  // coulombic_reciprocal skips frozen and q == 0 (:1599-1602)
+	}
+	__syncthreads();
+	const int k = blockIdx.y * 256 + tid;
+	if (k >= rc.K) return;
+	const int4 l = rc.lvec[k];
+	const int ay = abs(l.y), az = abs(l.z);
+	const double sy = (l.y < 0) ? -1.0 : 1.0, sz = (l.z < 0) ? -1.0 : 1.0;
+	double re = 0, im = 0, C = 0, S = 0;
+	for (int a = 0; a < kTile; ++a) {
+		const double2 ex = tab[(size_t)a * KM1 + l.x];
+		double2 ey = tab[(size_t)(kTile + a) * KM1 + ay];
+		double2 ez = tab[(size_t)(2 * kTile + a) * KM1 + az];
+		ey.y *= sy;
+		ez.y *= sz;
+		const double2 e = cmul(cmul(ex, ey), ez);
+		const double q = s_q[a], qe = s_qe[a];
+		C += q * e.x;
+		S += q * e.y;
+		re += qe * e.x;
+		im += qe * e.y;
+	}
+	part[(size_t)tile * rc.K + k] = make_double4(re, im, C, S);
+}
+// sf[k] = sum over tiles of part[tile][k]: 16 k-vectors x 16 tile groups per block (the loads of one thread are few and independent),
+// folded in a fixed order => reproducible
+__global__ __launch_bounds__(256) void k_recip_sf_reduce(RecipDev rc, const double4 *__restrict__ part, int n_tiles) {
+	__shared__ double4 sh[16][16];
+	const int kk = threadIdx.x & 15, g = threadIdx.x >> 4;
+	const int k = blockIdx.x * 16 + kk;
+	double4 acc = make_double4(0, 0, 0, 0);
+	if (k < rc.K)
+		for (int t = g; t < n_tiles; t += 16) {
+			const double4 v = part[(size_t)t * rc.K + k];
+			acc.x += v.x;
+			acc.y += v.y;
+			acc.z += v.z;
+			acc.w += v.w;
+		}
+	sh[g][kk] = acc;
+	__syncthreads();
+	if (g == 0 && k < rc.K) {
+		double4 r = sh[0][kk];
+		for (int j = 1; j < 16; ++j) {
+			r.x += sh[j][kk].x;
+			r.y += sh[j][kk].y;
+			r.z += sh[j][kk].z;
+			r.w += sh[j][kk].w;
+		}
+		rc.sf[k] = r;
+	}
+}
+
+void launch_recip_sf(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double4 *sf_part) {
+	if (rc.K <= 0) return;
+	if (sf_part && rc.lvec && kmax <= kRecipTabMaxK) {
+		const int nt = at.n_pad / kTile;
+		const size_t lds = (size_t)3 * kTile * (kmax + 1) * sizeof(double2);
+		hipLaunchKernelGGL(k_recip_sf_tab, dim3(nt, (rc.K + 255) / 256), dim3(256), lds, st, at, bx, rc, kmax, sf_part);
+		hipLaunchKernelGGL(k_recip_sf_reduce, dim3((rc.K + 15) / 16), dim3(256), 0, st, rc, sf_part, nt);
+		return;
+	}
+	hipLaunchKernelGGL(k_recip_sf, dim3(rc.K), dim3(256), 0, st, at, rc);
 }
 void launch_atom_terms(hipStream_t st, const AtomsDev &at, const RecipDev &rc, const Box &bx, double ewald_alpha, int rd_lrc, int do_es,
                        double *scal) {
@@ -312,7 +408,52 @@ __global__ __launch_bounds__(512) void k_field_finalize(AtomsDev at, Box bx, int
 	}
 }
 
-void launch_field_recip(hipStream_t st, const AtomsDev &at, const RecipDev &rc, double *e_recip_part) {
+// the field sum with the factorised phases: thread = atom, its table column [dir][m][lane] in LDS (every lane reads the same m: no
+// conflicts), k-vectors walked by all lanes together (l from uniform loads)
+__global__ __launch_bounds__(64) void k_field_recip_tab(AtomsDev at, Box bx, RecipDev rc, int kmax, double *__restrict__ e_part) {
+	extern __shared__ double2 tab[];
+	const int KM1 = kmax + 1;
+	const int lane = threadIdx.x, i = blockIdx.x * kTile + lane;
+	const double4 p = at.xyzq[i];
+	for (int q = 0; q < 3; ++q) {
+		const double2 base = phase_base(bx, p, q);
+		double2 v = make_double2(1.0, 0.0);
+		tab[(size_t)(q * KM1) * kTile + lane] = v;
+		for (int m = 1; m <= kmax; ++m) {
+			v = cmul(v, base);
+			tab[(size_t)(q * KM1 + m) * kTile + lane] = v;
+		}
+	}
+	const int per = (rc.K + kKSplit - 1) / kKSplit;
+	const int k0 = blockIdx.y * per, k1 = min(rc.K, k0 + per);
+	double ex = 0, ey = 0, ez = 0;
+	for (int k = k0; k < k1; ++k) {
+		const int4 l = rc.lvec[k];
+		const double4 sf = rc.sf[k];
+		const double4 kw = rc.kw[k];
+		const double2 a = tab[(size_t)l.x * kTile + lane];
+		double2 b = tab[(size_t)(KM1 + abs(l.y)) * kTile + lane];
+		double2 c = tab[(size_t)(2 * KM1 + abs(l.z)) * kTile + lane];
+		if (l.y < 0) b.y = -b.y;
+		if (l.z < 0) c.y = -c.y;
+		const double2 e = cmul(cmul(a, b), c);
+		const double g = e.y * sf.z - e.x * sf.w; // sin(k.r) C_k - cos(k.r) S_k  (:2877-2878)
+		ex += kw.x * g;
+		ey += kw.y * g;
+		ez += kw.z * g;
+	}
+	double *o = e_part + ((size_t)blockIdx.y * at.n_pad + i) * 3;
+	o[0] = ex;
+	o[1] = ey;
+	o[2] = ez;
+}
+
+void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double *e_recip_part) {
+	if (rc.lvec && kmax <= kRecipTabMaxK) {
+		const size_t lds = (size_t)3 * kTile * (kmax + 1) * sizeof(double2);
+		hipLaunchKernelGGL(k_field_recip_tab, dim3(at.n_pad / kTile, kKSplit), dim3(kTile), lds, st, at, bx, rc, kmax, e_recip_part);
+		return;
+	}
 	hipLaunchKernelGGL(k_field_recip, dim3(at.n_pad / kTile, kKSplit), dim3(kTile), 0, st, at, rc, e_recip_part);
 }
 
