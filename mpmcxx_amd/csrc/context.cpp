@@ -923,9 +923,16 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 
 	// ---- reciprocal space + O(N) atom terms on the side stream, next to the pair sweep ------------------------------
 	const bool need_sf = (mask & RUN_RECIP) || ((mask & RUN_FIELD) && o.polar_ewald);
-	const bool side_work = need_sf || (mask & RUN_ATOMTERMS);
+	// intramolecular charge-to-screen term of coulombic_real: position dependent but independent of the pair sweep; identically zero
+	// when every molecule is a single atom
+	const bool need_intra = (mask & RUN_PAIR) && (mask & RUN_PAIR_ES) && !(o.wolf && (mask & RUN_WOLF)) && (c->n_molecules != c->n);
+	const bool side_work = need_sf || (mask & RUN_ATOMTERMS) || need_intra;
 	if (side_work) {
 		hipStream_t s2 = fork_side(c);
+		if (need_intra) {
+			ProfScope p(c, MPMC_K_PAIR, s2);
+			launch_intra_terms(s2, at, c->d_slot_of, c->ewald_alpha, c->d_scal);
+		}
 		{
 			ProfScope p(c, MPMC_K_RECIP, s2);
 			if (need_sf) {
@@ -972,15 +979,19 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		}
 		fp.wolf_erfa_over_r = std::erf(c->ewald_alpha * c->box.cutoff) / c->box.cutoff;
 		fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
-		if (compact) launch_build_lists(st, c->d_cls, c->n_tile_pairs, c->d_lists, c->d_lists + 2 * (size_t)c->n_tile_pairs);
+		if (compact && !c->jacobi_hybrid) // work lists of the two-kernel Jacobi form only
+			launch_build_lists(st, c->d_cls, c->n_tile_pairs, c->d_lists, c->d_lists + 2 * (size_t)c->n_tile_pairs);
 		launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
 		                  compact ? c->d_ab : nullptr);
-		if (mask & RUN_PAIR) {
-			launch_reduce_pairs(st, c->d_block_part, c->d_block_cnt, c->n_tile_pairs, c->d_scal, c->d_cnt);
-			if ((mask & RUN_PAIR_ES) && !fp.wolf) launch_intra_terms(st, at, c->d_slot_of, c->ewald_alpha, c->d_scal);
-		}
 	}
 	if (side_work) join_side(c);
+	bool reduce_forked = false;
+	if (mask & RUN_PAIR) { // the scalar totals of the sweep are only read back at the very end: fold them beside the field / dipole work
+		hipStream_t s3 = fork_side(c);
+		ProfScope p(c, MPMC_K_REDUCE, s3);
+		launch_reduce_pairs(s3, c->d_block_part, c->d_block_cnt, c->n_tile_pairs, c->d_scal, c->d_cnt);
+		reduce_forked = true;
+	}
 
 	// ---- static field ---------------------------------------------------------------------------------------
 	if (mask & RUN_FIELD) {
@@ -1068,6 +1079,7 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		}
 		c->have_polar = true;
 	}
+	if (reduce_forked) join_side(c);
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipMemcpyAsync(c->h_scal, c->d_scal, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
 	HIP_TRY(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, C_COUNT * sizeof(long long), hipMemcpyDeviceToHost, st));
