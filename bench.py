@@ -105,6 +105,8 @@ def main():
                     help="async: all local beads enqueued on their own streams before the first wait; serial: one bead at a time")
     ap.add_argument("--cpu-baseline", choices=["port", "reference", "none"], default="port")
     ap.add_argument("--combine", choices=["gather", "reduce"], default="gather")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="diagnostic: leave the per-kernel HIP events off in the timed region (the roofline entry is then empty)")
     ap.add_argument("--host-positions", action="store_true",
                     help="also re-upload every bead's positions from host buffers inside each timed step (the PCIe-inclusive rate "
                          "noted in DESIGN.md §6; never the headline value)")
@@ -181,8 +183,11 @@ def main():
 
     for _ in range(args.warmup):
         v, obs = step()
-    for s in beads:
-        s.set_profiling(True)
+    # per-kernel HIP events on ONE bead's stream only: an event pair around every launch costs that stream about 5 us of back-to-back
+    # dispatch (measured: 8 % of the whole-job rate when all 32 beads carry them, 14 % with one bead at a time), so the other
+    # beads run uninstrumented and the instrumented one supplies the launch durations of the timed region
+    for k, s in enumerate(beads):
+        s.set_profiling((k == 0) and not args.no_kernel_timing)
         s.timings(reset=True)
     fence()
     t0 = time.perf_counter()
@@ -260,7 +265,10 @@ def main():
     n_pairs_stored = tiles["thole_stored"] * 4096
     n_pairs_far = tiles["thole_far"] * 4096
 
-    def roofline_of(name, tv, label, hybrid=None):
+    # the Jacobi iterations of the beads of one rank run in lockstep: one launch carries `batch` systems (mpmc_last_batch_size)
+    batch = beads[0].last_batch_size() if (beads and args.concurrency == "async") else 1
+
+    def roofline_of(name, tv, label, hybrid=None, per_launch=1):
         hybrid = hybrid_default if hybrid is None else hybrid
         """roofline of one kernel class from its HIP-event time.  Algorithmic figures (DESIGN.md §3):
         dipole_iter (k_dipole_iter_stream): HBM -- 16 B per stored unordered pair + 80 B per atom (positions, dipoles in, field out)
@@ -270,7 +278,7 @@ def main():
         avg_ms = tv["ms"] / max(tv["launches"], 1)
         sec = avg_ms * 1e-3
         if name == "dipole_iter":
-            alg = 16.0 * n_pairs_stored + n * 80.0
+            alg = (16.0 * n_pairs_stored + n * 80.0) * per_launch
             ach = alg / sec / 1e9 if sec > 0 else 0.0
             hbm = {"bound": "hbm", "kernel": "k_dipole_iter_hybrid" if hybrid else "k_dipole_iter_stream", "achieved": ach, "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": tv["launches"],
@@ -285,13 +293,19 @@ def main():
             # tensor.  fp64 issue is what binds it (measured on MI355X: sending every off-diagonal tile pair down the recompute path
             # leaves the launch time unchanged, dropping the HBM loads saves 8 %), so the compute roof is the primary
             # entry and the bytes are reported beside it.
-            fl = 33.0 * n_pairs_stored + 49.0 * n_pairs_far
+            fl = (33.0 * n_pairs_stored + 49.0 * n_pairs_far) * per_launch
             tf = fl / sec / 1e12 if sec > 0 else 0.0
-            out = {"bound": "mfma", "kernel": "k_dipole_iter_hybrid", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            if hbm["traffic"] is not None:
+                hbm["traffic"] *= per_launch
+            out = {"bound": "mfma", "kernel": "k_dipole_iter_hybrid_b" if per_launch > 1 else "k_dipole_iter_hybrid", "systems_per_launch": per_launch, "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": hbm["traffic"], "avg_launch_ms": avg_ms, "launches": tv["launches"],
                    "algorithmic_flops_per_launch": fl, "measured": label,
                    "hbm_side": {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "traffic")},
-                   "note": ("fp64 VALU bound (MI355X fp64 vector and matrix peaks are both 78.6 TFLOP/s; the kernel issues v_fma_f64).  One launch per Jacobi "
+                   "note": ("fp64 VALU bound (MI355X fp64 vector and matrix peaks are both 78.6 TFLOP/s; the kernel issues v_fma_f64).  In the default "
+                            "(async) mode the beads run on independent streams and this launch shares the GPU with other beads' kernels, so its "
+                            "duration in the timed region is about twice what it needs alone: `isolated` holds the same kernels one at a time, "
+                            "MPMC_PI_LOCKSTEP=1 runs all beads' iterations in one launch per iteration (clean durations, 9 % lower whole-job rate).  "
+                            "One launch per Jacobi "
                             "iteration over ALL tile pairs: 33 flop per streamed pair (16 B of stored tensor), 49 flop per recomputed far-field pair.  "
                             "Sustained v_fma_f64 issue measured on this pool (tools/microbench_f64.hip): 59 TFLOP/s, and the kernel's instruction mix "
                             "(FMA 41 %, MUL 29 %, DPP/int 17 %, ADD/RNDNE 11 %, RSQ 2 %) runs at ~80 % of the rate that mix sustains.  "
@@ -310,13 +324,15 @@ def main():
         evals = P * args.steps
         value = evals / dt
         solver_used = "compact" if mem_tensor > 0 else "matrix_free"
-        label = f"HIP events over the timed region ({args.concurrency}: {len(beads)} beads in flight on this GPU)"
+        label = f"HIP events on one bead's stream over the timed region ({args.concurrency}: {len(beads)} beads in flight on this GPU)"
         cand = [k for k in ("dipole_iter", "dipole_far", "pair") if agg.get(k, {}).get("launches")]
         dom = max(cand, key=lambda k: agg[k]["ms"]) if cand else "dipole_iter"
-        roof = roofline_of(dom, agg.get(dom, {"ms": 0.0, "launches": 0}), label)
-        roof["share_of_device_time"] = agg[dom]["ms"] / max(sum(v["ms"] for v in agg.values()), 1e-30) if cand else 0.0
+        roof = roofline_of(dom, agg.get(dom, {"ms": 0.0, "launches": 0}), label, per_launch=batch if dom == "dipole_iter" else 1)
+        # classes launched once per bead are seen on the instrumented bead only, the lockstep launches cover all `batch` beads
+        scaled = {k: v["ms"] * (1 if (batch > 1 and k == "dipole_iter") else max(batch, 1)) for k, v in agg.items()}
+        roof["share_of_device_time"] = scaled[dom] / max(sum(scaled.values()), 1e-30) if cand else 0.0
         roof["tile_pairs"] = tiles
-        roof["other_kernels"] = {k: roofline_of(k, agg[k], label) for k in cand if k != dom}
+        roof["other_kernels"] = {k: roofline_of(k, agg[k], label, per_launch=batch if k == "dipole_iter" else 1) for k in cand if k != dom}
         if iso is not None:
             lab2 = ("HIP events, extra untimed pass after the timed region: one bead at a time (each kernel alone on the GPU), Jacobi contraction "
                     "as two kernels on one stream (MPMC_JACOBI=split MPMC_ONE_STREAM=1)")

@@ -221,6 +221,9 @@ int mpmc_update_com(mpmc_ctx *ctx, double *com, double *wrapped_com, double *wra
  * sums4.  per_bead (may be NULL) receives n_local mpmc_result.  The cross-rank combine (4 fp64 all-reduce over
  * RCCL / MPI_Allgather in the reference, :763-766) is the caller's; mpmc_pi_finish divides by P. */
 int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sums4[4], mpmc_result *per_bead, int *any_iterator_failed);
+/* systems that shared each launch of the dipole iterations in this context's last evaluation (mpmc_pi_potential_local runs the
+ * Jacobi iterations of compatible beads in lockstep, one launch per iteration for the whole group); 1 = on its own */
+int mpmc_last_batch_size(mpmc_ctx *ctx);
 /* obs = sums / P ; returns V = rd + coulombic + vdw + polarization (:786-804) */
 double mpmc_pi_finish(const double sums4_global[4], int P, double obs4[4]);
 

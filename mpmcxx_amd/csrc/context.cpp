@@ -70,6 +70,15 @@ struct mpmc_ctx {
 	std::vector<double4> h_xyzq;     // host mirror of d_xyzq (slot order), for bulk position updates
 	std::vector<double> h_pos_sorted; // positions at the time of the last spatial sort
 	bool no_uniform = false;         // MPMC_NO_UNI=1
+	// lockstep solve of several systems (mpmc_pi_potential_local): enqueue() stops before the dipole iterations when asked to and
+	// possible; the batch driver then runs the iterations of all deferred systems in shared launches on one stream
+	bool defer_solve = false, solve_deferred = false, reduce_pending_join = false;
+	hipEvent_t ev_phase = nullptr;      // "everything before the solve is enqueued" marker on this context's stream
+	hipStream_t sync_stream = nullptr;  // stream that carries this context's final copies (null: its own)
+	SolveBead *d_solve_args = nullptr;  // device array of per-system pointers (owned by the first system of a batch)
+	std::vector<SolveBead> h_solve_args; // its host image (must outlive the asynchronous copy)
+	int cap_solve_args = 0;
+	int last_batch = 1;                 // systems per launch in the last evaluation's solve
 	size_t cap_tile_pairs = 0;
 	long long static_cnt[4] = {0, 0, 0, 0}; // n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent)
 
@@ -394,6 +403,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	(void)hipSetDevice(c->device);
 	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->ev_phase) (void)hipEventDestroy(c->ev_phase);
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -401,7 +411,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_inv_molmass, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -1002,6 +1012,17 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 	}
 
 	// ---- thole_iterative, reference src/System.Energy.cpp:3450-3543 ------------------------------------------------
+	c->solve_deferred = false;
+	c->last_batch = 1;
+	if ((mask & RUN_SOLVE) && c->defer_solve && compact && c->jacobi_hybrid && o.polar_precision == 0.0 && !o.polar_gs) {
+		// fixed iteration count, stored-tensor single-launch Jacobi: the caller runs the iterations of several systems together
+		if (reduce_forked) join_side(c);
+		if (!c->ev_phase) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_phase, hipEventDisableTiming));
+		HIP_TRY(c, hipEventRecord(c->ev_phase, st));
+		HIP_TRY(c, hipGetLastError());
+		c->solve_deferred = true;
+		return MPMC_OK;
+	}
 	if (mask & RUN_SOLVE) {
 		const bool by_precision = (o.polar_precision != 0.0);
 		const int want_rrms = (o.polar_rrms || o.polar_precision > 0) ? 1 : 0;
@@ -1092,7 +1113,8 @@ static unsigned full_mask(const mpmc_ctx *c);
 static int wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 	if (!c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_energy_wait: nothing enqueued");
 	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->sync_stream ? c->sync_stream : c->stream));
+	c->sync_stream = nullptr;
 	c->pending = false;
 	prof_harvest(c);
 	if (!out) return MPMC_OK;
@@ -1475,10 +1497,112 @@ extern "C" int mpmc_update_com(mpmc_ctx *c, double *com, double *wrapped_com, do
 }
 
 // ---- path integral ---------------------------------------------------------------------------------------
+// Enqueue one full evaluation of every system.  Systems whose solve can be deferred (same device, same box and options, fixed
+// iteration count, stored-tensor single-launch Jacobi) run everything up to the static field on their own streams -- the pair
+// sweeps of different systems overlap -- and then their dipole iterations together: one launch per iteration for the whole group
+// (SolveBead array, blockIdx.y = system) on the first system's stream, which also carries the final copies of every member.
+static bool same_solve_shape(const mpmc_ctx *a, const mpmc_ctx *b) {
+	return a->device == b->device && a->n == b->n && a->n_pad == b->n_pad && a->n_tile_pairs == b->n_tile_pairs &&
+	       std::memcmp(&a->opts, &b->opts, sizeof(mpmc_options)) == 0 && std::memcmp(a->box.b, b->box.b, sizeof(a->box.b)) == 0 &&
+	       a->jacc == b->jacc && a->no_uniform == b->no_uniform && a->no_classes == b->no_classes;
+}
+static int pi_enqueue_all(mpmc_ctx **beads, int n_local) {
+	// Opt-in (MPMC_PI_LOCKSTEP=1).  Measured on MI355X, 32 beads of the 10 000-atom box: the lockstep launches run each bead's
+	// contraction exactly as fast as a launch of its own (0.107 ms per bead: the kernel is issue-bound, not tail-bound), while
+	// independent streams let one bead's pair sweep fill the stalls of another bead's iterations -- 650 evaluations/s in lockstep
+	// against 737 on independent streams.  The lockstep form stays for its clean per-launch timings.
+	const char *e = std::getenv("MPMC_PI_LOCKSTEP");
+	const bool lockstep = e && e[0] == '1';
+	for (int b = 0; b < n_local; b++) {
+		mpmc_ctx *c = beads[b];
+		if (!c) return MPMC_ERR_ARG;
+		c->defer_solve = lockstep && n_local > 1;
+		int rc = enqueue(c, full_mask(c));
+		c->defer_solve = false;
+		if (rc != MPMC_OK) return rc;
+	}
+	std::vector<char> done(n_local, 0);
+	for (int lead = 0; lead < n_local; lead++) {
+		if (done[lead] || !beads[lead]->solve_deferred) continue;
+		std::vector<mpmc_ctx *> grp;
+		for (int b = lead; b < n_local; b++)
+			if (!done[b] && beads[b]->solve_deferred && same_solve_shape(beads[lead], beads[b])) {
+				grp.push_back(beads[b]);
+				done[b] = 1;
+			}
+		mpmc_ctx *L = grp[0];
+		const int nb = (int)grp.size();
+		const mpmc_options &o = L->opts;
+		HIP_TRY(L, hipSetDevice(L->device));
+		hipStream_t st = L->stream;
+		if (nb > L->cap_solve_args) {
+			dev_free(L, &L->d_solve_args, (size_t)L->cap_solve_args);
+			L->cap_solve_args = 0;
+			int rc = dev_alloc(L, &L->d_solve_args, (size_t)nb);
+			if (rc != MPMC_OK) return rc;
+			L->cap_solve_args = nb;
+		}
+		std::vector<SolveBead> &args = L->h_solve_args;
+		args.resize(nb);
+		for (int k = 0; k < nb; k++) {
+			mpmc_ctx *c = grp[k];
+			SolveBead &a = args[k];
+			a.at = atoms_view(c);
+			a.tile_pairs = c->d_tile_pairs;
+			a.cls = c->d_cls;
+			a.tp_shift = (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift;
+			a.ab = c->d_ab;
+			a.part = c->d_part;
+			a.mu[0] = c->d_mu[0];
+			a.mu[1] = c->d_mu[1];
+			a.e_static = c->d_e_static;
+			a.e_induced = c->d_e_induced;
+			a.rrms = c->d_rrms;
+			a.scal = c->d_scal;
+			if (k > 0) HIP_TRY(L, hipStreamWaitEvent(st, c->ev_phase, 0)); // the member's pre-solve work (its own stream) is done
+		}
+		HIP_TRY(L, hipMemcpyAsync(L->d_solve_args, args.data(), (size_t)nb * sizeof(SolveBead), hipMemcpyHostToDevice, st));
+		const int want_rrms = o.polar_rrms ? 1 : 0;
+		int cur = 0; // field_finalize wrote mu[0]
+		for (int it = 1; it <= o.polar_max_iter; it++) {
+			{
+				ProfScope p(L, MPMC_K_DIPOLE_ITER);
+				launch_dipole_iter_hybrid_batched(st, L->jacc, L->d_solve_args, nb, L->box, cur, L->n_tile_pairs);
+			}
+			{
+				ProfScope p(L, MPMC_K_REDUCE);
+				launch_dipole_update_batched(st, L->d_solve_args, nb, L->n_pad, L->n_tiles, cur, want_rrms);
+			}
+			cur = 1 - cur;
+		}
+		{
+			ProfScope p(L, MPMC_K_REDUCE);
+			launch_polar_energy_batched(st, L->d_solve_args, nb, cur, want_rrms);
+		}
+		HIP_TRY(L, hipGetLastError());
+		for (int k = 0; k < nb; k++) {
+			mpmc_ctx *c = grp[k];
+			c->mu_cur = cur;
+			c->iters = o.polar_max_iter;
+			c->have_polar = true;
+			c->last_batch = nb;
+			HIP_TRY(L, hipMemcpyAsync(c->h_scal, c->d_scal, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+			HIP_TRY(L, hipMemcpyAsync(c->h_cnt, c->d_cnt, C_COUNT * sizeof(long long), hipMemcpyDeviceToHost, st));
+			c->sync_stream = st;
+			c->pending = true;
+			c->solve_deferred = false;
+		}
+	}
+	return MPMC_OK;
+}
+
+// systems per launch in the dipole iterations of this context's last evaluation (1: it ran on its own)
+extern "C" int mpmc_last_batch_size(mpmc_ctx *c) { return c ? c->last_batch : 0; }
+
 extern "C" int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sums4[4], mpmc_result *per_bead, int *any_failed) {
 	if (!beads || n_local < 0 || !sums4) return MPMC_ERR_ARG;
-	for (int b = 0; b < n_local; b++) { // every bead enqueued on its own stream before the first wait
-		int rc = mpmc_energy_async(beads[b]);
+	{ // every bead enqueued before the first wait; the dipole iterations of compatible beads run in lockstep, in shared launches
+		int rc = pi_enqueue_all(beads, n_local);
 		if (rc != MPMC_OK) return rc;
 	}
 	sums4[0] = sums4[1] = sums4[2] = sums4[3] = 0;

@@ -117,6 +117,25 @@ void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const 
 void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                                const int *cls, const double4 *tp_shift /*null: no uniform-image fast path*/, int n_tile_pairs,
                                const double2 *ab, double *part);
+// ---- lockstep solve of B systems (path-integral images): per-system pointers of the batched Jacobi / update / energy kernels ----
+struct SolveBead {
+	AtomsDev at;
+	const int2 *tile_pairs;
+	const int *cls;
+	const double4 *tp_shift; // null: no uniform-image fast path
+	const double2 *ab;
+	double *part;            // [nt][n_pad][3]
+	double *mu[2];           // double-buffered dipoles
+	const double *e_static;
+	double *e_induced;
+	double *rrms;
+	double *scal;
+};
+void launch_dipole_iter_hybrid_batched(hipStream_t st, int jacc, const SolveBead *sb, int n_beads, const Box &bx, int cur, int n_tile_pairs);
+// mu[1-cur] = alpha (E0 + sum of slots) for every system (tail of contract_dipoles, calc_dipole_rrms)
+void launch_dipole_update_batched(hipStream_t st, const SolveBead *sb, int n_beads, int n_pad, int n_slots, int cur, int want_rrms);
+void launch_polar_energy_batched(hipStream_t st, const SolveBead *sb, int n_beads, int cur, int want_rrms);
+
 // lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
 void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm);
 

@@ -521,10 +521,10 @@ void launch_dipole_iter_mf(hipStream_t st, const AtomsDev &at, const Box &bx, do
 }
 
 // contract_dipoles tail :3586-3593, calc_dipole_rrms :3147-3177, are_we_done_yet :3227-3236
-__global__ __launch_bounds__(512) void k_dipole_update(AtomsDev at, const double *__restrict__ e_static, const double *__restrict__ part,
-                                                       int n_split, const double *__restrict__ mu_old, double *__restrict__ mu_new,
-                                                       double *__restrict__ e_induced, int want_rrms, double *__restrict__ rrms_atom,
-                                                       double allowed_sqerr, int *__restrict__ not_done_flag) {
+__device__ __forceinline__ void dipole_update_block(const AtomsDev &at, const double *__restrict__ e_static, const double *__restrict__ part,
+                                                    int n_split, const double *__restrict__ mu_old, double *__restrict__ mu_new,
+                                                    double *__restrict__ e_induced, int want_rrms, double *__restrict__ rrms_atom,
+                                                    double allowed_sqerr, int *__restrict__ not_done_flag) {
 	__shared__ double sh[kSlotGroups][kTile][3];
 	const int a = threadIdx.x & 63, g = threadIdx.x >> 6;
 	const int i = blockIdx.x * kTile + a;
@@ -557,6 +557,16 @@ __global__ __launch_bounds__(512) void k_dipole_update(AtomsDev at, const double
 	}
 	if (allowed_sqerr > 0.0 && broke && i < at.n) atomicOr(not_done_flag, 1);
 }
+__global__ __launch_bounds__(512) void k_dipole_update(AtomsDev at, const double *__restrict__ e_static, const double *__restrict__ part,
+                                                       int n_split, const double *__restrict__ mu_old, double *__restrict__ mu_new,
+                                                       double *__restrict__ e_induced, int want_rrms, double *__restrict__ rrms_atom,
+                                                       double allowed_sqerr, int *__restrict__ not_done_flag) {
+	dipole_update_block(at, e_static, part, n_split, mu_old, mu_new, e_induced, want_rrms, rrms_atom, allowed_sqerr, not_done_flag);
+}
+__global__ __launch_bounds__(512) void k_dipole_update_b(const SolveBead *__restrict__ sb, int n_split, int cur, int want_rrms) {
+	const SolveBead b = sb[blockIdx.y];
+	dipole_update_block(b.at, b.e_static, b.part, n_split, b.mu[cur], b.mu[1 - cur], b.e_induced, want_rrms, b.rrms, 0.0, nullptr);
+}
 
 __global__ __launch_bounds__(256) void k_dipole_reset(AtomsDev at, const double *__restrict__ e_static, double *__restrict__ mu) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
@@ -565,8 +575,8 @@ __global__ __launch_bounds__(256) void k_dipole_reset(AtomsDev at, const double 
 	for (int p = 0; p < 3; ++p) mu[3 * (size_t)i + p] = a * e_static[3 * (size_t)i + p]; // :3486
 }
 
-__global__ __launch_bounds__(256) void k_polar_energy(AtomsDev at, const double *__restrict__ mu, const double *__restrict__ e_static,
-                                                      const double *__restrict__ rrms_atom, double *__restrict__ scal) {
+__device__ __forceinline__ void polar_energy_block(const AtomsDev &at, const double *__restrict__ mu, const double *__restrict__ e_static,
+                                                   const double *__restrict__ rrms_atom, double *__restrict__ scal) {
 	__shared__ double sh[4];
 	double u = 0, rr = 0;
 	for (int i = threadIdx.x; i < at.n; i += 256) {
@@ -584,11 +594,25 @@ __global__ __launch_bounds__(256) void k_polar_energy(AtomsDev at, const double 
 		scal[S_RRMS] = rr / (double)at.n; // get_dipole_rrms :2656
 	}
 }
+__global__ __launch_bounds__(256) void k_polar_energy(AtomsDev at, const double *__restrict__ mu, const double *__restrict__ e_static,
+                                                      const double *__restrict__ rrms_atom, double *__restrict__ scal) {
+	polar_energy_block(at, mu, e_static, rrms_atom, scal);
+}
+__global__ __launch_bounds__(256) void k_polar_energy_b(const SolveBead *__restrict__ sb, int cur, int want_rrms) {
+	const SolveBead b = sb[blockIdx.x];
+	polar_energy_block(b.at, b.mu[cur], b.e_static, want_rrms ? b.rrms : nullptr, b.scal);
+}
 
 void launch_dipole_update(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, int n_split, const double *mu_old,
                           double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr, int *not_done_flag) {
 	hipLaunchKernelGGL(k_dipole_update, dim3(at.n_pad / kTile), dim3(kTile * kSlotGroups), 0, st, at, e_static, part, n_split, mu_old, mu_new,
 	                   e_induced, want_rrms, rrms_atom, allowed_sqerr, not_done_flag);
+}
+void launch_dipole_update_batched(hipStream_t st, const SolveBead *sb, int n_beads, int n_pad, int n_slots, int cur, int want_rrms) {
+	hipLaunchKernelGGL(k_dipole_update_b, dim3(n_pad / kTile, n_beads), dim3(kTile * kSlotGroups), 0, st, sb, n_slots, cur, want_rrms);
+}
+void launch_polar_energy_batched(hipStream_t st, const SolveBead *sb, int n_beads, int cur, int want_rrms) {
+	hipLaunchKernelGGL(k_polar_energy_b, dim3(n_beads), dim3(256), 0, st, sb, cur, want_rrms);
 }
 void launch_dipole_reset(hipStream_t st, const AtomsDev &at, const double *e_static, double *mu) {
 	hipLaunchKernelGGL(k_dipole_reset, dim3((at.n_pad + 255) / 256), dim3(256), 0, st, at, e_static, mu);

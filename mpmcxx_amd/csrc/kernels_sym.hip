@@ -855,18 +855,16 @@ __device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const d
 // W waves share one tile pair: wave w walks the steps [w n/W, (w+1) n/W) of the same 64 i-atoms, so a tile pair is W short
 // waves on W SIMDs instead of one long one (12 403 long waves on 1024 SIMDs left a quarter of the CU-time idle in the
 // tail of the launch).  The W partial sums of every atom meet in LDS and are added in wave order (fixed => reproducible).
-template <bool ORTHO, int JACC, int PIPE = 8, int W = 1>
-__global__ __launch_bounds__(64 * W) void k_dipole_iter_hybrid(AtomsDev at, Box bx, const double *__restrict__ mu,
-                                                                const int2 *__restrict__ tile_pairs, const int *__restrict__ cls,
-                                                                const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab,
-                                                                double *__restrict__ part /*[nt][n_pad][3]*/) {
+template <bool ORTHO, int JACC, int PIPE, int W>
+__device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
+                                          const int *__restrict__ cls, const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab,
+                                          double *__restrict__ part /*[nt][n_pad][3]*/, const int tp) {
 	static_assert(JACC != 2 || W == 1, "LDS-atomic accumulation is ordered only within one wave");
 	static_assert((32 / W) % PIPE == 0, "a wave's share of a diagonal tile (32 / W steps) must be whole rounds of PIPE");
 	__shared__ double s_j[7 * kJ2];
 	__shared__ double s_g[W][3][kTile];
 	__shared__ double s_f[W][3][kTile];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const int tp = blockIdx.x;
 	const int2 IJ = tile_pairs[tp];
 	const bool diag = (IJ.x == IJ.y);
 	const int i = IJ.x * kTile + lane;
@@ -946,6 +944,34 @@ __global__ __launch_bounds__(64 * W) void k_dipole_iter_hybrid(AtomsDev at, Box 
 		oj[0] = g[0];
 		oj[1] = g[1];
 		oj[2] = g[2];
+	}
+}
+
+template <bool ORTHO, int JACC, int PIPE = 8, int W = 1>
+__global__ __launch_bounds__(64 * W) void k_dipole_iter_hybrid(AtomsDev at, Box bx, const double *__restrict__ mu,
+                                                                const int2 *__restrict__ tile_pairs, const int *__restrict__ cls,
+                                                                const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab,
+                                                                double *__restrict__ part) {
+	hyb_block<ORTHO, JACC, PIPE, W>(at, bx, mu, tile_pairs, cls, tp_shift, ab, part, blockIdx.x);
+}
+
+// the same contraction for B systems in ONE launch (blockIdx.y = system): the images of a path-integral ensemble run their Jacobi
+// iterations in lockstep, so one launch carries B x 12 403 waves instead of 12 403 -- the launch tail (a quarter of the CU-time of a
+// single-system launch) and the per-launch gaps shrink by B.  `cur` selects the dipole buffer every system reads.
+template <bool ORTHO, int JACC, int PIPE = 8>
+__global__ __launch_bounds__(64) void k_dipole_iter_hybrid_b(const SolveBead *__restrict__ sb, Box bx, int cur) {
+	const SolveBead b = sb[blockIdx.y];
+	hyb_block<ORTHO, JACC, PIPE, 1>(b.at, bx, b.mu[cur], b.tile_pairs, b.cls, b.tp_shift, b.ab, b.part, blockIdx.x);
+}
+
+void launch_dipole_iter_hybrid_batched(hipStream_t st, int jacc, const SolveBead *sb, int n_beads, const Box &bx, int cur, int n_tile_pairs) {
+	dim3 grid(n_tile_pairs, n_beads), block(kTile);
+	if (bx.ortho) {
+		if (jacc == 1) hipLaunchKernelGGL((k_dipole_iter_hybrid_b<true, 1>), grid, block, 0, st, sb, bx, cur);
+		else hipLaunchKernelGGL((k_dipole_iter_hybrid_b<true, 0>), grid, block, 0, st, sb, bx, cur);
+	} else {
+		if (jacc == 1) hipLaunchKernelGGL((k_dipole_iter_hybrid_b<false, 1>), grid, block, 0, st, sb, bx, cur);
+		else hipLaunchKernelGGL((k_dipole_iter_hybrid_b<false, 0>), grid, block, 0, st, sb, bx, cur);
 	}
 }
 

@@ -106,6 +106,7 @@ def lib():
     L.mpmc_update_com.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_int)]
     L.mpmc_pi_potential_local.argtypes = [C.POINTER(vp), C.c_int, dp, C.POINTER(Result), C.POINTER(C.c_int)]
     L.mpmc_pi_finish.argtypes = [dp, C.c_int, dp]
+    L.mpmc_last_batch_size.argtypes = [vp]
     L.mpmc_pi_chain_mass_length2.argtypes = [C.c_int, C.c_int, dp, dp, ip]
     L.mpmc_pi_chain_mass_length2.restype = C.c_double
     L.mpmc_pi_kinetic.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
@@ -337,6 +338,10 @@ class System:
         a = (C.c_int64 * 4)()
         self._check(self._L.mpmc_get_tile_stats(self._h, a))
         return {"tile_pairs": a[0], "thole_stored": a[1], "thole_far": a[2], "beyond_cutoff": a[3]}
+
+    def last_batch_size(self) -> int:
+        """systems that shared each launch of the dipole iterations in the last evaluation (pi_potential_local batches compatible beads)."""
+        return int(self._L.mpmc_last_batch_size(self._h))
 
     def memory_usage(self):
         a, b = C.c_int64(), C.c_int64()

@@ -179,6 +179,33 @@ def test_pi_local_loop_matches_per_bead_energies():
         b.close()
 
 
+@pytest.mark.parametrize("lockstep", ["0", "1"])
+def test_pi_local_loop_polarizable_lockstep_solve(monkeypatch, lockstep):
+    """MPMC_PI_LOCKSTEP=1: the Jacobi iterations of the beads share launches (blockIdx.y = bead); same arithmetic per bead, so the
+    per-bead energies equal stand-alone evaluations bit for bit, with and without it."""
+    monkeypatch.setenv("MPMC_PI_LOCKSTEP", lockstep)
+    atoms, basis, opts = util.load_fixture("ion1000_polar")
+    beads = []
+    for b in range(3):
+        rng = np.random.default_rng(300 + b)
+        a = dict(atoms)
+        a["pos"] = atoms["pos"] + rng.normal(scale=0.05, size=atoms["pos"].shape)
+        beads.append(energy.System(a, basis, opts))
+    sums, per, failed = energy.pi_potential_local(beads)
+    assert not failed
+    assert beads[0].last_batch_size() == (3 if lockstep == "1" else 1)
+    mu_batch = [b.dipoles()[0].copy() for b in beads]
+    single = [b.energy() for b in beads]
+    assert [p["energy"] for p in per] == single
+    assert [p["polarization_energy"] for p in per] == [b.observables["polarization_energy"] for b in beads]
+    for m, b in zip(mu_batch, beads):
+        assert np.array_equal(m, b.dipoles()[0])
+    g = util.golden("ion1000_polar")
+    assert all(p["polar_iterations"] == int(g["polar_iterations"]) for p in per)
+    for b in beads:
+        b.close()
+
+
 @pytest.mark.parametrize("name", util.LARGE)
 def test_full_size_boxes_match_reference(name, tmp_path):
     """BASELINE configs 3 and 4 (10 000 atoms): energies from the reference run in the build container."""
