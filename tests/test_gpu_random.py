@@ -200,3 +200,16 @@ def test_random_systems_gauss_seidel(seed):
     if seed >= 5:
         opts.update(polar_precision=1e-4, polar_max_iter=10)
     check(atoms, basis, opts, f"gs seed {seed} n {n} {cell} {opts}")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_mid_size_systems(seed):
+    """700-1500 atoms: many tiles, mixed tile-pair classes (cutoff / damping range / uniform image), molecules spanning tile borders."""
+    rng = np.random.default_rng(9000 + seed)
+    n = [700, 1100, 1500, 900][seed]
+    cell = ["ortho", "cubic", "triclinic", "ortho"][seed]
+    atoms, basis = random_system(rng, n, cell)
+    opts = random_options(rng)
+    opts.update(rd_only=0, polarization=1, polar_iterative=1, polar_damp=float(rng.uniform(1.5, 2.6)), polar_ewald=int(seed != 1),
+                polar_max_iter=int(rng.integers(2, 5)), polar_gs=0)
+    check(atoms, basis, opts, f"mid seed {seed} n {n} {cell} {opts}")
