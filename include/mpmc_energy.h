@@ -50,7 +50,8 @@ extern "C" {
 #define MPMC_SOLVER_AUTO 0         /* COMPACT when its store fits, else MATRIX_FREE                         */
 #define MPMC_SOLVER_MATRIX_FREE 1  /* recompute the damped dipole tensor per pair per iteration (VALU-bound)  */
 #define MPMC_SOLVER_COMPACT 2      /* store (d1/r^3, 3 d2/r^5) per unordered pair, 16 B/pair (HBM-bound)      */
-#define MPMC_SOLVER_DENSE 3        /* store the reference's dense 3N x 3N A matrix (thole_amatrix layout)     */
+#define MPMC_SOLVER_DENSE 3        /* the reference's dense 3N x 3N A matrix in device memory, contraction on the
+                                    * fp64 matrix cores; on request only (HBM-bound at 9x the bytes of COMPACT)  */
 
 /* ---- out-of-scope reference switches: pass the ones that are ON so the library can refuse them ---------- */
 #define MPMC_FLAG_WOLF (1ull << 0)          /* (now supported: mpmc_options.wolf; the bit stays for ABI stability) */

@@ -106,6 +106,8 @@ struct mpmc_ctx {
 	int mu_cur = 0;
 	// dense A rows scratch
 	double *d_arows = nullptr;
+	double *d_adense = nullptr; // solver DENSE: the (3 n_pad)^2 matrix of thole_amatrix without its diagonal blocks
+	size_t cap_adense = 0;
 	size_t cap_arows = 0;
 	// compact Thole tensor store: (a,b) per unordered pair, tile-pair major, 64*64 double2 per tile pair
 	double2 *d_ab = nullptr;
@@ -411,7 +413,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_inv_molmass, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -471,8 +473,6 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 			return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: polar_max_iter must be >= 1 when polar_precision is 0 (the reference never terminates)");
 		if (o->polar_precision < 0.0) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: polar_precision < 0");
 		if (o->solver < MPMC_SOLVER_AUTO || o->solver > MPMC_SOLVER_DENSE) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: bad solver");
-		if (o->solver == MPMC_SOLVER_DENSE)
-			return fail(c, MPMC_ERR_UNSUPPORTED, "mpmc_set_options: the dense 3N x 3N solver is not built; mpmc_thole_amatrix gives the dense matrix, COMPACT stores the same tensors in 16 B/pair");
 	}
 	if (o->ewald_kmax < 0 || o->ewald_kmax > 64) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_set_options: ewald_kmax out of range");
 	if (o->feynman_hibbs) {
@@ -846,6 +846,16 @@ static int resolve_solver(mpmc_ctx *c) {
 		if (const char *e = std::getenv("MPMC_TENSOR_BUDGET_MB")) budget_mb = (size_t)std::strtoull(e, nullptr, 10);
 		want = (need * sizeof(double2) <= budget_mb * (size_t)1048576) ? MPMC_SOLVER_COMPACT : MPMC_SOLVER_MATRIX_FREE;
 	}
+	if (want == MPMC_SOLVER_DENSE) { // the reference's layout, on request only: (3 n_pad)^2 doubles
+		const size_t nd = (size_t)3 * c->n_pad * (size_t)3 * c->n_pad;
+		if (nd > c->cap_adense) {
+			dev_free(c, &c->d_adense, c->cap_adense);
+			c->cap_adense = 0;
+			int rc = dev_alloc(c, &c->d_adense, nd);
+			if (rc != MPMC_OK) return rc;
+			c->cap_adense = nd;
+		}
+	}
 	if (want == MPMC_SOLVER_COMPACT && need > c->cap_ab) {
 		dev_free(c, &c->d_ab, c->cap_ab);
 		c->cap_ab = 0;
@@ -1027,7 +1037,13 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		const bool by_precision = (o.polar_precision != 0.0);
 		const int want_rrms = (o.polar_rrms || o.polar_precision > 0) ? 1 : 0;
 		const double allowed = by_precision ? o.polar_precision * o.polar_precision * kDebye2SKA * kDebye2SKA : 0.0;
-		const int iter_slots = compact ? c->n_tiles : c->n_split;
+		const bool dense = (c->solver_used == MPMC_SOLVER_DENSE) && !o.polar_gs;
+		constexpr int kDenseChunks = 16;
+		const int iter_slots = dense ? kDenseChunks : (compact ? c->n_tiles : c->n_split);
+		if (dense) { // thole_amatrix into device memory, once per evaluation (the positions changed)
+			ProfScope p(c, MPMC_K_TENSOR);
+			launch_dense_build(st, at, c->box, o.polar_damp, c->d_adense);
+		}
 		int it = 0;
 		bool keep = true;
 		while (keep) {
@@ -1058,7 +1074,10 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 				}
 				continue;
 			}
-			if (compact && c->jacobi_hybrid) {
+			if (dense) {
+				ProfScope p(c, MPMC_K_DIPOLE_ITER);
+				launch_dense_matvec(st, c->d_adense, c->n_pad, c->d_mu[c->mu_cur], kDenseChunks, c->d_part);
+			} else if (compact && c->jacobi_hybrid) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
 				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
 				                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part);

@@ -139,6 +139,12 @@ void launch_polar_energy_batched(hipStream_t st, const SolveBead *sb, int n_bead
 // lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
 void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm);
 
+// ---- dense solver (kernels_dense.hip): the reference's 3N x 3N layout, contraction on the fp64 matrix cores ------------------------
+// a: (3 n_pad)^2 doubles, slot order, diagonal 3x3 blocks and padded slots zero
+void launch_dense_build(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, double *a);
+// part[chunk][n_pad][3] = - (rows of the chunk of A) . x  (A symmetric); k_dipole_update sums the chunks
+void launch_dense_matvec(hipStream_t st, const double *a, int n_pad, const double *x, int n_chunks, double *part);
+
 // ---- Gauss-Seidel sweeps (kernels_gs.hip): `polar_gs on`, identity atom order, matrix-free ---------------------------
 // one sweep over all tiles in atom order: mu is updated in place, e_induced receives each atom's induced field; part [nt][64][3]
 void launch_gs_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, const double *e_static, double *mu, double *e_induced,

@@ -121,6 +121,24 @@ def test_bulk_position_update_from_host_buffers():
     S.close()
 
 
+@pytest.mark.parametrize("solver", ["matrix_free", "compact", "dense"])
+@pytest.mark.parametrize("name", ["ion216_polar", "water64_polar", "ion216_triclinic", "ion1000_polar", "ion216_precision"])
+def test_every_dipole_solver_reproduces_the_reference(name, solver):
+    """matrix_free (tensors recomputed), compact (16 B/pair store, production), dense (the reference's 3N x 3N matrix in device memory,
+    contraction on the fp64 matrix cores): same energies, dipoles and iteration counts as the reference."""
+    atoms, basis, opts = util.load_fixture(name)
+    g = util.golden(name)
+    S = energy.System(atoms, basis, dict(opts, solver=solver))
+    S.energy()
+    r = S.observables
+    util.assert_energies(r, g, False, label=f"{name}/{solver}")
+    assert r["polar_iterations"] == int(g["polar_iterations"]) and r["iterator_failed"] == g["iterator_failed"]
+    mu, E, F = S.dipoles()
+    assert util.max_rel(mu.reshape(-1), g["mu"]) < util.REL_TOL
+    assert util.max_rel(F.reshape(-1), g["ef_induced"]) < 1e-8
+    S.close()
+
+
 def test_run_to_run_determinism():
     S, *_ = make("ion1000_polar")
     vals = [S.energy() for _ in range(3)]

@@ -1,13 +1,33 @@
-"""Jacobi vs Gauss-Seidel dipole solver on the 10 000-atom benchmark box: wall time per evaluation (python tools/solver_time.py)."""
+"""The dipole solvers on the 10 000-atom benchmark box: wall time per evaluation and HIP-event time of the solver's kernels
+(python tools/solver_time.py).  compact = production path (16 B/pair store + far-field recompute), matrix_free = every tensor
+recomputed, dense = the reference's 3N x 3N matrix in device memory with the contraction on the fp64 matrix cores, gauss_seidel =
+`polar_gs on` (in-place sweeps in atom order)."""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import bench
 from mpmcxx_amd import energy
 atoms, basis, opts = bench.build_case(10000, tempfile.mkdtemp())
-for gs in (0, 1):
-    o = dict(opts); o["polar_gs"] = gs
+n3 = 3 * ((10000 + 63) // 64 * 64)
+for label, extra in (("compact", {"solver": "compact"}), ("matrix_free", {"solver": "matrix_free"}), ("dense", {"solver": "dense"}),
+                     ("gauss_seidel", {"polar_gs": 1})):
+    o = dict(opts); o.update(extra)
     S = energy.System(atoms, basis, o)
-    e = S.energy(); 
-    t0 = time.perf_counter(); e = S.energy(); dt = time.perf_counter() - t0
-    print(f"polar_gs {gs}: {dt*1e3:.2f} ms per evaluation, E {e:.12e}, pol {S.observables['polarization_energy']:.12e}, iters {S.observables['polar_iterations']}")
+    e = S.energy()
+    S.set_profiling(True); S.timings(reset=True)
+    reps = 1 if label == "gauss_seidel" else 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        e = S.energy()
+    dt = (time.perf_counter() - t0) / reps
+    t = S.timings(reset=True)
+    it = t["dipole_iter"]; ten = t["tensor"]
+    line = (f"{label:12s}: {dt*1e3:8.2f} ms per evaluation ({1/dt:7.1f}/s), pol {S.observables['polarization_energy']:.12e}, "
+            f"iteration kernel {it['ms']/max(it['launches'],1):.4f} ms x {it['launches']//reps}")
+    if ten["launches"]:
+        line += f", matrix build {ten['ms']/ten['launches']:.3f} ms"
+    if label == "dense":
+        gb = n3 * n3 * 8 / 1e9
+        line += f"; dense contraction reads {gb:.2f} GB -> {gb / (it['ms']/it['launches']*1e-3) / 1e3:.2f} TB/s, {2*n3*n3*16/(it['ms']/it['launches']*1e-3)/1e12:.1f} TFLOP/s issued on v_mfma_f64 (1/16 useful)"
+    tot, tens = S.memory_usage()
+    print(line + f"; device memory {tot/2**30:.2f} GiB", flush=True)
     S.close()
