@@ -277,6 +277,16 @@ def main():
                                             Coulomb 3, field factor + both atoms 17, Thole damping + tensor 24, averaged over the in-cutoff fraction)"""
         avg_ms = tv["ms"] / max(tv["launches"], 1)
         sec = avg_ms * 1e-3
+        if name == "dipole_iter" and args.solver == "dense":  # the reference's 3N x 3N layout, contraction on v_mfma_f64_16x16x4_f64
+            n3 = 3 * ((n + 63) // 64 * 64)
+            alg = 8.0 * n3 * n3
+            ach = alg / sec / 1e9 if sec > 0 else 0.0
+            issued = 2.0 * n3 * n3 * 16 / sec / 1e12 if sec > 0 else 0.0
+            return {"bound": "hbm", "kernel": "k_dense_matvec", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "avg_launch_ms": avg_ms, "launches": tv["launches"], "algorithmic_bytes_per_launch": alg, "measured": label,
+                    "mfma_side": {"issued_tflops": issued, "peak_tflops": FP64_VALU_PEAK_TFLOPS, "frac": issued / FP64_VALU_PEAK_TFLOPS,
+                                  "useful_fraction": 1.0 / 16.0},
+                    "note": "dense (3N)^2 x 8 B matrix-vector product: the vector is replicated over the 16 rows of the MFMA's A operand, no operand reuse"}
         if name == "dipole_iter":
             alg = (16.0 * n_pairs_stored + n * 80.0) * per_launch
             ach = alg / sec / 1e9 if sec > 0 else 0.0
@@ -323,7 +333,7 @@ def main():
     if rank == 0:
         evals = P * args.steps
         value = evals / dt
-        solver_used = "compact" if mem_tensor > 0 else "matrix_free"
+        solver_used = "dense" if args.solver == "dense" else ("compact" if mem_tensor > 0 else "matrix_free")
         label = f"HIP events on one bead's stream over the timed region ({args.concurrency}: {len(beads)} beads in flight on this GPU)"
         cand = [k for k in ("dipole_iter", "dipole_far", "pair") if agg.get(k, {}).get("launches")]
         dom = max(cand, key=lambda k: agg[k]["ms"]) if cand else "dipole_iter"
