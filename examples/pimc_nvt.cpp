@@ -43,6 +43,7 @@ int main(int argc, char **argv) {
 			beads.emplace_back(new mpmc::System());
 			mpmc::System &s = *beads.back();
 			s.device = b % ndev; // image -> device round robin
+			s.eager_dipoles = false; // nothing here reads the per-atom dipoles
 			if (mc.cfg.parallel_restarts) { // one geometry per image: JOB.restart-%04d.pqr (src/SimulationControl.PathIntegral.cpp:619-621)
 				char name[64];
 				std::snprintf(name, sizeof name, ".restart-%04d.pqr", b);

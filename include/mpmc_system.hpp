@@ -81,6 +81,10 @@ public:
 	uint64_t unsupported_flags = 0; // MPMC_FLAG_*: reference switches outside the hot path that are ON
 	int solver = MPMC_SOLVER_AUTO;
 	int device = 0;
+	// the reference's energy() leaves mu / ef_static / ef_induced in every Atom, but reads them only when it writes the dipole and
+	// field files (src/System.Output.cpp:1132-1229): a Monte Carlo driver may switch the per-call copy-back off and call
+	// update_dipoles() when it samples
+	bool eager_dipoles = true;
 
 	// ---- state ----
 	PeriodicBoundary pbc;
@@ -238,6 +242,10 @@ public:
 		return a;
 	}
 
+	void update_dipoles() { // atoms[].mu / ef_static / ef_induced of the last evaluation
+		if (polarization && !rd_only && ctx_) fetch_dipoles();
+	}
+
 	mpmc_ctx *context() {
 		sync_state();
 		return ctx_;
@@ -344,7 +352,7 @@ private:
 		stats_.polarization_iterations = (double)r.polar_iterations;
 		iterator_failed = r.iterator_failed;
 		last_volume = pbc.volume;
-		if (polarization && !rd_only) fetch_dipoles();
+		if (polarization && !rd_only && eager_dipoles) fetch_dipoles();
 	}
 
 	double piece(int (*fn)(mpmc_ctx *, double *)) {
