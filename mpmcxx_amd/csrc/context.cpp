@@ -382,11 +382,12 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	A(dev_alloc(c, &c->d_tile_bounds, 12 * (P / kTile)));
 	A(dev_alloc(c, &c->d_slot_of, P));
 	A(dev_alloc(c, &c->d_perm, P));
-	A(dev_alloc(c, &c->d_scal, (size_t)S_COUNT));
-	A(dev_alloc(c, &c->d_cnt, (size_t)C_COUNT));
+	A(dev_alloc(c, &c->d_scal, (size_t)S_COUNT + (size_t)C_COUNT)); // scalars and counts share one buffer: one clear, one read-back
+	if (rc == MPMC_OK) c->d_cnt = reinterpret_cast<long long *>(c->d_scal + S_COUNT);
 	A(dev_alloc(c, &c->d_flag, (size_t)1));
-	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_scal, S_COUNT * sizeof(double)) != hipSuccess) rc = MPMC_ERR_HIP;
-	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_cnt, C_COUNT * sizeof(long long)) != hipSuccess) rc = MPMC_ERR_HIP;
+	static_assert(sizeof(long long) == sizeof(double), "scalars and counts share one buffer");
+	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_scal, (S_COUNT + C_COUNT) * sizeof(double)) != hipSuccess) rc = MPMC_ERR_HIP;
+	if (rc == MPMC_OK) c->h_cnt = reinterpret_cast<long long *>(c->h_scal + S_COUNT);
 	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_flag, sizeof(int)) != hipSuccess) rc = MPMC_ERR_HIP;
 	if (rc == MPMC_OK) rc = rot_selftest(c);
 	if (rc != MPMC_OK) {
@@ -411,14 +412,13 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	for (auto &e : c->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_inv_molmass, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal, c->d_cnt,
+	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_inv_molmass, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
 	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (c->h_scal) (void)hipHostFree(c->h_scal);
-	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 	if (c->h_flag) (void)hipHostFree(c->h_flag);
 	if (c->h_delta_out) (void)hipHostFree(c->h_delta_out);
 	if (c->h_mv_blob) (void)hipHostFree(c->h_mv_blob);
@@ -932,8 +932,7 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 	c->iters = 0;
 	c->failed = 0;
 
-	HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, S_COUNT * sizeof(double), st));
-	HIP_TRY(c, hipMemsetAsync(c->d_cnt, 0, C_COUNT * sizeof(long long), st));
+	HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (S_COUNT + C_COUNT) * sizeof(double), st));
 
 	if (mask & (RUN_FIELD | RUN_SOLVE)) {
 		if ((rc = ensure_polar_buffers(c)) != MPMC_OK) return rc;
@@ -947,8 +946,10 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 	// when every molecule is a single atom
 	const bool need_intra = (mask & RUN_PAIR) && (mask & RUN_PAIR_ES) && !(o.wolf && (mask & RUN_WOLF)) && (c->n_molecules != c->n);
 	const bool side_work = need_sf || (mask & RUN_ATOMTERMS) || need_intra;
+	// a fork/join costs ~20 us of dispatch latency: worth it next to reciprocal-space work, not for the O(N) atom terms alone
+	const bool side_fork = c->two_streams && (need_sf || need_intra);
 	if (side_work) {
-		hipStream_t s2 = fork_side(c);
+		hipStream_t s2 = side_fork ? fork_side(c) : st;
 		if (need_intra) {
 			ProfScope p(c, MPMC_K_PAIR, s2);
 			launch_intra_terms(s2, at, c->d_slot_of, c->ewald_alpha, c->d_scal);
@@ -1004,13 +1005,13 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
 		                  compact ? c->d_ab : nullptr);
 	}
-	if (side_work) join_side(c);
+	if (side_work && side_fork) join_side(c);
 	bool reduce_forked = false;
 	if (mask & RUN_PAIR) { // the scalar totals of the sweep are only read back at the very end: fold them beside the field / dipole work
-		hipStream_t s3 = fork_side(c);
+		reduce_forked = c->two_streams && (mask & RUN_FIELD) != 0;
+		hipStream_t s3 = reduce_forked ? fork_side(c) : st;
 		ProfScope p(c, MPMC_K_REDUCE, s3);
 		launch_reduce_pairs(s3, c->d_block_part, c->d_block_cnt, c->n_tile_pairs, c->d_scal, c->d_cnt);
-		reduce_forked = true;
 	}
 
 	// ---- static field ---------------------------------------------------------------------------------------
@@ -1121,8 +1122,7 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 	}
 	if (reduce_forked) join_side(c);
 	HIP_TRY(c, hipGetLastError());
-	HIP_TRY(c, hipMemcpyAsync(c->h_scal, c->d_scal, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
-	HIP_TRY(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, C_COUNT * sizeof(long long), hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipMemcpyAsync(c->h_scal, c->d_scal, (S_COUNT + C_COUNT) * sizeof(double), hipMemcpyDeviceToHost, st));
 	c->pending = true;
 	return MPMC_OK;
 }
@@ -1605,8 +1605,7 @@ static int pi_enqueue_all(mpmc_ctx **beads, int n_local) {
 			c->iters = o.polar_max_iter;
 			c->have_polar = true;
 			c->last_batch = nb;
-			HIP_TRY(L, hipMemcpyAsync(c->h_scal, c->d_scal, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
-			HIP_TRY(L, hipMemcpyAsync(c->h_cnt, c->d_cnt, C_COUNT * sizeof(long long), hipMemcpyDeviceToHost, st));
+			HIP_TRY(L, hipMemcpyAsync(c->h_scal, c->d_scal, (S_COUNT + C_COUNT) * sizeof(double), hipMemcpyDeviceToHost, st));
 			c->sync_stream = st;
 			c->pending = true;
 			c->solve_deferred = false;
