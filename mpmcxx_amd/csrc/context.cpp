@@ -34,7 +34,7 @@ struct mpmc_ctx {
 	hipStream_t stream2 = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	bool two_streams = true; // MPMC_ONE_STREAM=1 disables the fork/join
-	int jacc = 0; // hybrid Jacobi kernel variant (MPMC_JACC): 0 DPP rotation, 1 bpermute, 2 LDS ds_add_f64, 3 DPP with two waves per tile pair
+	int jacc = 0; // hybrid Jacobi kernel variant (MPMC_JACC): 0 DPP lane rotation, 1 ds_bpermute (when the DPP self-test fails)
 	bool jacobi_hybrid = true; // one launch per Jacobi iteration over all tile pairs; MPMC_JACOBI=split: two kernels (stream / far)
 	int max_atoms = 0, max_pad = 0;
 	int n = 0, n_pad = 0, n_tiles = 0, n_tile_pairs = 0, n_split = 1;

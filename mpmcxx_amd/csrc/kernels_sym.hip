@@ -749,9 +749,7 @@ void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const 
 //   JACC selects how the j-side accumulators meet their atoms:
 //     0  registers rotated by one lane per step with v_mov_b32_dpp wave_rol:1 (6 VALU issues per step)
 //     1  the same through ds_bpermute_b32 (fallback when the DPP self-test fails)
-//     2  ds_add_f64 into an LDS image of the 64 j-atoms: the 64 lanes hit 64 different addresses in every step (no
-//        conflicts, no contention) and a wave's LDS operations execute in program order, so the sum order is fixed;
-//        the adds run in the LDS unit and cost no VALU issue.
+//   (ds_add_f64 into an LDS image of the j-atoms was measured too: 0.113 ms against 0.105 ms per launch, dropped.)
 // ------------------------------------------------------------------------------------------------------
 // FAR / UNI are wave-uniform properties of the tile pair: the walk is instantiated for each combination so that the
 // inner loop carries no branch.  UNI: the periodic image index is the same for all 4096 atom pairs (k_classify), the
@@ -795,19 +793,13 @@ __device__ __forceinline__ void hyb_step(const Box &bx, const HybLds &L, const i
 	A.fx = fma(-t.x, mjx, fma(dj, ox, A.fx));
 	A.fy = fma(-t.x, mjy, fma(dj, oy, A.fy));
 	A.fz = fma(-t.x, mjz, fma(dj, oz, A.fz));
-	if (JACC == 2) {
-		atomicAdd(&L.gx[jl & 63], fma(di, ox, -(t.x * mix)));
-		atomicAdd(&L.gy[jl & 63], fma(di, oy, -(t.x * miy)));
-		atomicAdd(&L.gz[jl & 63], fma(di, oz, -(t.x * miz)));
-	} else {
-		A.gx = fma(-t.x, mix, fma(di, ox, A.gx));
-		A.gy = fma(-t.x, miy, fma(di, oy, A.gy));
-		A.gz = fma(-t.x, miz, fma(di, oz, A.gz));
-		if (ROT) {
-			A.gx = rot_from_next<JACC == 0>(A.gx, src4);
-			A.gy = rot_from_next<JACC == 0>(A.gy, src4);
-			A.gz = rot_from_next<JACC == 0>(A.gz, src4);
-		}
+	A.gx = fma(-t.x, mix, fma(di, ox, A.gx));
+	A.gy = fma(-t.x, miy, fma(di, oy, A.gy));
+	A.gz = fma(-t.x, miz, fma(di, oz, A.gz));
+	if (ROT) {
+		A.gx = rot_from_next<JACC == 0>(A.gx, src4);
+		A.gy = rot_from_next<JACC == 0>(A.gy, src4);
+		A.gz = rot_from_next<JACC == 0>(A.gz, src4);
 	}
 }
 
@@ -859,7 +851,6 @@ template <bool ORTHO, int JACC, int PIPE, int W>
 __device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
                                           const int *__restrict__ cls, const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab,
                                           double *__restrict__ part /*[nt][n_pad][3]*/, const int tp) {
-	static_assert(JACC != 2 || W == 1, "LDS-atomic accumulation is ordered only within one wave");
 	static_assert((32 / W) % PIPE == 0, "a wave's share of a diagonal tile (32 / W steps) must be whole rounds of PIPE");
 	__shared__ double s_j[7 * kJ2];
 	__shared__ double s_g[W][3][kTile];
@@ -879,7 +870,6 @@ __device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, con
 		                        (at.mf[j0 + lane].y & AF_PAD) ? 0.0 : 1.0};
 #pragma unroll
 		for (int c = 0; c < 7; ++c) s_j[c * kJ2 + lane] = s_j[c * kJ2 + lane + kTile] = vals[c]; // twice: slot l + s never wraps (hyb_step)
-		if (JACC == 2) s_g[0][0][lane] = s_g[0][1][lane] = s_g[0][2][lane] = 0.0;
 	}
 	__syncthreads();
 	const int c = cls[tp];
@@ -906,7 +896,7 @@ __device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, con
 		else MPMC_WALK(false, false, pi.x, pi.y, pi.z);
 	}
 #undef MPMC_WALK
-	if (JACC != 2) { // park the rotated accumulators at their atoms' LDS slots
+	{ // park the rotated accumulators at their atoms' LDS slots
 		const int jl_last = (lane + s_first + n_steps - 1) & 63;
 		s_g[w][0][jl_last] = A.gx;
 		s_g[w][1][jl_last] = A.gy;
@@ -981,13 +971,10 @@ void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, con
 #define MPMC_LAUNCH_HYB(O, J, P, W) \
 	hipLaunchKernelGGL((k_dipole_iter_hybrid<O, J, P, W>), grid, dim3(kTile * W), 0, st, at, bx, mu, tile_pairs, cls, tp_shift, ab, part)
 	if (bx.ortho) {
-		if (jacc == 2) MPMC_LAUNCH_HYB(true, 2, 8, 1);
-		else if (jacc == 1) MPMC_LAUNCH_HYB(true, 1, 8, 1);
-		else if (jacc == 3) MPMC_LAUNCH_HYB(true, 0, 8, 2); // two waves per tile pair (measured equal to one: kept as a tuning knob)
+		if (jacc == 1) MPMC_LAUNCH_HYB(true, 1, 8, 1);
 		else MPMC_LAUNCH_HYB(true, 0, 8, 1);
 	} else {
-		if (jacc == 2) MPMC_LAUNCH_HYB(false, 2, 8, 1);
-		else if (jacc == 1) MPMC_LAUNCH_HYB(false, 1, 8, 1);
+		if (jacc == 1) MPMC_LAUNCH_HYB(false, 1, 8, 1);
 		else MPMC_LAUNCH_HYB(false, 0, 8, 1);
 	}
 #undef MPMC_LAUNCH_HYB
