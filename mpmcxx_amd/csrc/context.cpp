@@ -1040,7 +1040,7 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		const double allowed = by_precision ? o.polar_precision * o.polar_precision * kDebye2SKA * kDebye2SKA : 0.0;
 		const bool dense = (c->solver_used == MPMC_SOLVER_DENSE) && !o.polar_gs;
 		constexpr int kDenseChunks = 16;
-		const int iter_slots = dense ? kDenseChunks : (compact ? c->n_tiles : c->n_split);
+		const int iter_slots = dense ? kDenseChunks : c->n_tiles;
 		if (dense) { // thole_amatrix into device memory, once per evaluation (the positions changed)
 			ProfScope p(c, MPMC_K_TENSOR);
 			launch_dense_build(st, at, c->box, o.polar_damp, c->d_adense);
@@ -1081,7 +1081,7 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 			} else if (compact && c->jacobi_hybrid) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
 				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
-				                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part);
+				                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part, o.polar_damp);
 			} else if (compact) {
 				const int *counts = c->d_lists + 2 * (size_t)c->n_tile_pairs;
 				hipStream_t s2 = fork_side(c); // the fp64-bound far-field kernel runs beside the HBM-bound streaming kernel
@@ -1095,9 +1095,10 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 					                          c->d_ab, c->d_part);
 				}
 				join_side(c);
-			} else {
+			} else { // matrix-free: the same symmetric tile-pair walk with nothing stored (null store => damped tensors rebuilt)
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
-				launch_dipole_iter_mf(st, at, c->box, o.polar_damp, c->d_mu[c->mu_cur], c->n_split, c->d_part);
+				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
+				                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, nullptr, c->d_part, o.polar_damp);
 			}
 			{
 				ProfScope p(c, MPMC_K_REDUCE);

@@ -62,9 +62,6 @@ void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const
 void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip,
                            const double *part, int n_split, double gamma, double *e_static, double *mu);
 
-// Thole dipole iteration, matrix-free: part[s][i] = - sum_{j in split s, j != i} T_ij mu_j
-void launch_dipole_iter_mf(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, const double *mu, int n_split,
-                           double *part);
 // new_mu = alpha (E0 + F) ; optionally rrms per atom and the "broke tolerance" flag (are_we_done_yet)
 void launch_dipole_update(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, int n_split,
                           const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom,
@@ -116,7 +113,8 @@ void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const 
 // jacc: 0 DPP lane rotation, 1 ds_bpermute rotation, 2 ds_add_f64 into an LDS image of the j-atoms
 void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                                const int *cls, const double4 *tp_shift /*null: no uniform-image fast path*/, int n_tile_pairs,
-                               const double2 *ab, double *part);
+                               const double2 *ab /*null: matrix-free, tensors inside the damping range rebuilt from the positions*/,
+                               double *part, double polar_damp);
 // ---- lockstep solve of B systems (path-integral images): per-system pointers of the batched Jacobi / update / energy kernels ----
 struct SolveBead {
 	AtomsDev at;

@@ -463,63 +463,6 @@ void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, in
 	                   gamma, e_static, mu);
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Thole dipole iteration, matrix-free (reference thole_amatrix :2661-2770 + contract_dipoles :3564-3598 fused):
-//   part[s][i] = - sum_{j in split s, j != i} ( a mu_j - b d (d . mu_j) ),  a = damp1/r^3, b = 3 damp2/r^5
-// No cutoff, no exclusions (the A matrix couples every pair).
-// ------------------------------------------------------------------------------------------------------
-template <bool ORTHO>
-__global__ __launch_bounds__(64) void k_dipole_iter_mf(AtomsDev at, Box bx, double lambda, const double *__restrict__ mu, int tiles_per_split,
-                                                       double *__restrict__ part) {
-	__shared__ double4 s_xyzq[kTile];
-	__shared__ double s_mu[kTile * 3];
-	__shared__ int s_fl[kTile];
-	const int lane = threadIdx.x;
-	const int i = blockIdx.x * kTile + lane;
-	const int nt = at.n_pad / kTile;
-	const int t0 = blockIdx.y * tiles_per_split, t1 = min(nt, t0 + tiles_per_split);
-	const double4 pi = at.xyzq[i];
-	double fx = 0, fy = 0, fz = 0;
-	for (int t = t0; t < t1; ++t) {
-		__syncthreads();
-		const int jg = t * kTile + lane;
-		s_xyzq[lane] = at.xyzq[jg];
-		s_fl[lane] = at.mf[jg].y;
-		s_mu[3 * lane + 0] = mu[3 * (size_t)jg + 0];
-		s_mu[3 * lane + 1] = mu[3 * (size_t)jg + 1];
-		s_mu[3 * lane + 2] = mu[3 * (size_t)jg + 2];
-		__syncthreads();
-		for (int jj = 0; jj < kTile; ++jj) {
-			const int j = t * kTile + jj;
-			if ((s_fl[jj] & (AF_PAD | AF_ZERO_ALPHA)) || j == i) continue; // mu_j == 0 for non-polarizable sites
-			const double4 pj = s_xyzq[jj];
-			double ox, oy, oz;
-			const double r = min_image<ORTHO>(bx, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, ox, oy, oz);
-			double a, b;
-			thole_ab(r, lambda, a, b);
-			const double mx = s_mu[3 * jj], my = s_mu[3 * jj + 1], mz = s_mu[3 * jj + 2];
-			const double t3 = b * (((ox * mx) + oy * my) + oz * mz);
-			fx -= a * mx - t3 * ox;
-			fy -= a * my - t3 * oy;
-			fz -= a * mz - t3 * oz;
-		}
-	}
-	double *o = part + ((size_t)blockIdx.y * at.n_pad + i) * 3;
-	o[0] = fx;
-	o[1] = fy;
-	o[2] = fz;
-}
-
-void launch_dipole_iter_mf(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, const double *mu, int n_split, double *part) {
-	const int nt = at.n_pad / kTile;
-	const int tps = (nt + n_split - 1) / n_split;
-	dim3 grid(nt, n_split), block(kTile);
-	if (bx.ortho)
-		hipLaunchKernelGGL(k_dipole_iter_mf<true>, grid, block, 0, st, at, bx, polar_damp, mu, tps, part);
-	else
-		hipLaunchKernelGGL(k_dipole_iter_mf<false>, grid, block, 0, st, at, bx, polar_damp, mu, tps, part);
-}
-
 // contract_dipoles tail :3586-3593, calc_dipole_rrms :3147-3177, are_we_done_yet :3227-3236
 __device__ __forceinline__ void dipole_update_block(const AtomsDev &at, const double *__restrict__ e_static, const double *__restrict__ part,
                                                     int n_split, const double *__restrict__ mu_old, double *__restrict__ mu_new,

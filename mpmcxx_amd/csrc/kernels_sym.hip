@@ -766,7 +766,10 @@ struct HybAcc {
 // one pair step: lane l against j = (l + s) & 63.  The LDS images of the j-tile hold every value twice (slots k and k + 64),
 // so the slot is jl = l + s with no wrap and, inside an unrolled round, a compile-time offset from one base address.
 // ROT: rotate the j-side accumulators afterwards (not after the last step).
-template <bool ORTHO, int JACC, bool FAR, bool UNI, bool ROT>
+// RECOMP (with !FAR): nothing is stored at all (solver MATRIX_FREE, the store does not fit its budget): the damped tensor of a tile pair
+// inside the damping range is rebuilt from the positions with the arithmetic of the pair sweep (thole_amatrix :2731-2757); t.x then
+// carries the pair's 0/1 mask (padded slots, the half-counted step 32 of diagonal tiles) and t.y the damping constant lambda.
+template <bool ORTHO, int JACC, bool FAR, bool UNI, bool ROT, bool RECOMP = false>
 __device__ __forceinline__ void hyb_step(const Box &bx, const HybLds &L, const int jl, const int src4, const double pix, const double piy,
                                          const double piz, const double mix, const double miy, const double miz, double2 t, const double padi,
                                          HybAcc &A) {
@@ -786,6 +789,19 @@ __device__ __forceinline__ void hyb_step(const Box &bx, const HybLds &L, const i
 		t.x = ir2 * ir;
 		if (padi >= 0.0) t.x *= padi * L.j[jl + 6 * kJ2]; // wave-uniform: only tile pairs that touch the padded last tile
 		t.y = 3.0 * t.x * ir2;
+	} else if (RECOMP) {
+		const double mask = t.x, lam = t.y;
+		const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
+		const double ir = fast_rsqrt(r2);
+		const double r = r2 * ir;
+		const double ir3 = ir * ir * ir, ir5 = ir3 * ir * ir;
+		const double lr = lam * r;
+		const double explr = exp_fast(-lr);
+		const double damp1 = fma(-explr, fma(lr, fma(0.5, lr, 1.0), 1.0), 1.0);
+		const double damp2 = fma(-explr, (lr * lr) * (lr * (1.0 / 6.0)), damp1);
+		const double live = (r2 > 0.0) ? mask * L.j[jl + 6 * kJ2] : 0.0;
+		t.x = live * (damp1 * ir3);
+		t.y = live * (3.0 * damp2 * ir5);
 	}
 	const double mjx = L.j[jl + 3 * kJ2], mjy = L.j[jl + 4 * kJ2], mjz = L.j[jl + 5 * kJ2];
 	const double dj = t.y * fma(oz, mjz, fma(oy, mjy, ox * mjx));
@@ -806,8 +822,18 @@ __device__ __forceinline__ void hyb_step(const Box &bx, const HybLds &L, const i
 template <bool ORTHO, int JACC, int PIPE, bool FAR, bool UNI>
 __device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const double pix, const double piy, const double piz, const double mix,
                                          const double miy, const double miz, const double2 *__restrict__ abt, const int s_first,
-                                         const int n_steps, const int lane, const int src4, const double padi, HybAcc &A) {
+                                         const int n_steps, const int lane, const int src4, const double padi, HybAcc &A, const double lambda = 0.0,
+                                         const double vi = 1.0, const bool diag = false) {
 	int jb = lane + s_first; // LDS slot of the round's first step
+	if (!FAR && abt == nullptr) { // matrix-free: rebuild the damped tensors (RECOMP); step 32 of a diagonal tile counts lanes 0..31 only
+		for (int k = 0; k < n_steps; ++k) {
+			const int s = s_first + k;
+			const double mask = (diag && s == 32 && lane >= 32) ? 0.0 : vi;
+			if (k != n_steps - 1) hyb_step<ORTHO, JACC, false, UNI, true, true>(bx, L, jb + k, src4, pix, piy, piz, mix, miy, miz, make_double2(mask, lambda), padi, A);
+			else hyb_step<ORTHO, JACC, false, UNI, false, true>(bx, L, jb + k, src4, pix, piy, piz, mix, miy, miz, make_double2(mask, lambda), padi, A);
+		}
+		return;
+	}
 	if (FAR) {
 		for (int kc = 0; kc < n_steps - 4; kc += 4, jb += 4) {
 #pragma unroll
@@ -850,7 +876,7 @@ __device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const d
 template <bool ORTHO, int JACC, int PIPE, int W>
 __device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
                                           const int *__restrict__ cls, const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab,
-                                          double *__restrict__ part /*[nt][n_pad][3]*/, const int tp) {
+                                          double *__restrict__ part /*[nt][n_pad][3]*/, const int tp, const double lambda = 0.0) {
 	static_assert((32 / W) % PIPE == 0, "a wave's share of a diagonal tile (32 / W steps) must be whole rounds of PIPE");
 	__shared__ double s_j[7 * kJ2];
 	__shared__ double s_g[W][3][kTile];
@@ -878,14 +904,14 @@ __device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, con
 	const double vi = (at.mf[i].y & AF_PAD) ? 0.0 : 1.0;
 	const bool has_pad = (at.n != at.n_pad) && (IJ.y == at.n_pad / kTile - 1); // only the last tile holds padding slots (I <= J)
 
-	const double2 *__restrict__ abt = ab + (size_t)tp * (kTile * kTile) + lane;
+	const double2 *__restrict__ abt = ab ? ab + (size_t)tp * (kTile * kTile) + lane : nullptr; // null: matrix-free (nothing stored)
 	HybAcc A = {0, 0, 0, 0, 0, 0};
 	const HybLds L = {s_j, &s_g[0][0][0], &s_g[0][1][0], &s_g[0][2][0]};
 	const double padi = has_pad ? vi : -1.0;
 	// 64 steps (off-diagonal, s = 0..63) or 32 steps (diagonal, s = 1..32), W equal shares of whole PIPE rounds
 	const int n_steps = (diag ? 32 : 64) / W;
 	const int s_first = (diag ? 1 : 0) + w * n_steps;
-#define MPMC_WALK(F, U, X, Y, Z) hyb_walk<ORTHO, JACC, PIPE, F, U>(bx, L, X, Y, Z, mix, miy, miz, abt, s_first, n_steps, lane, src4, padi, A)
+#define MPMC_WALK(F, U, X, Y, Z) hyb_walk<ORTHO, JACC, PIPE, F, U>(bx, L, X, Y, Z, mix, miy, miz, abt, s_first, n_steps, lane, src4, padi, A, lambda, vi, diag)
 	if (uni) {
 		const double4 sh = tp_shift[tp];
 		const double qx = pi.x - sh.x, qy = pi.y - sh.y, qz = pi.z - sh.z;
@@ -941,8 +967,8 @@ template <bool ORTHO, int JACC, int PIPE = 8, int W = 1>
 __global__ __launch_bounds__(64 * W) void k_dipole_iter_hybrid(AtomsDev at, Box bx, const double *__restrict__ mu,
                                                                 const int2 *__restrict__ tile_pairs, const int *__restrict__ cls,
                                                                 const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab,
-                                                                double *__restrict__ part) {
-	hyb_block<ORTHO, JACC, PIPE, W>(at, bx, mu, tile_pairs, cls, tp_shift, ab, part, blockIdx.x);
+                                                                double *__restrict__ part, double lambda) {
+	hyb_block<ORTHO, JACC, PIPE, W>(at, bx, mu, tile_pairs, cls, tp_shift, ab, part, blockIdx.x, lambda);
 }
 
 // the same contraction for B systems in ONE launch (blockIdx.y = system): the images of a path-integral ensemble run their Jacobi
@@ -966,10 +992,10 @@ void launch_dipole_iter_hybrid_batched(hipStream_t st, int jacc, const SolveBead
 }
 
 void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                               const int *cls, const double4 *tp_shift, int n_tile_pairs, const double2 *ab, double *part) {
+                               const int *cls, const double4 *tp_shift, int n_tile_pairs, const double2 *ab, double *part, double polar_damp) {
 	dim3 grid(n_tile_pairs);
 #define MPMC_LAUNCH_HYB(O, J, P, W) \
-	hipLaunchKernelGGL((k_dipole_iter_hybrid<O, J, P, W>), grid, dim3(kTile * W), 0, st, at, bx, mu, tile_pairs, cls, tp_shift, ab, part)
+	hipLaunchKernelGGL((k_dipole_iter_hybrid<O, J, P, W>), grid, dim3(kTile * W), 0, st, at, bx, mu, tile_pairs, cls, tp_shift, ab, part, polar_damp)
 	if (bx.ortho) {
 		if (jacc == 1) MPMC_LAUNCH_HYB(true, 1, 8, 1);
 		else MPMC_LAUNCH_HYB(true, 0, 8, 1);
