@@ -66,9 +66,10 @@ struct mpmc_ctx {
 	int *d_cls = nullptr;           // tile-pair classes (CLS_*), recomputed every evaluation
 	int *d_lists = nullptr;         // [2 ntp] work lists of the two Jacobi kernels + [2] their lengths (at the end)
 	double *d_tile_bounds = nullptr; // [n_tiles][12]: wrapped fractional lo/hi, raw Cartesian lo/hi
-	double4 *d_tp_shift = nullptr;   // [n_tile_pairs] lattice vector of the common image index (CLS_UNIFORM_IMG)
+	double4 *d_tp_shift = nullptr;   // [n_tile_pairs] lattice vector components of the common image index (CLS_UNIFORM_X/Y/Z)
 	std::vector<double4> h_xyzq;     // host mirror of d_xyzq (slot order), for bulk position updates
 	std::vector<double> h_pos_sorted; // positions at the time of the last spatial sort
+	double sort_origin_f[3] = {0, 0, 0}; // fractional coordinate at which the spatial sort cuts the periodic wrap
 	bool no_uniform = false;         // MPMC_NO_UNI=1
 	// lockstep solve of several systems (mpmc_pi_potential_local): enqueue() stops before the dipole iterations when asked to and
 	// possible; the batch driver then runs the iterations of all deferred systems in shared launches on one stream
@@ -501,11 +502,22 @@ static void compute_spatial_order(mpmc_ctx *c) {
 	if (c->opts_set && c->opts.polar_gs && c->opts.polarization && !c->opts.rd_only) enable = false; // the sweep order IS the atom order (:3569)
 	if (const char *e = std::getenv("MPMC_NO_SORT")) if (e[0] == '1') enable = false;
 	if (enable) {
+		// fractional coordinates counted from the smallest one in each dimension: with all atoms inside one period (the usual case) the
+		// periodic wrap is cut at the edge of the occupied range, so tiles are compact in the RAW coordinates too -- which is what lets
+		// whole tile pairs share one periodic image index (k_classify)
 		std::vector<double> f(3 * (size_t)n);
+		double org[3] = {1e300, 1e300, 1e300};
 		for (int i = 0; i < n; i++)
 			for (int p = 0; p < 3; p++) {
 				double v = 0;
 				for (int q = 0; q < 3; q++) v += c->box.r[3 * q + p] * c->h_pos[3 * i + q];
+				f[3 * (size_t)i + p] = v;
+				if (v < org[p]) org[p] = v;
+			}
+		for (int p = 0; p < 3; p++) c->sort_origin_f[p] = org[p];
+		for (int i = 0; i < n; i++)
+			for (int p = 0; p < 3; p++) {
+				double v = f[3 * (size_t)i + p] - org[p];
 				v -= std::floor(v);
 				f[3 * (size_t)i + p] = v;
 			}
@@ -983,7 +995,7 @@ static int enqueue(mpmc_ctx *c, unsigned mask) {
 		// tile-pair classes from this configuration's tile bounding boxes (orthorhombic cells; all "near" otherwise)
 		if (c->no_classes) HIP_TRY(c, hipMemsetAsync(c->d_cls, 0, (size_t)c->n_tile_pairs * sizeof(int), st));
 		else launch_tile_classes(st, at, c->box, c->d_tile_pairs, c->n_tile_pairs, (o.polarization && !o.rd_only) ? o.polar_damp : 0.0,
-		                         c->d_tile_bounds, c->d_cls, c->no_uniform ? nullptr : c->d_tp_shift);
+		                         c->d_tile_bounds, c->d_cls, c->no_uniform ? nullptr : c->d_tp_shift, c->sort_origin_f);
 		FusedParams fp;
 		fp.ewald_alpha = c->ewald_alpha;
 		fp.polar_ewald_alpha = c->polar_ewald_alpha;

@@ -35,7 +35,9 @@ enum : int { C_LJ_IN = 0, C_ES_IN, C_INTRA, C_RDX, C_ESX, C_FROZEN, C_COUNT = 8 
 enum : int {
 	CLS_BEYOND_CUTOFF = 1, // > cutoff: no pair of the tile pair passes any cutoff predicate
 	CLS_THOLE_FAR = 2,     // lambda*r > 40 for every pair: exponential damping is below 1e-13, T is the bare dipole tensor
-	CLS_UNIFORM_IMG = 4    // one periodic image index serves all 4096 pairs (tp_shift holds the lattice vector B img)
+	CLS_UNIFORM_X = 4,     // per dimension (x, y, z = 4, 8, 16): one periodic image index serves all 4096 pairs of the tile pair in
+	CLS_UNIFORM_Y = 8,     // that dimension (wrapped coordinates); tp_shift holds the lattice vector component B img
+	CLS_UNIFORM_Z = 16
 };
 constexpr double kTholeFarX = 40.0; // exp(-40)*(40^3/6) = 4.5e-14
 
@@ -101,7 +103,8 @@ void launch_static_counts(hipStream_t st, const AtomsDev &at, const int2 *tile_p
 void launch_intra_terms(hipStream_t st, const AtomsDev &at, const int *slot_of, double ewald_alpha, double *scal);
 // per-tile bounding boxes (wrapped fractional coordinates) and tile-pair classes (CLS_*)
 void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, const int2 *tile_pairs, int n_tile_pairs, double polar_damp,
-                         double *tile_bounds /*[nt][12]*/, int *cls, double4 *tp_shift /*[ntp], may be null*/);
+                         double *tile_bounds /*[nt][12]*/, int *cls, double4 *tp_shift /*[ntp], may be null*/,
+                         const double origin_f[3] /*fractional origin of the spatial sort: where the periodic wrap is cut*/);
 // work lists of the two Jacobi kernels from the class array: lists[0..ntp) stored tile pairs, lists[ntp..2ntp) far ones
 void launch_build_lists(hipStream_t st, const int *cls, int n_tile_pairs, int *lists /*[2 ntp]*/, int *counts /*[2]*/);
 // one Jacobi contraction = these two launches (each partial slot is written by exactly one of them): part[nt][n_pad][3]

@@ -408,7 +408,7 @@ void launch_intra_terms(hipStream_t st, const AtomsDev &at, const int *slot_of, 
 // ------------------------------------------------------------------------------------------------------
 // tile bounding boxes in wrapped fractional coordinates and tile-pair classes (orthorhombic cells only)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_tile_bounds(AtomsDev at, Box bx, double *__restrict__ tb /*[nt][12]*/) {
+__global__ __launch_bounds__(64) void k_tile_bounds(AtomsDev at, Box bx, double3 origin_f, double *__restrict__ tb /*[nt][12]*/) {
 	const int lane = threadIdx.x;
 	const int k = blockIdx.x * kTile + lane;
 	const double4 p = at.xyzq[k];
@@ -416,7 +416,8 @@ __global__ __launch_bounds__(64) void k_tile_bounds(AtomsDev at, Box bx, double 
 	double lo[6], hi[6]; // 0..2 wrapped fractional coordinates, 3..5 raw Cartesian coordinates
 	const double pos[3] = {p.x, p.y, p.z};
 	for (int d = 0; d < 3; ++d) {
-		double f = bx.r[4 * d] * pos[d]; // diagonal cell: fractional coordinate
+		const double of[3] = {origin_f.x, origin_f.y, origin_f.z};
+		double f = bx.r[4 * d] * pos[d] - of[d]; // diagonal cell: fractional coordinate, counted from the origin of the spatial sort
 		f -= floor(f);
 		lo[d] = real ? f : 2.0;
 		hi[d] = real ? f : -1.0;
@@ -459,26 +460,27 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 		if (thr_far2 > 0.0 && d2 > thr_far2) c |= CLS_THOLE_FAR;
 	}
 	if (tp_shift) {
-		// Is the periodic image index rint(R (x_i - x_j)) the same for every atom pair of the tile pair?  x_i - x_j, the
+		// Per dimension: is the periodic image index rint(R (x_i - x_j)) the same for every atom pair of the tile pair?  x_i - x_j, the
 		// product and rint are all monotone in their argument (also after rounding), so it suffices that the two extreme
-		// displacements of the RAW coordinate ranges round to the same integer.  Then d_img = (x_i - B img) - x_j.
+		// displacements of the RAW coordinate ranges round to the same integer -- the very operations the pair would perform, so
+		// even a pair sitting exactly on the half-box tie (coordinates read from 6-decimal files do) gets the reference's image.
+		// Then d_img = (x_i - B img) - x_j in that dimension.
 		double sh[3];
-		bool uni = true;
 		for (int d = 0; d < 3; ++d) {
 			const double ilo = tb[12 * (size_t)IJ.x + 6 + d], ihi = tb[12 * (size_t)IJ.x + 9 + d];
 			const double jlo = tb[12 * (size_t)IJ.y + 6 + d], jhi = tb[12 * (size_t)IJ.y + 9 + d];
 			const double m0 = rint(bx.r[4 * d] * (ilo - jhi)), m1 = rint(bx.r[4 * d] * (ihi - jlo));
-			uni = uni && (m0 == m1) && (ihi >= ilo) && (jhi >= jlo);
+			const bool uni = (m0 == m1) && (ihi >= ilo) && (jhi >= jlo);
+			if (uni) c |= (CLS_UNIFORM_X << d);
 			sh[d] = bx.b[4 * d] * m0;
 		}
-		if (uni) c |= CLS_UNIFORM_IMG;
 		tp_shift[t] = make_double4(sh[0], sh[1], sh[2], 0.0);
 	}
 	cls[t] = c;
 }
 
 void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, const int2 *tile_pairs, int n_tile_pairs, double polar_damp,
-                         double *tile_bounds, int *cls, double4 *tp_shift) {
+                         double *tile_bounds, int *cls, double4 *tp_shift, const double origin_f[3]) {
 	if (!bx.ortho) {
 		(void)hipMemsetAsync(cls, 0, (size_t)n_tile_pairs * sizeof(int), st);
 		return;
@@ -490,7 +492,7 @@ void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, cons
 		const double rf = kTholeFarX / polar_damp;
 		thr_far2 = rf * rf * (1.0 + 1e-9);
 	}
-	hipLaunchKernelGGL(k_tile_bounds, dim3(at.n_pad / kTile), dim3(kTile), 0, st, at, bx, tile_bounds);
+	hipLaunchKernelGGL(k_tile_bounds, dim3(at.n_pad / kTile), dim3(kTile), 0, st, at, bx, make_double3(origin_f[0], origin_f[1], origin_f[2]), tile_bounds);
 	hipLaunchKernelGGL(k_classify, dim3((n_tile_pairs + 255) / 256), dim3(256), 0, st, tile_bounds, tile_pairs, n_tile_pairs, bx, thr_cut2,
 	                   thr_far2, cls, tp_shift);
 }
@@ -751,9 +753,10 @@ void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const 
 //     1  the same through ds_bpermute_b32 (fallback when the DPP self-test fails)
 //   (ds_add_f64 into an LDS image of the j-atoms was measured too: 0.113 ms against 0.105 ms per launch, dropped.)
 // ------------------------------------------------------------------------------------------------------
-// FAR / UNI are wave-uniform properties of the tile pair: the walk is instantiated for each combination so that the
-// inner loop carries no branch.  UNI: the periodic image index is the same for all 4096 atom pairs (k_classify), the
-// caller has already moved the i-atom by that lattice vector and the displacement is one subtraction per component.
+// FAR and the uniform-image mask UM (3 bits, one per dimension) are wave-uniform properties of the tile pair: the walk is instantiated
+// for each combination so that the inner loop carries no branch.  A set UM bit: in that dimension the periodic image index is the same
+// for all 4096 atom pairs (k_classify), the caller has already moved the i-atom by that lattice vector component and the displacement
+// is one subtraction.  At the benchmark box 1.9 of the 3 dimensions are uniform on average (all three for 25 % of the tile pairs).
 struct HybLds {
 	const double *j; // ONE array [7][2 * kTile]: x, y, z, mu_x, mu_y, mu_z, valid -- one base register, compile-time offsets
 	double *gx, *gy, *gz;
@@ -769,16 +772,19 @@ struct HybAcc {
 // RECOMP (with !FAR): nothing is stored at all (solver MATRIX_FREE, the store does not fit its budget): the damped tensor of a tile pair
 // inside the damping range is rebuilt from the positions with the arithmetic of the pair sweep (thole_amatrix :2731-2757); t.x then
 // carries the pair's 0/1 mask (padded slots, the half-counted step 32 of diagonal tiles) and t.y the damping constant lambda.
-template <bool ORTHO, int JACC, bool FAR, bool UNI, bool ROT, bool RECOMP = false>
+template <bool ORTHO, int JACC, bool FAR, int UM, bool ROT, bool RECOMP = false>
 __device__ __forceinline__ void hyb_step(const Box &bx, const HybLds &L, const int jl, const int src4, const double pix, const double piy,
                                          const double piz, const double mix, const double miy, const double miz, double2 t, const double padi,
                                          HybAcc &A) {
 	double ox, oy, oz;
 	const double xj = L.j[jl + 0 * kJ2], yj = L.j[jl + 1 * kJ2], zj = L.j[jl + 2 * kJ2];
-	if (UNI) {
+	if (ORTHO) { // per dimension: one subtraction when the image index is known for the whole tile pair (UM bit), else sub-mul-rint-fma
 		ox = pix - xj;
 		oy = piy - yj;
 		oz = piz - zj;
+		if (!(UM & 1)) ox = fma(-bx.b[0], rint(bx.r[0] * ox), ox);
+		if (!(UM & 2)) oy = fma(-bx.b[4], rint(bx.r[4] * oy), oy);
+		if (!(UM & 4)) oz = fma(-bx.b[8], rint(bx.r[8] * oz), oz);
 	} else {
 		image_vec<ORTHO>(bx, pix - xj, piy - yj, piz - zj, ox, oy, oz);
 	}
@@ -819,7 +825,7 @@ __device__ __forceinline__ void hyb_step(const Box &bx, const HybLds &L, const i
 	}
 }
 
-template <bool ORTHO, int JACC, int PIPE, bool FAR, bool UNI>
+template <bool ORTHO, int JACC, int PIPE, bool FAR, int UM>
 __device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const double pix, const double piy, const double piz, const double mix,
                                          const double miy, const double miz, const double2 *__restrict__ abt, const int s_first,
                                          const int n_steps, const int lane, const int src4, const double padi, HybAcc &A, const double lambda = 0.0,
@@ -829,19 +835,19 @@ __device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const d
 		for (int k = 0; k < n_steps; ++k) {
 			const int s = s_first + k;
 			const double mask = (diag && s == 32 && lane >= 32) ? 0.0 : vi;
-			if (k != n_steps - 1) hyb_step<ORTHO, JACC, false, UNI, true, true>(bx, L, jb + k, src4, pix, piy, piz, mix, miy, miz, make_double2(mask, lambda), padi, A);
-			else hyb_step<ORTHO, JACC, false, UNI, false, true>(bx, L, jb + k, src4, pix, piy, piz, mix, miy, miz, make_double2(mask, lambda), padi, A);
+			if (k != n_steps - 1) hyb_step<ORTHO, JACC, false, UM, true, true>(bx, L, jb + k, src4, pix, piy, piz, mix, miy, miz, make_double2(mask, lambda), padi, A);
+			else hyb_step<ORTHO, JACC, false, UM, false, true>(bx, L, jb + k, src4, pix, piy, piz, mix, miy, miz, make_double2(mask, lambda), padi, A);
 		}
 		return;
 	}
 	if (FAR) {
 		for (int kc = 0; kc < n_steps - 4; kc += 4, jb += 4) {
 #pragma unroll
-			for (int u = 0; u < 4; ++u) hyb_step<ORTHO, JACC, true, UNI, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
+			for (int u = 0; u < 4; ++u) hyb_step<ORTHO, JACC, true, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
 		}
 #pragma unroll
-		for (int u = 0; u < 3; ++u) hyb_step<ORTHO, JACC, true, UNI, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
-		hyb_step<ORTHO, JACC, true, UNI, false>(bx, L, jb + 3, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
+		for (int u = 0; u < 3; ++u) hyb_step<ORTHO, JACC, true, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
+		hyb_step<ORTHO, JACC, true, UM, false>(bx, L, jb + 3, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
 		return;
 	}
 	// rolling prefetch ring: the (a,b) of step k + PIPE is requested as soon as the registers of step k are consumed, so PIPE
@@ -858,14 +864,14 @@ __device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const d
 		for (int u = 0; u < PIPE; ++u) {
 			const double2 t = buf[u];
 			buf[u] = ld_stream<true>(pn + u * kTile);
-			hyb_step<ORTHO, JACC, false, UNI, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, t, padi, A);
+			hyb_step<ORTHO, JACC, false, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, t, padi, A);
 			__builtin_amdgcn_sched_barrier(0); // keep the steps in program order (no hoisting of all LDS reads to the top)
 		}
 	}
 #pragma unroll
 	for (int u = 0; u < PIPE; ++u) {
-		if (u != PIPE - 1) hyb_step<ORTHO, JACC, false, UNI, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
-		else hyb_step<ORTHO, JACC, false, UNI, false>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
+		if (u != PIPE - 1) hyb_step<ORTHO, JACC, false, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
+		else hyb_step<ORTHO, JACC, false, UM, false>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
 		__builtin_amdgcn_sched_barrier(0);
 	}
 }
@@ -889,6 +895,8 @@ __device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, con
 	const int src4 = ((lane + 1) & 63) * 4;
 
 	const double4 pi = at.xyzq[i];
+	const int c = cls[tp];
+	const int um = (ORTHO && tp_shift) ? ((c / CLS_UNIFORM_X) & 7) : 0; // dimensions with one image index for the whole tile pair
 	const double mix = mu[3 * (size_t)i], miy = mu[3 * (size_t)i + 1], miz = mu[3 * (size_t)i + 2];
 	if (w == 0) {
 		const double4 pj = at.xyzq[j0 + lane];
@@ -898,9 +906,7 @@ __device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, con
 		for (int c = 0; c < 7; ++c) s_j[c * kJ2 + lane] = s_j[c * kJ2 + lane + kTile] = vals[c]; // twice: slot l + s never wraps (hyb_step)
 	}
 	__syncthreads();
-	const int c = cls[tp];
 	const bool far = (c & CLS_THOLE_FAR) != 0; // wave-uniform: beyond the damping range, nothing was stored
-	const bool uni = ORTHO && tp_shift && (c & CLS_UNIFORM_IMG) != 0;
 	const double vi = (at.mf[i].y & AF_PAD) ? 0.0 : 1.0;
 	const bool has_pad = (at.n != at.n_pad) && (IJ.y == at.n_pad / kTile - 1); // only the last tile holds padding slots (I <= J)
 
@@ -911,16 +917,32 @@ __device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, con
 	// 64 steps (off-diagonal, s = 0..63) or 32 steps (diagonal, s = 1..32), W equal shares of whole PIPE rounds
 	const int n_steps = (diag ? 32 : 64) / W;
 	const int s_first = (diag ? 1 : 0) + w * n_steps;
-#define MPMC_WALK(F, U, X, Y, Z) hyb_walk<ORTHO, JACC, PIPE, F, U>(bx, L, X, Y, Z, mix, miy, miz, abt, s_first, n_steps, lane, src4, padi, A, lambda, vi, diag)
-	if (uni) {
-		const double4 sh = tp_shift[tp];
-		const double qx = pi.x - sh.x, qy = pi.y - sh.y, qz = pi.z - sh.z;
-		if (far) MPMC_WALK(true, true, qx, qy, qz);
-		else MPMC_WALK(false, true, qx, qy, qz);
-	} else {
-		if (far) MPMC_WALK(true, false, pi.x, pi.y, pi.z);
-		else MPMC_WALK(false, false, pi.x, pi.y, pi.z);
+#define MPMC_WALK(F, U) hyb_walk<ORTHO, JACC, PIPE, F, U>(bx, L, qx, qy, qz, mix, miy, miz, abt, s_first, n_steps, lane, src4, padi, A, lambda, vi, diag)
+#define MPMC_WALK_UM(F)                                                       \
+	switch (um) {                                                             \
+	case 1: MPMC_WALK(F, 1); break;                                           \
+	case 2: MPMC_WALK(F, 2); break;                                           \
+	case 3: MPMC_WALK(F, 3); break;                                           \
+	case 4: MPMC_WALK(F, 4); break;                                           \
+	case 5: MPMC_WALK(F, 5); break;                                           \
+	case 6: MPMC_WALK(F, 6); break;                                           \
+	case 7: MPMC_WALK(F, 7); break;                                           \
+	default: MPMC_WALK(F, 0); break;                                          \
 	}
+	double qx = pi.x, qy = pi.y, qz = pi.z;
+	if (um) { // the i-atom moves by the common lattice vector of the uniform dimensions, once
+		const double4 sh = tp_shift[tp];
+		if (um & 1) qx -= sh.x;
+		if (um & 2) qy -= sh.y;
+		if (um & 4) qz -= sh.z;
+	}
+	if (ORTHO) {
+		if (far) { MPMC_WALK_UM(true) } else { MPMC_WALK_UM(false) }
+	} else {
+		if (far) MPMC_WALK(true, 0);
+		else MPMC_WALK(false, 0);
+	}
+#undef MPMC_WALK_UM
 #undef MPMC_WALK
 	{ // park the rotated accumulators at their atoms' LDS slots
 		const int jl_last = (lane + s_first + n_steps - 1) & 63;
