@@ -794,7 +794,7 @@ __device__ __forceinline__ void hyb_step(const Box &bx, const HybLds &L, const i
 		const double ir2 = ir * ir;
 		t.x = ir2 * ir;
 		if (padi >= 0.0) t.x *= padi * L.j[jl + 6 * kJ2]; // wave-uniform: only tile pairs that touch the padded last tile
-		t.y = 3.0 * t.x * ir2;
+		t.y = t.x * (3.0 * ir2);
 	} else if (RECOMP) {
 		const double mask = t.x, lam = t.y;
 		const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
@@ -862,9 +862,8 @@ __device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const d
 		pn += PIPE * kTile;
 #pragma unroll
 		for (int u = 0; u < PIPE; ++u) {
-			const double2 t = buf[u];
-			buf[u] = ld_stream<true>(pn + u * kTile);
-			hyb_step<ORTHO, JACC, false, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, t, padi, A);
+			hyb_step<ORTHO, JACC, false, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
+			buf[u] = ld_stream<true>(pn + u * kTile); // refill the slot just consumed: in place, no register copies
 			__builtin_amdgcn_sched_barrier(0); // keep the steps in program order (no hoisting of all LDS reads to the top)
 		}
 	}
