@@ -15,11 +15,12 @@ run_case() { # dir input P job
 	(cd "$d" && "$BIN" -P "$3" "$2" >stock.log 2>&1)
 	grep -v '^#' "$d/$4.energy.dat" >/dev/null
 	cp "$d/$4.energy.dat" "$G/$1/golden_energy.dat"
-	for f in "$d/$4".final-*.pqr; do cp "$f" "$G/$1/golden_${f##*/$4.}"; done
-	for k in dipole field; do [ -s "$d/$4.$k.dat" ] && cp "$d/$4.$k.dat" "$G/$1/golden_$k.dat"; done
+	if [ "${5:-finals}" = finals ]; then for f in "$d/$4".final-*.pqr; do cp "$f" "$G/$1/golden_${f##*/$4.}"; done; fi
+	if [ "${5:-finals}" = finals ]; then for k in dipole field; do [ -s "$d/$4.$k.dat" ] && cp "$d/$4.$k.dat" "$G/$1/golden_$k.dat"; done; fi
 	grep -E '^OUTPUT: (AR =|total energy|kinetic energy|polarization energy)' "$d/stock.log" | tail -12 >"$G/$1/golden_final_averages.txt"
 	echo "$1: $(grep -vc '^#' "$G/$1/golden_energy.dat") energy rows"
 	rm -rf "$d"
 }
 run_case pi001 equilibrate.in 8 ArAr2K
 run_case pi_ion27 input.in 4 ion27
+run_case pi_ion1000 input.in 4 ion1000 rows-only   # 1000 polarizable ions: energy.dat rows and averages only (size)

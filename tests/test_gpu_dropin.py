@@ -78,3 +78,11 @@ def test_pi_polarizable_box_runs_on_the_hip_path(tmp_path, mode):
         assert len(ours) == len(ref)
         for x, y in zip(ours, ref):
             assert abs(float(x) - float(y)) <= 1e-6 * max(abs(float(y)), 1.0) + 2e-6, (name, x, y)
+
+
+def test_pi_1000_ion_box_stock_driver_checks_every_call(tmp_path):
+    """1000 polarizable ions, P = 4, 12 PI-NVT steps of the STOCK driver with MPMC_WRAP_MODE=both: every energy() call is evaluated by the
+    reference as well and the adapter aborts on any component differing by more than 1e-9."""
+    p = run_case(tmp_path, "pi_ion1000", "input.in", 4, "both")
+    compare_energy_dat(os.path.join(tmp_path, "ion1000.energy.dat"), os.path.join(util.GOLDEN, "pi_ion1000", "golden_energy.dat"), 1e-9)
+    assert "MISMATCH" not in p.stderr

@@ -21,6 +21,7 @@ CASES = {
     # name: (input file, P, job name, expected acceptance: (AR, displace, bead))
     "pi001": ("equilibrate.in", 8, "ArAr2K"),
     "pi_ion27": ("input.in", 4, "ion27"),
+    "pi_ion1000": ("input.in", 4, "ion1000"),  # 1000 polarizable ions, 12 steps: rows and acceptance rates only (no final geometries kept)
 }
 LIBDIR = os.path.join(util.ROOT, "mpmcxx_amd")
 ORACLE = os.path.join(util.ROOT, "oracle")
@@ -53,6 +54,8 @@ def pimc_check(tmp_path_factory):
 @pytest.mark.parametrize("trial", [False, True], ids=["full", "trial_moves"])
 @pytest.mark.parametrize("name", list(CASES))
 def test_driver_with_oracle_evaluator_reproduces_the_stock_binary(pimc_check, name, trial, tmp_path):
+    if name == "pi_ion1000" and trial:
+        pytest.skip("the 1000-atom case runs once on the CPU (15 s of oracle evaluations)")
     inp, P, job = CASES[name]
     out = subprocess.run([pimc_check, os.path.join(util.GOLDEN, name, inp), str(P), str(tmp_path)] + (["--trial"] if trial else []),
                          stdout=subprocess.PIPE, text=True, check=True)
@@ -64,7 +67,7 @@ def test_driver_with_oracle_evaluator_reproduces_the_stock_binary(pimc_check, na
     nd, nb = r["accept_displace"] + r["reject_displace"], r["accept_bead"] + r["reject_bead"]
     assert f"{(r['accept_displace'] / nd if nd else 0.0):.5f}" == f"{ar_d:.5f}"
     assert f"{(r['accept_bead'] / nb if nb else 0.0):.5f}" == f"{ar_b:.5f}"
-    for k in range(P):
+    for k in range(P if os.path.exists(os.path.join(util.GOLDEN, name, "golden_final-0000.pqr")) else 0):
         a = pqr.read_pqr(os.path.join(tmp_path, f"final-{k:04d}.pqr"))["pos"]
         b = pqr.read_pqr(os.path.join(util.GOLDEN, name, f"golden_final-{k:04d}.pqr"))["pos"]
         assert np.abs(a - b).max() <= 1.0e-6  # both files carry 6 decimals
@@ -116,7 +119,7 @@ def test_pimc_on_the_hip_path_reproduces_the_stock_binary(pimc_nvt, name, trial,
             assert abs(float(x) - float(y)) <= 1e-9 * max(abs(float(y)), 1.0) + 1.1e-6, (a, b)  # 6 printed decimals
     ar, ar_d, ar_b = golden_ar(name)
     assert f"{r['AR']:.5f}" == f"{ar:.5f}" and f"{r['AR_displace']:.5f}" == f"{ar_d:.5f}" and f"{r['AR_bead']:.5f}" == f"{ar_b:.5f}"
-    for k in range(P):
+    for k in range(P if os.path.exists(os.path.join(util.GOLDEN, name, "golden_final-0000.pqr")) else 0):
         a = pqr.read_pqr(os.path.join(tmp_path, f"{job}.final-{k:04d}.pqr"))["pos"]
         b = pqr.read_pqr(os.path.join(util.GOLDEN, name, f"golden_final-{k:04d}.pqr"))["pos"]
         assert np.abs(a - b).max() <= 1.0e-6
