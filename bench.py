@@ -348,6 +348,14 @@ def main():
                     "as two kernels on one stream (MPMC_JACOBI=split MPMC_ONE_STREAM=1)")
             roof["isolated"] = {k: roofline_of(k, iso[k], lab2, hybrid=False) for k in ("dipole_iter", "dipole_far", "pair") if iso.get(k, {}).get("launches")}
             roof["isolated_kernel_ms"] = {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in iso.items() if tv["launches"]}
+            # the same contraction with nothing else on the GPU (its two halves as separate launches on one stream): what the kernel
+            # reaches when its duration is not stretched by other beads' kernels
+            it_ms = sum(iso[k]["ms"] / max(iso[k]["launches"], 1) for k in ("dipole_iter", "dipole_far") if iso.get(k, {}).get("launches"))
+            if it_ms > 0:
+                fl = 33.0 * n_pairs_stored + 49.0 * n_pairs_far
+                roof["alone_on_the_gpu"] = {"ms_per_contraction": it_ms, "achieved_tflops": fl / (it_ms * 1e-3) / 1e12,
+                                            "frac": fl / (it_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                            "note": "k_dipole_iter_stream + k_dipole_iter_far back to back; the single-launch kernel alone takes ~25 % less (tools/kernel_ab.py)"}
         cpu = cpu_baseline(args.cpu_baseline, {**atoms, "pos": bead_positions(atoms["pos"], 0)}, basis, opts, workdir) if world == 1 else None
         out = {
             "metric": "energy-evals/sec (10k-atom LJ+Ewald+polar box); 1/2/4/8-GPU scaling",
