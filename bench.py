@@ -14,8 +14,8 @@ value = (P * steps) / wall  [energy evaluations / s, whole job], inputs resident
 Extra objects on the JSON line:
   roofline     -- dominant kernel (the Thole dipole-iteration kernel, one launch per Jacobi iteration), timed with
                   HIP events on the stream it is launched on (mpmc_set_profiling / mpmc_get_timings).
-  cpu_baseline -- the CPU oracle (kind "port", 1 core) or the reference's own object code (kind "reference",
-                  --cpu-baseline reference) timed on this host on ONE evaluation of the same 10k box.
+  cpu_baseline -- ONE evaluation of the same 10k box on one core of this host: by the reference's own object code (kind "reference",
+                  oracle/_ref/ref_harness, the default wherever that binary was built) or by the C port of the oracle (kind "port").
 """
 from __future__ import annotations
 
@@ -62,6 +62,8 @@ def bead_positions(pos: np.ndarray, bead: int) -> np.ndarray:
 def cpu_baseline(kind: str, atoms, basis, opts, workdir: str):
     if kind == "none":
         return None
+    if kind == "auto":
+        kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_harness")) else "port"
     n = atoms["pos"].shape[0]
     if kind == "reference":
         import subprocess
@@ -103,7 +105,8 @@ def main():
     ap.add_argument("--solver", default="auto")
     ap.add_argument("--concurrency", choices=["async", "serial"], default="async",
                     help="async: all local beads enqueued on their own streams before the first wait; serial: one bead at a time")
-    ap.add_argument("--cpu-baseline", choices=["port", "reference", "none"], default="port")
+    ap.add_argument("--cpu-baseline", choices=["auto", "port", "reference", "none"], default="auto",
+                    help="auto: the reference's own object code (oracle/_ref/ref_harness, ~25 s) where it was built, else the C port of the oracle")
     ap.add_argument("--combine", choices=["gather", "reduce"], default="gather")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: leave the per-kernel HIP events off in the timed region (the roofline entry is then empty)")
