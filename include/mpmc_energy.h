@@ -155,6 +155,8 @@ const char *mpmc_last_error(const mpmc_ctx *ctx); /* ctx may be NULL: last creat
 int mpmc_pbc_compute(const double basis[9], double reciprocal[9], double *volume, double *cutoff);
 
 /* ---- context lifetime (one per System; replaces the per-System pair lists of src/System.Pairs.cpp:21) ---- */
+/*      max_atoms is a capacity hint: mpmc_set_atoms with more atoms (insertions in the uVT / Gibbs ensembles) rebuilds the device
+ *      buffers behind the same handle with 25 % headroom. */
 int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out);
 int mpmc_ctx_destroy(mpmc_ctx *ctx);
 

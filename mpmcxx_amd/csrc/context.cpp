@@ -613,10 +613,38 @@ static int upload_atoms(mpmc_ctx *c) {
 	return MPMC_OK;
 }
 
+// A context that has to hold more atoms than it was created for is rebuilt in place: a fresh context of the larger capacity takes
+// over the caller's handle (same device, box, options, profiling state), the old device buffers are released.  Everything sized by
+// the capacity is allocated on first use, so nothing else has to know.
+static int grow_capacity(mpmc_ctx *c, int n) {
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream2);
+	(void)hipStreamSynchronize(c->stream);
+	mpmc_ctx *f = nullptr;
+	const int cap = n + n / 4 + kTile;
+	int rc = mpmc_ctx_create(c->device, cap, &f);
+	if (rc != MPMC_OK) return fail(c, rc, "mpmc_set_atoms: cannot grow the context to " + std::to_string(cap) + " atoms: " + g_create_error);
+	if (c->box_set) rc = mpmc_set_box(f, c->box.b, c->box.r, c->box.volume, c->box.cutoff);
+	if (rc == MPMC_OK && c->opts_set) rc = mpmc_set_options(f, &c->opts);
+	if (rc != MPMC_OK) {
+		c->err = "mpmc_set_atoms: growing the context failed: " + f->err;
+		mpmc_ctx_destroy(f);
+		return rc;
+	}
+	f->prof = c->prof;
+	f->tim = c->tim;
+	std::swap(*c, *f);
+	mpmc_ctx_destroy(f); // now owns the old, smaller buffers
+	return MPMC_OK;
+}
+
 extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const double *charge, const double *polarizability, const double *epsilon,
                               const double *sigma, const int32_t *mol_id, const int32_t *frozen, const int32_t *has_disp, const double *mass) {
 	if (!c || n <= 0 || !pos || !charge || !polarizability || !epsilon || !sigma || !mol_id || !frozen) return MPMC_ERR_ARG;
-	if (n > c->max_atoms) return fail(c, MPMC_ERR_ARG, "mpmc_set_atoms: n exceeds max_atoms of this context");
+	if (n > c->max_atoms) { // insertions (uVT / Gibbs callers) outgrew the capacity hint given at creation
+		const int rc_grow = grow_capacity(c, n);
+		if (rc_grow != MPMC_OK) return rc_grow;
+	}
 	for (int i = 0; i < n; i++) {
 		if (!std::isfinite(pos[3 * i]) || !std::isfinite(pos[3 * i + 1]) || !std::isfinite(pos[3 * i + 2]))
 			return fail(c, MPMC_ERR_INVALID_DATUM, "mpmc_set_atoms: non-finite position");
@@ -624,9 +652,6 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 			return fail(c, MPMC_ERR_INVALID_DATUM, "mpmc_set_atoms: epsilon < 0 or non-finite atom parameter");
 	}
 	{ // molecules are contiguous runs of the atom list (reference System.cpp:672): an id may not reappear later
-		std::vector<int32_t> seen;
-		seen.reserve(64);
-		std::vector<int32_t> ids(mol_id, mol_id + n);
 		std::vector<int32_t> firsts;
 		for (int i = 0; i < n; i++)
 			if (i == 0 || mol_id[i] != mol_id[i - 1]) firsts.push_back(mol_id[i]);

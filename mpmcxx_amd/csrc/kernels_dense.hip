@@ -52,7 +52,6 @@ __global__ __launch_bounds__(64) void k_dense_matvec(const double *__restrict__ 
 	const int kk = lane >> 4, nn = lane & 15;
 	v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 	const double *col = a + n0 + nn;
-#pragma unroll 4
 	for (int k0 = k_begin; k0 < k_end; k0 += 4) {
 		const int k = k0 + kk;
 		const double xa = x[k];                                       // A operand: A[m][kk] = x[k0 + kk] for every m

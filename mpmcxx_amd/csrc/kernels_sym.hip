@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 			const double dx = pi.x - s_x[jl], dy = pi.y - s_y[jl], dz = pi.z - s_z[jl];
 			double ox, oy, oz;
 			const double ri2 = min_image_sq<ORTHO>(bx, dx, dy, dz, ox, oy, oz);
-			const double ir = fast_rsqrt(ri2); // 1/rimg   (inf/NaN when ri2 == 0: coincident atoms => non-finite energy, as in the reference)
+			const double ir = fast_rsqrt_1(ri2); // 1/rimg to ~2e-14 (inf/NaN when ri2 == 0: coincident atoms => non-finite energy, as in the reference)
 			const double r = ri2 * ir;
 			const bool in_lj = (ri2 <= bx.t_lj); // rimg - 1e-12 < rc
 			const bool in_es = (ri2 <= bx.t_es); // !(rimg > rc)
@@ -191,9 +191,12 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 				}
 				const double rr = (ri2 == 0.0) ? 0.0 : r;
 				const double lr = lam * rr;
-				const double explr = exp_fast(-lr);
-				const double damp1 = fma(-explr, fma(lr, fma(0.5, lr, 1.0), 1.0), 1.0);   // 1 - e^{-lr} (lr^2/2 + lr + 1)
-				const double damp2 = fma(-explr, (lr * lr) * (lr * (1.0 / 6.0)), damp1);    // damp1 - e^{-lr} lr^3/6
+				double damp1 = 1.0, damp2 = 1.0;
+				if (__any(lr < kTholeFarX)) { // wave-uniform: beyond lambda r = 40 the damping differs from 1 by < 1e-13 (as in CLS_THOLE_FAR)
+					const double explr = exp_fast(-lr);
+					damp1 = fma(-explr, fma(lr, fma(0.5, lr, 1.0), 1.0), 1.0);   // 1 - e^{-lr} (lr^2/2 + lr + 1)
+					damp2 = fma(-explr, (lr * lr) * (lr * (1.0 / 6.0)), damp1);    // damp1 - e^{-lr} lr^3/6
+				}
 				ta = damp1 * ir3;
 				tb = 3.0 * damp2 * ir5;
 			}

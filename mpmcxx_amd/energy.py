@@ -75,8 +75,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = os.environ.get("MPMC_ENERGY_LIB") or _build.LIB  # override: same-box A/B of two builds (tools/ab_bench.sh)
     if not os.path.exists(path):
+        if path != _build.LIB:
+            raise FileNotFoundError(path)
         path = _build.build_library()
     L = C.CDLL(path)
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)

@@ -27,7 +27,7 @@ class Box:
         self.atoms = {k: np.array(v) for k, v in atoms.items()}
         self.basis = np.array(basis, dtype=np.float64)
         self.opts = opts
-        self.sys = energy.System(self.atoms, self.basis, opts, max_atoms=len(self.atoms["charge"]) + 64)  # room for insertions
+        self.sys = energy.System(self.atoms, self.basis, opts)  # capacity = the initial atom count: insertions make the context grow
 
     def snapshot(self):
         return {k: v.copy() for k, v in self.atoms.items()}, self.basis.copy()

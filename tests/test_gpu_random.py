@@ -178,12 +178,25 @@ def test_input_validation():
     with pytest.raises(energy.MpmcError) as ei:
         energy.System(atoms, np.zeros((3, 3)), opts)
     assert ei.value.code == 6004  # invalid_box_dimensions
+
+
+def test_context_grows_past_its_capacity_hint():
+    """max_atoms is a hint: a context created for 64 atoms takes 128 (insertions in the uVT / Gibbs ensembles), keeps its box and
+    options, and gives the energy a fresh context gives."""
+    atoms, basis, opts = util.load_fixture("lj64")
     S = energy.System(atoms, basis, opts, max_atoms=64)
+    e64 = S.energy()
     big = {k: np.concatenate([v, v]) for k, v in atoms.items()}
+    big["pos"] = np.concatenate([atoms["pos"], atoms["pos"] + 1.7])
     big["mol_id"] = np.arange(128, dtype=np.int32)
-    with pytest.raises(energy.MpmcError):
-        S.set_atoms(big)
+    S.set_atoms(big)
+    e128 = S.energy()
+    F = energy.System(big, basis, opts)
+    assert e128 == F.energy() and S.observables["n_lj_in_cutoff"] == F.observables["n_lj_in_cutoff"]
+    S.set_atoms(atoms)  # and back down
+    assert S.energy() == e64
     S.close()
+    F.close()
 
 
 @pytest.mark.parametrize("seed", range(8))
