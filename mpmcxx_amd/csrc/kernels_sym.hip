@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 
 	const bool i_real = !(mi.y & AF_PAD);
 	const bool same_alpha = (fp.polar_ewald_alpha == fp.ewald_alpha);
-	const double lam = fp.polar_damp, lam2 = lam * lam, lam3 = lam2 * lam;
+	const double lam = fp.polar_damp;
 	double e_lj = 0, e_re = 0;
 	int n_lj = 0, n_es = 0;
 	double eix = 0, eiy = 0, eiz = 0; // field on my i-atom
