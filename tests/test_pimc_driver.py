@@ -123,3 +123,24 @@ def test_pimc_on_the_hip_path_reproduces_the_stock_binary(pimc_nvt, name, trial,
         a = pqr.read_pqr(os.path.join(tmp_path, f"{job}.final-{k:04d}.pqr"))["pos"]
         b = pqr.read_pqr(os.path.join(util.GOLDEN, name, f"golden_final-{k:04d}.pqr"))["pos"]
         assert np.abs(a - b).max() <= 1.0e-6
+
+
+def test_host_side_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The driver, the C++ facade and the file readers (everything above the C ABI) under -fsanitize=address,undefined with the oracle
+    as evaluator: any report aborts the run (GPU sanitizers are not available on the pool; the host side is where the pointer work is)."""
+    from mpmcxx_amd import build as mbuild
+
+    mbuild.build_library()
+    subprocess.check_call(["make", "-s", "-C", ORACLE, "oracle"])
+    exe = str(tmp_path / "pimc_san")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-Wall", "-Wextra",
+                           "-Werror", "-I", os.path.join(util.ROOT, "include"), os.path.join(util.ROOT, "tests", "cpp", "pimc_check.cpp"),
+                           "-L", LIBDIR, "-lmpmc_energy", "-L", ORACLE, "-lmpmc_oracle", f"-Wl,-rpath,{LIBDIR}", f"-Wl,-rpath,{ORACLE}",
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1")
+    for name, trial in (("pi_ion27", False), ("pi001", True)):
+        inp, P, _ = CASES[name]
+        out = subprocess.run([exe, os.path.join(util.GOLDEN, name, inp), str(P), str(tmp_path)] + (["--trial"] if trial else []),
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert rows(os.path.join(tmp_path, "energy.dat")) == rows(os.path.join(util.GOLDEN, name, "golden_energy.dat"))
