@@ -191,7 +191,8 @@ int mpmc_energy_wait(mpmc_ctx *ctx, mpmc_result *out);
  *                       geometry of every pair that involves a moved atom) + O(K * count) structure-factor update, added
  *                       to the accepted totals.  Polarizable boxes: a full evaluation (the dipole solve is global).
  *   mpmc_trial_accept : the trial configuration becomes the accepted one / mpmc_trial_reject : it is discarded.
- * A full mpmc_energy() at any time re-bases the totals (the reference's flag_all_pairs, src/System.cpp:1284). */
+ * A full mpmc_energy() at any time re-bases the totals (the reference's flag_all_pairs, src/System.cpp:1284).
+ * Trial positions equal to the accepted ones cost nothing: the trial totals are the accepted totals, no kernel runs. */
 #define MPMC_TRIAL_MAX_ATOMS 256
 int mpmc_trial_begin(mpmc_ctx *ctx, int first, int count, const double *new_pos /*[count][3]*/);
 int mpmc_trial_energy(mpmc_ctx *ctx, mpmc_result *out);

@@ -132,7 +132,7 @@ struct mpmc_ctx {
 	bool cache_valid = false;   // last_full = totals of the accepted configuration, d_sf = its structure factors
 	mpmc_result last_full{};
 	mpmc_result trial_res{};
-	bool trial_open = false, trial_evaluated = false, trial_was_full = false, trial_enqueued = false;
+	bool trial_open = false, trial_evaluated = false, trial_was_full = false, trial_enqueued = false, trial_noop = false;
 	mpmc_result trial_keep{}; // accepted totals while a full-evaluation trial is in flight
 	int trial_first = 0, trial_count = 0;
 	std::vector<double> trial_new, trial_old;
@@ -1273,6 +1273,9 @@ extern "C" int mpmc_trial_begin(mpmc_ctx *c, int first, int count, const double 
 	c->trial_open = true;
 	c->trial_evaluated = false;
 	c->trial_enqueued = false;
+	// a "move" that leaves every coordinate as it is (e.g. the box a two-box move does not touch): the trial totals ARE the accepted
+	// totals, nothing is evaluated.  (The reference's bead moves re-centre the whole chain, so they do touch every image.)
+	c->trial_noop = (std::memcmp(new_pos, c->h_pos.data() + 3 * (size_t)first, 3 * (size_t)count * sizeof(double)) == 0);
 	return MPMC_OK;
 }
 
@@ -1282,6 +1285,11 @@ extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
 	if (!c) return MPMC_ERR_ARG;
 	if (!c->trial_open) return fail(c, MPMC_ERR_ARG, "mpmc_trial_energy: no trial move is open");
 	if (c->trial_enqueued) return fail(c, MPMC_ERR_ARG, "mpmc_trial_energy_async: already enqueued");
+	if (c->trial_noop) {
+		c->trial_was_full = false;
+		c->trial_enqueued = true;
+		return MPMC_OK;
+	}
 	const mpmc_options &o = c->opts;
 	const bool polar = o.polarization && !o.rd_only;
 	const int m = c->trial_count;
@@ -1328,6 +1336,12 @@ extern "C" int mpmc_trial_energy_wait(mpmc_ctx *c, mpmc_result *out) {
 	if (!c || !out) return MPMC_ERR_ARG;
 	if (!c->trial_open || !c->trial_enqueued) return fail(c, MPMC_ERR_ARG, "mpmc_trial_energy_wait: nothing enqueued");
 	c->trial_enqueued = false;
+	if (c->trial_noop) {
+		c->trial_res = c->last_full;
+		c->trial_evaluated = true;
+		*out = c->trial_res;
+		return MPMC_OK;
+	}
 	if (c->trial_was_full) {
 		int rc = mpmc_energy_wait(c, out);
 		if (rc != MPMC_OK) return rc;
@@ -1371,6 +1385,10 @@ extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
 	if (!c->trial_open || !c->trial_evaluated) return fail(c, MPMC_ERR_ARG, "mpmc_trial_accept: no evaluated trial move");
 	HIP_TRY(c, hipSetDevice(c->device));
 	const int m = c->trial_count;
+	if (c->trial_noop) {
+		c->trial_open = false;
+		return MPMC_OK;
+	}
 	if (!c->trial_was_full) {
 		launch_commit_positions(c->stream, c->d_xyzq, c->d_mv_slot, c->d_mv_new, m);
 		HIP_TRY(c, hipGetLastError());

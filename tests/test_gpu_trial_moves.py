@@ -86,3 +86,36 @@ def test_trial_protocol_errors():
     with pytest.raises(energy.MpmcError):
         S.reject()
     S.close()
+
+
+@pytest.mark.parametrize("name,polar", [("ion64_es", False), ("water64_polar", True)])
+def test_a_trial_that_moves_nothing_costs_nothing_and_returns_the_accepted_totals(name, polar):
+    """Trial positions equal to the accepted ones: no kernel runs, the totals are the accepted ones, accept and reject both leave the
+    context as it was -- also in between real moves."""
+    atoms, basis, opts = util.load_fixture(name)
+    if not polar:
+        opts = nonpolar(opts)
+    S = energy.System(atoms, basis, opts)
+    e0 = S.energy()
+    obs0 = dict(S.observables)
+    a, b = molecules(atoms)[3]
+    S.set_profiling(True)
+    S.timings(reset=True)
+    for verdict in ("accept", "reject"):
+        assert S.trial_energy(a, atoms["pos"][a:b]) == e0
+        assert S.trial_observables == obs0
+        getattr(S, verdict)()
+    assert sum(v["launches"] for v in S.timings().values()) == 0  # nothing was launched
+    S.set_profiling(False)
+    # a real move, then a no-op on top of the NEW accepted state
+    trial = atoms["pos"][a:b] + 0.3
+    e1 = S.trial_energy(a, trial)
+    S.accept()
+    assert S.trial_energy(a, trial) == e1
+    S.reject()
+    pos = atoms["pos"].copy()
+    pos[a:b] = trial
+    F = energy.System(dict(atoms, pos=pos), basis, opts)
+    assert util.close(F.energy(), e1, 1e-11) and util.close(S.energy(), e1, 1e-11)
+    S.close()
+    F.close()

@@ -2,7 +2,9 @@
 """Monte Carlo steps per second of the PI-NVT driver (examples/pimc_nvt.cpp) on the 10 000-atom LJ + Ewald box (BASELINE
 configs[2] as a P-image path-integral system): full evaluations per move versus per-move delta energies (--trial).
 
-usage: python tools/pimc_bench.py [P] [steps] [natoms]
+usage: python tools/pimc_bench.py [P] [steps] [natoms] [polar]
+"polar": the polarizable box (Thole iterative, 10 iterations) -- every trial is then a full evaluation of every image (a bead move
+re-centres the whole chain, so no image keeps its coordinates).
 Both runs use the same seed, so they make the same moves; their energy.dat rows must agree to 1e-9.
 """
 import json
@@ -20,6 +22,8 @@ from mpmcxx_amd import build  # noqa: E402
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 natoms = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
+polar = len(sys.argv) > 4 and sys.argv[4] == "polar"
+POLAR = "polarization on\npolar_damp_type exponential\npolar_damp 2.1304\npolar_iterative on\npolar_max_iter 10\npolar_ewald on\n"
 wd = tempfile.mkdtemp(prefix="pimc_bench_")
 L = 86.0 * (natoms / 10000.0) ** (1.0 / 3.0)
 rows = gen_box.lattice_box(natoms, L, 13)
@@ -36,7 +40,7 @@ rot_factor 1.0
 bead_perturb_probability 0.5
 PI_trial_chain_length 2
 ewald_kmax 7
-basis1 {L!r} 0.0 0.0
+{POLAR if polar else ""}basis1 {L!r} 0.0 0.0
 basis2 0.0 {L!r} 0.0
 basis3 0.0 0.0 {L!r}
 pqr_input box.pqr
