@@ -30,7 +30,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec)
@@ -38,7 +37,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec)
 
 def build_case(natoms: int, workdir: str):
     """the config-4 box through the reference's own file formats (so every loader sees the same doubles)."""
-    import gen_box
+    from mpmcxx_amd import gen_box
     from mpmcxx_amd import pqr
 
     if natoms == 10000:
@@ -81,6 +80,7 @@ def cpu_baseline(kind: str, atoms, basis, opts, workdir: str):
                 "sample": f"1 steady-state full-recompute System::energy() of the same {n}-atom box by the reference's object code "
                           f"(oracle/_ref/ref_harness; {sec:.2f} s; harness wall incl. pair-list setup {time.time() - t0:.0f} s)",
                 "energy": res["total"]}
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))  # the checker: this leg is the only place bench.py touches oracle/
     from oracle import OracleSystem
 
     S = OracleSystem(atoms, basis, opts)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*  from the REFERENCE's own object code (build container only).
 
-For every named fixture in oracle/gen_box.py this script
+For every named fixture in mpmcxx_amd/gen_box.py this script
   1. writes NAME.in / NAME.pqr (the reference's on-disk formats) into tests/golden/,
   2. runs oracle/_ref/ref_harness (reference System::energy(), compiled in place from /root/reference/src
      by `make -C oracle ref`) on them,
@@ -25,7 +25,8 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
-import gen_box  # noqa: E402
+sys.path.insert(0, ROOT)
+from mpmcxx_amd import gen_box  # noqa: E402
 
 HARNESS = os.path.join(HERE, "_ref", "ref_harness")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -64,7 +65,7 @@ def main():
             extra += ["--amatrix"] + spots
         res = run_harness(inp, extra)
         res["fixture"] = name
-        res["generator"] = "oracle/gen_box.py:fixture + oracle/_ref/ref_harness (reference System::energy)"
+        res["generator"] = "mpmcxx_amd/gen_box.py:fixture + oracle/_ref/ref_harness (reference System::energy)"
         with open(os.path.join(GOLDEN, f"{name}.json"), "w") as f:
             json.dump(res, f, indent=0, separators=(",", ":"))
             f.write("\n")

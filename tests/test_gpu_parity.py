@@ -243,7 +243,7 @@ def test_full_size_boxes_match_reference(name, tmp_path):
 def test_full_size_translation_invariance_and_image_shift():
     """size-independent property at the full 10k size: shifting every atom by a lattice vector, or the whole box
     rigidly, leaves every energy component unchanged (to rounding) and the pair counts identical."""
-    import gen_box
+    from mpmcxx_amd import gen_box
 
     rows, basis, opts = gen_box.fixture("ion10k_es")
     import tempfile

@@ -36,7 +36,7 @@ def load_fixture(name):
 
 def load_generated(name, tmpdir):
     """large boxes are regenerated deterministically instead of being committed as text."""
-    import gen_box
+    from mpmcxx_amd import gen_box
 
     inp, _ = gen_box.materialize(name, str(tmpdir))
     return pqr.load_case(inp)

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import gen_box  # noqa: E402
+from mpmcxx_amd import gen_box  # noqa: E402
 from mpmcxx_amd import energy, pqr  # noqa: E402
 
 wd = tempfile.mkdtemp()

@@ -1,6 +1,6 @@
 import os, sys, tempfile, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle"))
-import gen_box
+from mpmcxx_amd import gen_box
 from mpmcxx_amd import energy, pqr
 wd = tempfile.mkdtemp()
 for name in ("lj1000", "ion1000_polar", "ion216_polar"):

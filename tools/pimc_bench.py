@@ -16,8 +16,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import gen_box  # noqa: E402
-from mpmcxx_amd import build  # noqa: E402
+from mpmcxx_amd import build, gen_box  # noqa: E402
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
