@@ -32,6 +32,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Algorithmic fp64 flops per unordered pair, counted the way the 78.6 TFLOP/s peak is: one FMA = 2 flops.
+#   Jacobi contraction, tensor (a, b) read from the store: d = r_i - r_j 3, minimum image 3 x (mul, rint, fma) 9 [rint not counted],
+#     mu_j.d and mu_i.d 2 x (mul + 2 fma) 10, b x dot 2, E_i += a mu_j - (b mu_j.d) d and the same for E_j 2 x 6 fma 24         = 48
+#   ... tensor recomputed (far field): + r^2 (mul + 2 fma) 5, 1/r = rsq + one Newton step 7, 1/r^3 and 3/r^5 4                 = 64
+#   pair sweep: d + minimum image 12, r^2 5, 1/r 8 = 25 for every pair; inside the cutoff (52.3 % of the pairs of the benchmark box)
+#     LJ 11, erfc(x) exp(-x^2) 85 (two Horner polynomials of 20 + 11 FMA, range reduction, one reciprocal), Coulomb 4, field factor and
+#     both atoms 20 = 120; Thole damping + (a, b) 49 for the pairs of the stored tile pairs (36 %)          25 + 0.523 x 120 + 0.36 x 49 = 105
+FLOP_PAIR_STORED, FLOP_PAIR_FAR, FLOP_PAIR_SWEEP = 48.0, 64.0, 105.0
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec)
 
 
@@ -293,9 +301,8 @@ def main():
         hybrid = hybrid_default if hybrid is None else hybrid
         """roofline of one kernel class from its HIP-event time.  Algorithmic figures (DESIGN.md §3):
         dipole_iter (k_dipole_iter_stream): HBM -- 16 B per stored unordered pair + 80 B per atom (positions, dipoles in, field out)
-        dipole_far  (k_dipole_iter_far)   : fp64 -- 49 flop per far-field pair (min-image 9, r^2 5, 1/r^3 & 3/r^5 11, two dots 10, two applications 14)
-        pair        (k_pair_fused)        : fp64 -- 120 flop per pair (min-image 9, r^2 5, 1/r 8, LJ 9, erfc polynomial + Gaussian 45,
-                                            Coulomb 3, field factor + both atoms 17, Thole damping + tensor 24, averaged over the in-cutoff fraction)"""
+        dipole_far  (k_dipole_iter_far)   : fp64 -- FLOP_PAIR_FAR per far-field pair
+        pair        (k_pair_fused)        : fp64 -- FLOP_PAIR_SWEEP per pair (breakdowns next to the constants at the top of this file)"""
         avg_ms = tv["ms"] / max(tv["launches"], 1)
         sec = avg_ms * 1e-3
         if name == "dipole_iter" and args.solver == "dense":  # the reference's 3N x 3N layout, contraction on v_mfma_f64_16x16x4_f64
@@ -324,7 +331,7 @@ def main():
             # tensor.  fp64 issue is what binds it (measured on MI355X: sending every off-diagonal tile pair down the recompute path
             # leaves the launch time unchanged, dropping the HBM loads saves 8 %), so the compute roof is the primary
             # entry and the bytes are reported beside it.
-            fl = (33.0 * n_pairs_stored + 49.0 * n_pairs_far) * per_launch
+            fl = (FLOP_PAIR_STORED * n_pairs_stored + FLOP_PAIR_FAR * n_pairs_far) * per_launch
             tf = fl / sec / 1e12 if sec > 0 else 0.0
             if hbm["traffic"] is not None:
                 hbm["traffic"] *= per_launch
@@ -337,14 +344,14 @@ def main():
                             "duration in the timed region is about twice what it needs alone: `isolated` holds the same kernels one at a time, "
                             "MPMC_PI_LOCKSTEP=1 runs all beads' iterations in one launch per iteration (clean durations, 9 % lower whole-job rate).  "
                             "One launch per Jacobi "
-                            "iteration over ALL tile pairs: 33 flop per streamed pair (16 B of stored tensor), 49 flop per recomputed far-field pair.  "
+                            "iteration over ALL tile pairs: 48 flop per streamed pair (16 B of stored tensor), 64 flop per recomputed far-field pair (FMA = 2).  "
                             "Sustained v_fma_f64 issue measured on this pool (tools/microbench_f64.hip): 59 TFLOP/s, and the kernel's instruction mix "
                             "(FMA 41 %, MUL 29 %, DPP/int 17 %, ADD/RNDNE 11 %, RSQ 2 %) runs at ~80 % of the rate that mix sustains.  "
                             "MPMC_JACOBI=split runs the two halves as separate kernels (k_dipole_iter_stream HBM-bound, k_dipole_iter_far fp64-bound).")}
             if hbm.get("traffic_source"):
                 out["traffic_source"] = hbm["traffic_source"]
             return out
-        flops = 49.0 * n_pairs_far if name == "dipole_far" else 120.0 * n_pairs_all
+        flops = FLOP_PAIR_FAR * n_pairs_far if name == "dipole_far" else FLOP_PAIR_SWEEP * n_pairs_all
         ach = flops / sec / 1e12 if sec > 0 else 0.0
         return {"bound": "mfma", "kernel": "k_dipole_iter_far" if name == "dipole_far" else "k_pair_fused", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches": tv["launches"],
@@ -373,7 +380,7 @@ def main():
             ih = iso_hybrid.get("dipole_iter", {"ms": 0.0, "launches": 0})
             if ih["launches"] and not ("dipole_far" in iso_hybrid and iso_hybrid["dipole_far"]["launches"]):
                 it_ms = ih["ms"] / ih["launches"]
-                fl = 33.0 * n_pairs_stored + 49.0 * n_pairs_far
+                fl = FLOP_PAIR_STORED * n_pairs_stored + FLOP_PAIR_FAR * n_pairs_far
                 roof["alone_on_the_gpu"] = {"kernel": "k_dipole_iter_hybrid", "avg_launch_ms": it_ms, "achieved": fl / (it_ms * 1e-3) / 1e12,
                                             "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (it_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                             "hbm_GBps": (16.0 * n_pairs_stored + n * 80.0) / (it_ms * 1e-3) / 1e9,
