@@ -12,8 +12,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmpmc_energy.so")
-SOURCES = ["kernels.hip", "kernels_sym.hip", "kernels_delta.hip", "kernels_gs.hip", "kernels_dense.hip", "context.cpp"]
-HEADERS = ["kernels.h", "pair_math.h", "erfcx_coeffs.h", "device_math.h", os.path.join("..", "..", "include", "mpmc_energy.h")]
+SOURCES = ["kernels.hip", "kernels_sym.hip", "kernels_delta.hip", "kernels_gs.hip", "kernels_dense.hip", "context.cpp", "evaluate.cpp", "trial.cpp", "pi.cpp"]
+HEADERS = ["kernels.h", "context.h", "pair_math.h", "erfcx_coeffs.h", "device_math.h", os.path.join("..", "..", "include", "mpmc_energy.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

@@ -1,0 +1,248 @@
+// context.h -- INTERNAL to libmpmc_energy.so: the device-resident state behind an mpmc_ctx handle and the helpers its translation units
+// share (context.cpp: lifetime, box, options, atoms; evaluate.cpp: one energy evaluation and its pieces; trial.cpp: per-move delta
+// energies; pi.cpp: the path-integral bead loop).  Not installed, not part of the C ABI (include/mpmc_energy.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mpmc_energy.h"
+#include "kernels.h"
+
+using namespace mpmc;
+
+namespace mpmc {
+extern thread_local std::string g_create_error; // last create-time error of this thread (context.cpp)
+}
+
+struct EvPair {
+	hipEvent_t a, b;
+	int cls;
+};
+
+struct mpmc_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	// second stream for work that is independent of the main chain inside ONE evaluation (reciprocal space next to the
+	// pair sweep; the far-field Jacobi kernel next to the streaming one); always joined back before results are used
+	hipStream_t stream2 = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	bool two_streams = true; // MPMC_ONE_STREAM=1 disables the fork/join
+	int jacc = 0; // hybrid Jacobi kernel variant (MPMC_JACC): 0 DPP lane rotation, 1 ds_bpermute (when the DPP self-test fails)
+	bool jacobi_hybrid = true; // one launch per Jacobi iteration over all tile pairs; MPMC_JACOBI=split: two kernels (stream / far)
+	int max_atoms = 0, max_pad = 0;
+	int n = 0, n_pad = 0, n_tiles = 0, n_tile_pairs = 0, n_split = 1;
+	int n_molecules = 0;
+	double N_movable = 0; // countN
+	std::string err;
+
+	// host mirrors of the flattened System
+	std::vector<double> h_pos, h_q, h_alpha, h_eps, h_sigma, h_mass;
+	std::vector<int32_t> h_mol, h_frozen, h_disp;
+
+	// spatial order: device slot k holds original atom perm[k]; slot_of[i] is the slot of original atom i.
+	// Atoms are sorted (nested x / y / z bisection of the wrapped fractional coordinates) so that each tile of 64
+	// consecutive slots is spatially compact; every result that leaves the library is returned in ORIGINAL order.
+	std::vector<int32_t> perm, slot_of;
+	int32_t *d_slot_of = nullptr, *d_perm = nullptr;
+	bool atoms_dirty = true; // host mirror newer than the device arrays (full upload pending)
+
+	// device atom arrays
+	double4 *d_xyzq = nullptr;
+	double2 *d_lj = nullptr;
+	int2 *d_mf = nullptr;
+	double *d_alpha = nullptr, *d_eps = nullptr, *d_inv_molmass = nullptr;
+
+	// pair kernel
+	int2 *d_tile_pairs = nullptr;
+	double *d_block_part = nullptr; // [ntp][2]
+	int *d_block_cnt = nullptr;     // [ntp][4] (2 used by the pair kernel, 4 by the static-count kernel)
+	int *d_cls = nullptr;           // tile-pair classes (CLS_*), recomputed every evaluation
+	int *d_lists = nullptr;         // [2 ntp] work lists of the two Jacobi kernels + [2] their lengths (at the end)
+	double *d_tile_bounds = nullptr; // [n_tiles][12]: wrapped fractional lo/hi, raw Cartesian lo/hi
+	double4 *d_tp_shift = nullptr;   // [n_tile_pairs] lattice vector components of the common image index (CLS_UNIFORM_X/Y/Z)
+	std::vector<double4> h_xyzq;     // host mirror of d_xyzq (slot order), for bulk position updates
+	std::vector<double> h_pos_sorted; // positions at the time of the last spatial sort
+	double sort_origin_f[3] = {0, 0, 0}; // fractional coordinate at which the spatial sort cuts the periodic wrap
+	bool no_uniform = false;         // MPMC_NO_UNI=1
+	// lockstep solve of several systems (mpmc_pi_potential_local): enqueue() stops before the dipole iterations when asked to and
+	// possible; the batch driver then runs the iterations of all deferred systems in shared launches on one stream
+	bool defer_solve = false, solve_deferred = false, reduce_pending_join = false;
+	hipEvent_t ev_phase = nullptr;      // "everything before the solve is enqueued" marker on this context's stream
+	hipStream_t sync_stream = nullptr;  // stream that carries this context's final copies (null: its own)
+	SolveBead *d_solve_args = nullptr;  // device array of per-system pointers (owned by the first system of a batch)
+	std::vector<SolveBead> h_solve_args; // its host image (must outlive the asynchronous copy)
+	int cap_solve_args = 0;
+	int last_batch = 1;                 // systems per launch in the last evaluation's solve
+	size_t cap_tile_pairs = 0;
+	long long static_cnt[4] = {0, 0, 0, 0}; // n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent)
+
+	// scalars
+	double *d_scal = nullptr;
+	long long *d_cnt = nullptr;
+	double *h_scal = nullptr; // pinned
+	long long *h_cnt = nullptr;
+	int *d_flag = nullptr;
+	int *h_flag = nullptr; // pinned
+
+	// reciprocal tables
+	int K = 0, cap_K = 0;
+	double4 *d_kvec = nullptr, *d_kw = nullptr, *d_sf = nullptr;
+	int4 *d_lvec = nullptr;       // integer l-vectors of the k table
+	double4 *d_sf_part = nullptr; // [n_tiles][K] per-tile structure-factor partials (factorised phases)
+	size_t cap_sf_part = 0;
+	bool no_recip_tab = false;    // MPMC_NO_RECIP_TAB=1: one sincos per (k, atom)
+	double *d_w_en = nullptr;
+
+	// polarization work
+	double *d_e_recip_part = nullptr, *d_part = nullptr, *d_e_static = nullptr, *d_mu[2] = {nullptr, nullptr}, *d_e_induced = nullptr,
+	       *d_rrms = nullptr;
+	size_t cap_part = 0;
+	int mu_cur = 0;
+	// dense A rows scratch
+	double *d_arows = nullptr;
+	double *d_adense = nullptr; // solver DENSE: the (3 n_pad)^2 matrix of thole_amatrix without its diagonal blocks
+	size_t cap_adense = 0;
+	size_t cap_arows = 0;
+	// compact Thole tensor store: (a,b) per unordered pair, tile-pair major, 64*64 double2 per tile pair
+	double2 *d_ab = nullptr;
+	size_t cap_ab = 0; // in double2 elements
+	int solver_used = MPMC_SOLVER_MATRIX_FREE;
+	bool use_dpp = true;   // lane rotation by v_mov_b32_dpp wave_rol:1 (verified at create), else ds_bpermute
+	bool no_classes = false; // MPMC_NO_CLASSES=1: treat every tile pair as near (A/B comparisons only)
+
+	Box box{};
+	bool box_set = false, atoms_set = false, opts_set = false, k_dirty = true;
+	mpmc_options opts{};
+	double ewald_alpha = 0, polar_ewald_alpha = 0;
+
+	// results of the last evaluation
+	bool pending = false;
+	bool have_polar = false;
+	int iters = 0, failed = 0;
+	unsigned run_mask = 0;
+
+	// trial moves (delta energies)
+	bool cache_valid = false;   // last_full = totals of the accepted configuration, d_sf = its structure factors
+	mpmc_result last_full{};
+	mpmc_result trial_res{};
+	bool trial_open = false, trial_evaluated = false, trial_was_full = false, trial_enqueued = false, trial_noop = false;
+	mpmc_result trial_keep{}; // accepted totals while a full-evaluation trial is in flight
+	int trial_first = 0, trial_count = 0;
+	std::vector<double> trial_new, trial_old;
+	int *d_mv_slot = nullptr, *d_mv_orig = nullptr, *d_moved_idx = nullptr; // d_mv_slot/d_mv_orig/d_mv_new live in ONE allocation (d_mv_blob)
+	double4 *d_mv_new = nullptr, *d_sf_trial = nullptr;
+	unsigned char *d_mv_blob = nullptr, *h_mv_blob = nullptr; // device / pinned host staging of a trial's moved-atom list
+	int cap_sf_trial = 0;
+	double *d_delta_out = nullptr, *h_delta_out = nullptr;
+	long long *d_delta_cnt = nullptr, *h_delta_cnt = nullptr;
+
+	// profiling
+	bool prof = false;
+	std::vector<EvPair> ev_free, ev_used;
+	mpmc_timings tim{};
+
+	int64_t bytes_total = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+#define HIP_TRY(ctx, call)                                                                                        \
+	do {                                                                                                          \
+		hipError_t _e = (call);                                                                                   \
+		if (_e != hipSuccess) {                                                                                   \
+			(ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e);                                       \
+			return MPMC_ERR_HIP;                                                                                  \
+		}                                                                                                         \
+	} while (0)
+
+namespace mpmc { // internal helpers: mangled names, nothing here can collide with a symbol of the host program
+
+template <typename T>
+inline int dev_alloc(mpmc_ctx *c, T **p, size_t count) {
+	HIP_TRY(c, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+	c->bytes_total += (int64_t)(count * sizeof(T));
+	return MPMC_OK;
+}
+template <typename T>
+inline void dev_free(mpmc_ctx *c, T **p, size_t count) {
+	if (*p) {
+		(void)hipFree(*p);
+		c->bytes_total -= (int64_t)(count * sizeof(T));
+		*p = nullptr;
+	}
+}
+
+inline int fail(mpmc_ctx *c, int code, const std::string &msg) {
+	if (c) c->err = msg;
+	else g_create_error = msg;
+	return code;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------------
+inline void prof_begin(mpmc_ctx *c, int cls, int &cur, hipStream_t st) {
+	cur = -1;
+	if (!c->prof) return;
+	EvPair e;
+	if (!c->ev_free.empty()) {
+		e = c->ev_free.back();
+		c->ev_free.pop_back();
+	} else {
+		if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+	}
+	e.cls = cls;
+	(void)hipEventRecord(e.a, st);
+	c->ev_used.push_back(e);
+	cur = (int)c->ev_used.size() - 1;
+}
+inline void prof_end(mpmc_ctx *c, int cur, hipStream_t st) {
+	if (cur >= 0 && cur < (int)c->ev_used.size()) (void)hipEventRecord(c->ev_used[cur].b, st);
+}
+inline void prof_harvest(mpmc_ctx *c) { // stream must be idle
+	for (auto &e : c->ev_used) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+			c->tim.ms[e.cls] += ms;
+			c->tim.launches[e.cls] += 1;
+		}
+		c->ev_free.push_back(e);
+	}
+	c->ev_used.clear();
+}
+struct ProfScope { // HIP-event bracket on the stream the kernels are launched on
+	mpmc_ctx *c;
+	int cur;
+	hipStream_t st;
+	ProfScope(mpmc_ctx *c_, int cls, hipStream_t st_ = nullptr) : c(c_), st(st_ ? st_ : c_->stream) { prof_begin(c, cls, cur, st); }
+	~ProfScope() { prof_end(c, cur, st); }
+};
+// side stream: starts after everything enqueued so far on the main stream / main stream waits for the side stream
+inline hipStream_t fork_side(mpmc_ctx *c) {
+	if (!c->two_streams) return c->stream;
+	(void)hipEventRecord(c->ev_fork, c->stream);
+	(void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+	return c->stream2;
+}
+inline void join_side(mpmc_ctx *c) {
+	if (!c->two_streams) return;
+	(void)hipEventRecord(c->ev_join, c->stream2);
+	(void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+}
+
+
+// ---- shared between the translation units ---------------------------------------------------------------------
+enum : unsigned { RUN_PAIR = 1, RUN_PAIR_ES = 2, RUN_RECIP = 4, RUN_ATOMTERMS = 8, RUN_FIELD = 16, RUN_SOLVE = 32, RUN_WOLF = 64 };
+int prepare(mpmc_ctx *c);                        // uploads what is dirty, (re)builds the k tables, resolves the solver (evaluate.cpp)
+int enqueue(mpmc_ctx *c, unsigned mask);         // one evaluation (the pieces in `mask`) on the context's streams (evaluate.cpp)
+int wait_and_fill(mpmc_ctx *c, mpmc_result *out); // waits for it and assembles the result (evaluate.cpp)
+unsigned full_mask(const mpmc_ctx *c);           // what double System::energy() runs under the current options
+AtomsDev atoms_view(const mpmc_ctx *c);
+RecipDev recip_view(const mpmc_ctx *c);
+int upload_atoms(mpmc_ctx *c);                   // spatial order + device atom arrays (context.cpp)
+
+} // namespace mpmc

@@ -1,0 +1,589 @@
+// evaluate.cpp -- one energy evaluation: k tables, work buffers, the enqueue of every kernel of double System::energy(), result assembly, component entry points
+// (part of libmpmc_energy.so; shared state and helpers: context.h.  There is no CPU fallback anywhere in this library.)
+#include "context.h"
+
+
+using namespace mpmc;
+
+// ---- k-vector tables (hemisphere enumeration of coulombic_reciprocal :1577-1590 / recip_term :2849-2865) --------
+static int build_k_tables(mpmc_ctx *c) {
+	const int kmax = c->opts.ewald_kmax;
+	const double alpha = c->ewald_alpha, ea = c->polar_ewald_alpha;
+	std::vector<double4> kvec, kw;
+	std::vector<double> wen;
+	std::vector<int4> lvec;
+	int l[3];
+	for (l[0] = 0; l[0] <= kmax; l[0]++)
+		for (l[1] = (!l[0] ? 0 : -kmax); l[1] <= kmax; l[1]++)
+			for (l[2] = ((!l[0] && !l[1]) ? 1 : -kmax); l[2] <= kmax; l[2]++) {
+				if (l[0] * l[0] + l[1] * l[1] + l[2] * l[2] > kmax * kmax) continue;
+				double k[3];
+				for (int p = 0; p < 3; p++) {
+					k[p] = 0;
+					for (int q = 0; q < 3; q++) k[p] += 2.0 * kPi * c->box.r[3 * p + q] * l[q];
+				}
+				const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+				kvec.push_back(make_double4(k[0], k[1], k[2], k2));
+				lvec.push_back(make_int4(l[0], l[1], l[2], 0));
+				wen.push_back(std::exp(-k2 / (4.0 * alpha * alpha)) / k2);
+				const double g = std::exp(-k2 / (4.0 * ea * ea));
+				kw.push_back(make_double4(k[0] / k2 * g, k[1] / k2 * g, k[2] / k2 * g, 0.0));
+			}
+	const int K = (int)kvec.size();
+	if (K > c->cap_K) {
+		dev_free(c, &c->d_kvec, (size_t)c->cap_K);
+		dev_free(c, &c->d_kw, (size_t)c->cap_K);
+		dev_free(c, &c->d_lvec, (size_t)c->cap_K);
+		dev_free(c, &c->d_sf, (size_t)c->cap_K);
+		dev_free(c, &c->d_w_en, (size_t)c->cap_K);
+		c->cap_K = 0;
+		int rc;
+		if ((rc = dev_alloc(c, &c->d_kvec, (size_t)K)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_kw, (size_t)K)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_lvec, (size_t)K)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_sf, (size_t)K)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_w_en, (size_t)K)) != MPMC_OK) return rc;
+		c->cap_K = K;
+	}
+	if (K > 0) {
+		HIP_TRY(c, hipMemcpy(c->d_kvec, kvec.data(), K * sizeof(double4), hipMemcpyHostToDevice));
+		HIP_TRY(c, hipMemcpy(c->d_kw, kw.data(), K * sizeof(double4), hipMemcpyHostToDevice));
+		HIP_TRY(c, hipMemcpy(c->d_lvec, lvec.data(), K * sizeof(int4), hipMemcpyHostToDevice));
+		HIP_TRY(c, hipMemcpy(c->d_w_en, wen.data(), K * sizeof(double), hipMemcpyHostToDevice));
+	}
+	c->K = K;
+	return MPMC_OK;
+}
+
+static int ensure_polar_buffers(mpmc_ctx *c) {
+	const size_t np = (size_t)c->max_pad;
+	int rc;
+	if (!c->d_e_static) {
+		if ((rc = dev_alloc(c, &c->d_e_static, 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_mu[0], 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_mu[1], 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_e_induced, 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_rrms, np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_e_recip_part, (size_t)kKSplit * 3 * np)) != MPMC_OK) return rc;
+		HIP_TRY(c, hipMemset(c->d_e_static, 0, 3 * np * sizeof(double)));
+		HIP_TRY(c, hipMemset(c->d_mu[0], 0, 3 * np * sizeof(double)));
+		HIP_TRY(c, hipMemset(c->d_mu[1], 0, 3 * np * sizeof(double)));
+		HIP_TRY(c, hipMemset(c->d_e_induced, 0, 3 * np * sizeof(double)));
+		HIP_TRY(c, hipMemset(c->d_rrms, 0, np * sizeof(double)));
+	}
+	// per-atom partial slots: one per source tile (symmetric kernels) -- also covers the n_split <= n_tiles slots
+	// of the matrix-free row kernel
+	const size_t need = (size_t)c->n_tiles * c->n_pad * 3;
+	if (need > c->cap_part) {
+		dev_free(c, &c->d_part, c->cap_part);
+		c->cap_part = 0;
+		if ((rc = dev_alloc(c, &c->d_part, need)) != MPMC_OK) return rc;
+		c->cap_part = need;
+	}
+	return MPMC_OK;
+}
+
+// decide how the dipole iteration runs and (COMPACT) make room for the tensor store
+static int resolve_solver(mpmc_ctx *c) {
+	const size_t need = (size_t)c->n_tile_pairs * (kTile * kTile); // double2 elements, 16 B each
+	int want = c->opts.solver;
+	if (c->opts.polar_gs) want = MPMC_SOLVER_MATRIX_FREE; // Gauss-Seidel sweeps rebuild the tensors row block by row block (kernels_gs.hip)
+	if (want == MPMC_SOLVER_AUTO) {
+		size_t budget_mb = 4096;
+		if (const char *e = std::getenv("MPMC_TENSOR_BUDGET_MB")) budget_mb = (size_t)std::strtoull(e, nullptr, 10);
+		want = (need * sizeof(double2) <= budget_mb * (size_t)1048576) ? MPMC_SOLVER_COMPACT : MPMC_SOLVER_MATRIX_FREE;
+		// building the store costs about as much as three iterations save (0.10 ms against 0.03 ms per iteration at 10 000 atoms)
+		if (c->opts.polar_precision == 0.0 && c->opts.polar_max_iter <= 3) want = MPMC_SOLVER_MATRIX_FREE;
+	}
+	if (want == MPMC_SOLVER_DENSE) { // the reference's layout, on request only: (3 n_pad)^2 doubles
+		const size_t nd = (size_t)3 * c->n_pad * (size_t)3 * c->n_pad;
+		if (nd > c->cap_adense) {
+			dev_free(c, &c->d_adense, c->cap_adense);
+			c->cap_adense = 0;
+			int rc = dev_alloc(c, &c->d_adense, nd);
+			if (rc != MPMC_OK) return rc;
+			c->cap_adense = nd;
+		}
+	}
+	if (want == MPMC_SOLVER_COMPACT && need > c->cap_ab) {
+		dev_free(c, &c->d_ab, c->cap_ab);
+		c->cap_ab = 0;
+		int rc = dev_alloc(c, &c->d_ab, need);
+		if (rc != MPMC_OK) {
+			if (c->opts.solver == MPMC_SOLVER_COMPACT) return rc; // explicitly requested: report
+			(void)hipGetLastError();
+			want = MPMC_SOLVER_MATRIX_FREE; // AUTO: fall back to recomputing the tensors (still the HIP path)
+		} else {
+			c->cap_ab = need;
+		}
+	}
+	c->solver_used = want;
+	return MPMC_OK;
+}
+
+// resolve alpha defaults, rebuild k tables when box/options changed
+int mpmc::prepare(mpmc_ctx *c) {
+	if (!c->box_set) return fail(c, MPMC_ERR_BOX, "energy: no box set (mpmc_set_box)");
+	if (!c->atoms_set) return fail(c, MPMC_ERR_INVALID_DATUM, "energy: no atoms set (mpmc_set_atoms)");
+	HIP_TRY(c, hipSetDevice(c->device));
+	if (c->opts.feynman_hibbs && c->h_mass.empty())
+		return fail(c, MPMC_ERR_INVALID_DATUM, "energy: feynman_hibbs needs atom masses (mpmc_set_atoms was called without them)");
+	if (c->atoms_dirty) {
+		int rc = upload_atoms(c);
+		if (rc != MPMC_OK) return rc;
+	}
+	if (c->k_dirty) {
+		// System::update_pbc, reference src/System.cpp:871-874
+		c->ewald_alpha = (c->opts.ewald_alpha > 0) ? c->opts.ewald_alpha : 3.5 / c->box.cutoff;
+		c->polar_ewald_alpha = (c->opts.polar_ewald_alpha > 0) ? c->opts.polar_ewald_alpha : 3.5 / c->box.cutoff;
+		int rc = build_k_tables(c);
+		if (rc != MPMC_OK) return rc;
+		c->k_dirty = false;
+	}
+	return MPMC_OK;
+}
+
+AtomsDev mpmc::atoms_view(const mpmc_ctx *c) {
+	AtomsDev a;
+	a.xyzq = c->d_xyzq;
+	a.lj = c->d_lj;
+	a.mf = c->d_mf;
+	a.alpha = c->d_alpha;
+	a.eps = c->d_eps;
+	a.inv_molmass = c->d_inv_molmass;
+	a.n = c->n;
+	a.n_pad = c->n_pad;
+	return a;
+}
+RecipDev mpmc::recip_view(const mpmc_ctx *c) {
+	RecipDev r;
+	r.kvec = c->d_kvec;
+	r.w_en = c->d_w_en;
+	r.kw = c->d_kw;
+	r.lvec = c->no_recip_tab ? nullptr : c->d_lvec;
+	r.sf = c->d_sf;
+	r.K = c->K;
+	return r;
+}
+
+// which pieces of energy() to run
+
+int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
+	int rc = prepare(c);
+	if (rc != MPMC_OK) return rc;
+	const AtomsDev at = atoms_view(c);
+	const RecipDev rcp = recip_view(c);
+	const mpmc_options &o = c->opts;
+	hipStream_t st = c->stream;
+	c->run_mask = mask;
+	c->have_polar = false;
+	c->iters = 0;
+	c->failed = 0;
+
+	HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (S_COUNT + C_COUNT) * sizeof(double), st));
+
+	if (mask & (RUN_FIELD | RUN_SOLVE)) {
+		if ((rc = ensure_polar_buffers(c)) != MPMC_OK) return rc;
+		if ((rc = resolve_solver(c)) != MPMC_OK) return rc;
+	}
+	const bool compact = (mask & RUN_SOLVE) && c->solver_used == MPMC_SOLVER_COMPACT;
+
+	// ---- reciprocal space + O(N) atom terms on the side stream, next to the pair sweep ------------------------------
+	const bool need_sf = (mask & RUN_RECIP) || ((mask & RUN_FIELD) && o.polar_ewald);
+	// intramolecular charge-to-screen term of coulombic_real: position dependent but independent of the pair sweep; identically zero
+	// when every molecule is a single atom
+	const bool need_intra = (mask & RUN_PAIR) && (mask & RUN_PAIR_ES) && !(o.wolf && (mask & RUN_WOLF)) && (c->n_molecules != c->n);
+	const bool side_work = need_sf || (mask & RUN_ATOMTERMS) || need_intra;
+	// a fork/join costs ~20 us of dispatch latency: worth it next to reciprocal-space work, not for the O(N) atom terms alone
+	const bool side_fork = c->two_streams && (need_sf || need_intra);
+	if (side_work) {
+		hipStream_t s2 = side_fork ? fork_side(c) : st;
+		if (need_intra) {
+			ProfScope p(c, MPMC_K_PAIR, s2);
+			launch_intra_terms(s2, at, c->d_slot_of, c->ewald_alpha, c->d_scal);
+		}
+		{
+			ProfScope p(c, MPMC_K_RECIP, s2);
+			if (need_sf) {
+				const size_t need_part = (size_t)c->n_tiles * (size_t)c->K;
+				if (rcp.lvec && o.ewald_kmax <= kRecipTabMaxK && need_part > c->cap_sf_part) {
+					dev_free(c, &c->d_sf_part, c->cap_sf_part);
+					c->cap_sf_part = 0;
+					if ((rc = dev_alloc(c, &c->d_sf_part, need_part)) != MPMC_OK) return rc;
+					c->cap_sf_part = need_part;
+				}
+				launch_recip_sf(s2, at, c->box, rcp, o.ewald_kmax, c->d_sf_part);
+			}
+			if (mask & (RUN_RECIP | RUN_ATOMTERMS))
+				launch_atom_terms(s2, at, rcp, c->box, c->ewald_alpha, (mask & RUN_ATOMTERMS) ? o.rd_lrc : 0, (mask & RUN_RECIP) ? 1 : 0, c->d_scal);
+		}
+		if ((mask & RUN_FIELD) && o.polar_ewald) {
+			ProfScope p(c, MPMC_K_FIELD, s2);
+			launch_field_recip(s2, at, c->box, rcp, o.ewald_kmax, c->d_e_recip_part);
+		}
+	}
+
+	// ---- pairwise pass: one symmetric sweep (energies + counts, static-field partials, Thole tensor store) ----------
+	if (mask & (RUN_PAIR | RUN_FIELD)) {
+		ProfScope p(c, MPMC_K_PAIR);
+		// tile-pair classes from this configuration's tile bounding boxes (orthorhombic cells; all "near" otherwise)
+		if (c->no_classes) HIP_TRY(c, hipMemsetAsync(c->d_cls, 0, (size_t)c->n_tile_pairs * sizeof(int), st));
+		else launch_tile_classes(st, at, c->box, c->d_tile_pairs, c->n_tile_pairs, (o.polarization && !o.rd_only) ? o.polar_damp : 0.0,
+		                         c->d_tile_bounds, c->d_cls, c->no_uniform ? nullptr : c->d_tp_shift, c->sort_origin_f);
+		FusedParams fp;
+		fp.ewald_alpha = c->ewald_alpha;
+		fp.polar_ewald_alpha = c->polar_ewald_alpha;
+		fp.polar_damp = o.polar_damp;
+		fp.rd_lrc = o.rd_lrc;
+		fp.do_es = ((mask & RUN_PAIR_ES) || (mask & RUN_FIELD)) ? 1 : 0;
+		fp.do_field = (mask & RUN_FIELD) ? (o.polar_ewald ? 1 : 2) : 0;
+		fp.do_thole = compact ? 1 : 0;
+		fp.wolf = (o.wolf && (mask & RUN_WOLF)) ? 1 : 0;
+		fp.fh_order = o.feynman_hibbs ? ((o.feynman_hibbs_order == 4) ? 4 : 2) : 0;
+		fp.fh_c2 = fp.fh_c4 = 0.0;
+		if (fp.fh_order) { // reference constants.h:15-33: M2A2 hBar2 / (24 kB T) and M2A4 hBar4 / (1152 kB2 T^2), reduced mass in kg
+			const double hBar2 = 1.11211999e-68, hBar4 = 1.23681087e-136, kB = 1.3806503e-23, kB2 = 1.90619525e-46, amu = 1.66053873e-27;
+			fp.fh_c2 = 1.0e20 * (hBar2 / (24.0 * kB * o.temperature)) / amu;
+			fp.fh_c4 = 1.0e40 * (hBar4 / (1152.0 * kB2 * o.temperature * o.temperature)) / (amu * amu);
+		}
+		fp.wolf_erfa_over_r = std::erf(c->ewald_alpha * c->box.cutoff) / c->box.cutoff;
+		fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
+		if (compact && !c->jacobi_hybrid) // work lists of the two-kernel Jacobi form only
+			launch_build_lists(st, c->d_cls, c->n_tile_pairs, c->d_lists, c->d_lists + 2 * (size_t)c->n_tile_pairs);
+		launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
+		                  compact ? c->d_ab : nullptr);
+	}
+	if (side_work && side_fork) join_side(c);
+	bool reduce_forked = false;
+	if (mask & RUN_PAIR) { // the scalar totals of the sweep are only read back at the very end: fold them beside the field / dipole work
+		reduce_forked = c->two_streams && (mask & RUN_FIELD) != 0;
+		hipStream_t s3 = reduce_forked ? fork_side(c) : st;
+		ProfScope p(c, MPMC_K_REDUCE, s3);
+		launch_reduce_pairs(s3, c->d_block_part, c->d_block_cnt, c->n_tile_pairs, c->d_scal, c->d_cnt);
+	}
+
+	// ---- static field ---------------------------------------------------------------------------------------
+	if (mask & RUN_FIELD) {
+		ProfScope p(c, MPMC_K_FIELD);
+		c->mu_cur = 0;
+		launch_field_finalize(st, at, c->box, o.polar_ewald, c->d_e_recip_part, c->d_part, c->n_tiles, o.polar_gamma, c->d_e_static,
+		                      c->d_mu[0]);
+	}
+
+	// ---- thole_iterative, reference src/System.Energy.cpp:3450-3543 ------------------------------------------------
+	c->solve_deferred = false;
+	c->last_batch = 1;
+	if ((mask & RUN_SOLVE) && c->defer_solve && compact && c->jacobi_hybrid && o.polar_precision == 0.0 && !o.polar_gs) {
+		// fixed iteration count, stored-tensor single-launch Jacobi: the caller runs the iterations of several systems together
+		if (reduce_forked) join_side(c);
+		if (!c->ev_phase) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_phase, hipEventDisableTiming));
+		HIP_TRY(c, hipEventRecord(c->ev_phase, st));
+		HIP_TRY(c, hipGetLastError());
+		c->solve_deferred = true;
+		return MPMC_OK;
+	}
+	if (mask & RUN_SOLVE) {
+		const bool by_precision = (o.polar_precision != 0.0);
+		const int want_rrms = (o.polar_rrms || o.polar_precision > 0) ? 1 : 0;
+		const double allowed = by_precision ? o.polar_precision * o.polar_precision * kDebye2SKA * kDebye2SKA : 0.0;
+		const bool dense = (c->solver_used == MPMC_SOLVER_DENSE) && !o.polar_gs;
+		constexpr int kDenseChunks = 16;
+		const int iter_slots = dense ? kDenseChunks : c->n_tiles;
+		if (dense) { // thole_amatrix into device memory, once per evaluation (the positions changed)
+			ProfScope p(c, MPMC_K_TENSOR);
+			launch_dense_build(st, at, c->box, o.polar_damp, c->d_adense);
+		}
+		int it = 0;
+		bool keep = true;
+		while (keep) {
+			it++;
+			if (it >= kMaxIterationCount && by_precision) { // divergence: mu = alpha E0, iterator_failed (:3483-3494)
+				launch_dipole_reset(st, at, c->d_e_static, c->d_mu[c->mu_cur]);
+				c->failed = 1;
+				break;
+			}
+			if (by_precision) HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
+			if (o.polar_gs) { // in-place sweep in atom order; old_mu is kept only when rrms / precision need it (:3503-3507)
+				double *mu = c->d_mu[c->mu_cur], *mu_old = c->d_mu[1 - c->mu_cur];
+				if (want_rrms) HIP_TRY(c, hipMemcpyAsync(mu_old, mu, 3 * (size_t)at.n_pad * sizeof(double), hipMemcpyDeviceToDevice, st));
+				{
+					ProfScope p(c, MPMC_K_DIPOLE_ITER);
+					launch_gs_sweep(st, at, c->box, o.polar_damp, c->d_e_static, mu, c->d_e_induced, c->d_part);
+				}
+				if (want_rrms) {
+					ProfScope p(c, MPMC_K_REDUCE);
+					launch_gs_finish(st, at, mu_old, mu, want_rrms, c->d_rrms, allowed, c->d_flag);
+				}
+				if (by_precision) {
+					HIP_TRY(c, hipMemcpyAsync(c->h_flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+					HIP_TRY(c, hipStreamSynchronize(st));
+					keep = (*c->h_flag != 0);
+				} else {
+					keep = (it != o.polar_max_iter);
+				}
+				continue;
+			}
+			if (dense) {
+				ProfScope p(c, MPMC_K_DIPOLE_ITER);
+				launch_dense_matvec(st, c->d_adense, c->n_pad, c->d_mu[c->mu_cur], kDenseChunks, c->d_part);
+			} else if (compact && c->jacobi_hybrid) {
+				ProfScope p(c, MPMC_K_DIPOLE_ITER);
+				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
+				                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part, o.polar_damp);
+			} else if (compact) {
+				const int *counts = c->d_lists + 2 * (size_t)c->n_tile_pairs;
+				hipStream_t s2 = fork_side(c); // the fp64-bound far-field kernel runs beside the HBM-bound streaming kernel
+				{
+					ProfScope p(c, MPMC_K_DIPOLE_FAR, s2);
+					launch_dipole_iter_far(s2, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_lists, counts, c->n_tile_pairs, c->d_part);
+				}
+				{
+					ProfScope p(c, MPMC_K_DIPOLE_ITER);
+					launch_dipole_iter_stream(st, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_lists, counts, c->n_tile_pairs,
+					                          c->d_ab, c->d_part);
+				}
+				join_side(c);
+			} else { // matrix-free: the same symmetric tile-pair walk with nothing stored (null store => damped tensors rebuilt)
+				ProfScope p(c, MPMC_K_DIPOLE_ITER);
+				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
+				                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, nullptr, c->d_part, o.polar_damp);
+			}
+			{
+				ProfScope p(c, MPMC_K_REDUCE);
+				launch_dipole_update(st, at, c->d_e_static, c->d_part, iter_slots, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur], c->d_e_induced,
+				                     want_rrms, c->d_rrms, allowed, c->d_flag);
+			}
+			c->mu_cur = 1 - c->mu_cur;
+			if (by_precision) { // are_we_done_yet needs the verdict on the host
+				HIP_TRY(c, hipMemcpyAsync(c->h_flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+				HIP_TRY(c, hipStreamSynchronize(st));
+				keep = (*c->h_flag != 0);
+			} else {
+				keep = (it != o.polar_max_iter);
+			}
+		}
+		c->iters = it;
+		{
+			ProfScope p(c, MPMC_K_REDUCE);
+			launch_polar_energy(st, at, c->d_mu[c->mu_cur], c->d_e_static, want_rrms ? c->d_rrms : nullptr, c->d_scal);
+		}
+		c->have_polar = true;
+	}
+	if (reduce_forked) join_side(c);
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipMemcpyAsync(c->h_scal, c->d_scal, (S_COUNT + C_COUNT) * sizeof(double), hipMemcpyDeviceToHost, st));
+	c->pending = true;
+	return MPMC_OK;
+}
+
+
+int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
+	if (!c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_energy_wait: nothing enqueued");
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->sync_stream ? c->sync_stream : c->stream));
+	c->sync_stream = nullptr;
+	c->pending = false;
+	prof_harvest(c);
+	if (!out) return MPMC_OK;
+	std::memset(out, 0, sizeof(*out));
+	const double *s = c->h_scal;
+	out->lj_pairs = s[S_LJ];
+	out->lrc_pair = s[S_LRC_PAIR];
+	out->lrc_self = s[S_LRC_SELF];
+	out->rd_energy = (s[S_LJ] + s[S_LRC_PAIR]) + s[S_LRC_SELF];
+	out->es_real = s[S_ES_REAL] - s[S_ES_INTRA];
+	out->es_recip = s[S_ES_RECIP];
+	out->es_self = s[S_ES_SELF];
+	out->coulombic_energy = (out->es_real + out->es_recip) + out->es_self; // coulombic() :1412
+	out->polarization_energy = s[S_POLAR];
+	out->dipole_rrms = s[S_RRMS];
+	out->energy = out->rd_energy + out->coulombic_energy + out->polarization_energy + out->vdw_energy + out->three_body_energy; // :136
+	out->N = c->N_movable;
+	out->NU = out->N * out->energy; // :162
+	out->n_pairs = (int64_t)c->n * (c->n - 1) / 2;
+	out->n_lj_in_cutoff = c->h_cnt[C_LJ_IN];
+	out->n_es_in_cutoff = c->h_cnt[C_ES_IN];
+	out->n_intra = c->static_cnt[0];
+	out->n_rd_excluded = c->static_cnt[1];
+	out->n_es_excluded = c->static_cnt[2];
+	out->n_frozen = c->static_cnt[3];
+	out->polar_iterations = c->iters;
+	out->iterator_failed = c->failed;
+	if (c->run_mask == full_mask(c)) { // a complete energy(): it re-bases the trial-move totals
+		c->last_full = *out;
+		c->cache_valid = true;
+	}
+	return MPMC_OK;
+}
+
+unsigned mpmc::full_mask(const mpmc_ctx *c) {
+	unsigned m = RUN_PAIR | RUN_ATOMTERMS;
+	if (!c->opts.rd_only) {
+		m |= RUN_PAIR_ES;
+		m |= c->opts.wolf ? RUN_WOLF : RUN_RECIP; // coulombic() :1404-1413: Wolf replaces real + reciprocal + self
+		if (c->opts.polarization) m |= RUN_FIELD | RUN_SOLVE;
+	}
+	return m;
+}
+
+extern "C" int mpmc_energy_async(mpmc_ctx *c) {
+	if (!c) return MPMC_ERR_ARG;
+	return enqueue(c, full_mask(c));
+}
+extern "C" int mpmc_energy_wait(mpmc_ctx *c, mpmc_result *out) {
+	if (!c) return MPMC_ERR_ARG;
+	return wait_and_fill(c, out);
+}
+extern "C" int mpmc_energy(mpmc_ctx *c, mpmc_result *out) {
+	if (!c || !out) return MPMC_ERR_ARG;
+	int rc = enqueue(c, full_mask(c));
+	if (rc != MPMC_OK) return rc;
+	return wait_and_fill(c, out);
+}
+
+
+// ---- component entry points --------------------------------------------------------------------------------
+static int run_piece(mpmc_ctx *c, unsigned mask, mpmc_result *r) {
+	if (!c) return MPMC_ERR_ARG;
+	int rc = enqueue(c, mask);
+	if (rc != MPMC_OK) return rc;
+	return wait_and_fill(c, r);
+}
+extern "C" int mpmc_lj(mpmc_ctx *c, double *out) {
+	mpmc_result r;
+	int rc = run_piece(c, RUN_PAIR | RUN_ATOMTERMS, &r);
+	if (rc == MPMC_OK && out) *out = r.rd_energy;
+	return rc;
+}
+extern "C" int mpmc_coulombic_real(mpmc_ctx *c, double *out) {
+	mpmc_result r;
+	int rc = run_piece(c, RUN_PAIR | RUN_PAIR_ES, &r);
+	if (rc == MPMC_OK && out) *out = r.es_real;
+	return rc;
+}
+extern "C" int mpmc_coulombic_reciprocal(mpmc_ctx *c, double *out) {
+	mpmc_result r;
+	int rc = run_piece(c, RUN_RECIP, &r);
+	if (rc == MPMC_OK && out) *out = r.es_recip;
+	return rc;
+}
+extern "C" int mpmc_coulombic_self(mpmc_ctx *c, double *out) {
+	mpmc_result r;
+	int rc = run_piece(c, RUN_RECIP, &r);
+	if (rc == MPMC_OK && out) *out = r.es_self;
+	return rc;
+}
+extern "C" int mpmc_coulombic(mpmc_ctx *c, double *out) {
+	if (!c) return MPMC_ERR_ARG;
+	mpmc_result r;
+	int rc = run_piece(c, RUN_PAIR | RUN_PAIR_ES | (c->opts.wolf ? RUN_WOLF : RUN_RECIP), &r);
+	if (rc == MPMC_OK && out) *out = r.coulombic_energy;
+	return rc;
+}
+extern "C" int mpmc_polar(mpmc_ctx *c, double *out) {
+	if (!c) return MPMC_ERR_ARG;
+	if (!c->opts.polarization) return fail(c, MPMC_ERR_INVALID_SETTING, "mpmc_polar: polarization is off");
+	mpmc_result r;
+	int rc = run_piece(c, RUN_FIELD | RUN_SOLVE, &r);
+	if (rc == MPMC_OK && out) *out = r.polarization_energy;
+	return rc;
+}
+// device per-atom vectors are in slot order; everything handed to the caller is in original atom order
+static int fetch_atoms3(mpmc_ctx *c, const double *d_src, double *out) {
+	std::vector<double> tmp(3 * (size_t)c->n);
+	HIP_TRY(c, hipMemcpy(tmp.data(), d_src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+	for (int k = 0; k < c->n; k++) {
+		const int i = c->perm[k];
+		out[3 * (size_t)i] = tmp[3 * (size_t)k];
+		out[3 * (size_t)i + 1] = tmp[3 * (size_t)k + 1];
+		out[3 * (size_t)i + 2] = tmp[3 * (size_t)k + 2];
+	}
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_thole_field(mpmc_ctx *c, double *ef_static) {
+	if (!c) return MPMC_ERR_ARG;
+	mpmc_result r;
+	int rc = run_piece(c, RUN_FIELD, &r);
+	if (rc != MPMC_OK) return rc;
+	if (ef_static) return fetch_atoms3(c, c->d_e_static, ef_static);
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_thole_amatrix(mpmc_ctx *c, int row0, int nrows, double *a) {
+	if (!c || !a || row0 < 0 || nrows <= 0) return MPMC_ERR_ARG;
+	int rc = prepare(c);
+	if (rc != MPMC_OK) return rc;
+	if (row0 % 3 || nrows % 3 || row0 + nrows > 3 * c->n) return fail(c, MPMC_ERR_ARG, "mpmc_thole_amatrix: rows must cover whole atoms (multiples of 3) inside 3N");
+	const size_t need = (size_t)nrows * 3 * c->n;
+	if (need > c->cap_arows) {
+		dev_free(c, &c->d_arows, c->cap_arows);
+		c->cap_arows = 0;
+		if ((rc = dev_alloc(c, &c->d_arows, need)) != MPMC_OK) return rc;
+		c->cap_arows = need;
+	}
+	{
+		ProfScope p(c, MPMC_K_TENSOR);
+		launch_amatrix_rows(c->stream, atoms_view(c), c->d_slot_of, c->box, c->opts.polar_damp, row0, nrows, c->d_arows);
+	}
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipMemcpyAsync(a, c->d_arows, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	prof_harvest(c);
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_get_dipoles(mpmc_ctx *c, double *mu, double *ef_static, double *ef_induced) {
+	if (!c) return MPMC_ERR_ARG;
+	if (!c->d_e_static) return fail(c, MPMC_ERR_ARG, "mpmc_get_dipoles: no polarization evaluation has run");
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	int rc = MPMC_OK;
+	if (mu && rc == MPMC_OK) rc = fetch_atoms3(c, c->d_mu[c->mu_cur], mu);
+	if (ef_static && rc == MPMC_OK) rc = fetch_atoms3(c, c->d_e_static, ef_static);
+	if (ef_induced && rc == MPMC_OK) rc = fetch_atoms3(c, c->d_e_induced, ef_induced);
+	return rc;
+}
+
+// update_com + wrap_all, reference src/System.cpp:1347-1425 (host side: O(N), consumed by I/O only)
+extern "C" int mpmc_update_com(mpmc_ctx *c, double *com, double *wrapped_com, double *wrapped_pos, int *n_molecules) {
+	if (!c) return MPMC_ERR_ARG;
+	if (!c->atoms_set || !c->box_set) return fail(c, MPMC_ERR_ARG, "mpmc_update_com: atoms and box must be set");
+	if (c->h_mass.empty()) return fail(c, MPMC_ERR_ARG, "mpmc_update_com: mpmc_set_atoms was called without masses");
+	if (n_molecules) *n_molecules = c->n_molecules;
+	int m = 0;
+	for (int i0 = 0; i0 < c->n;) {
+		int i1 = i0;
+		while (i1 + 1 < c->n && c->h_mol[i1 + 1] == c->h_mol[i0]) i1++;
+		double cm[3] = {0, 0, 0}, mass = 0;
+		for (int i = i0; i <= i1; i++) {
+			mass += c->h_mass[i];
+			for (int p = 0; p < 3; p++) cm[p] += c->h_mass[i] * c->h_pos[3 * i + p];
+		}
+		for (int p = 0; p < 3; p++) cm[p] /= mass;
+		const bool mol_frozen = c->h_frozen[i1] != 0;
+		double w[3] = {0, 0, 0};
+		if (!mol_frozen) {
+			double d[3];
+			for (int p = 0; p < 3; p++) {
+				d[p] = 0;
+				for (int q = 0; q < 3; q++) d[p] += c->box.r[3 * q + p] * cm[q];
+				d[p] = std::rint(d[p]);
+			}
+			for (int p = 0; p < 3; p++) {
+				w[p] = 0;
+				for (int q = 0; q < 3; q++) w[p] += c->box.b[3 * q + p] * d[q];
+			}
+		}
+		if (com)
+			for (int p = 0; p < 3; p++) com[3 * m + p] = cm[p];
+		if (wrapped_com)
+			for (int p = 0; p < 3; p++) wrapped_com[3 * m + p] = w[p]; // the reference stores the lattice shift here (:1404)
+		if (wrapped_pos)
+			for (int i = i0; i <= i1; i++)
+				for (int p = 0; p < 3; p++) wrapped_pos[3 * i + p] = mol_frozen ? c->h_pos[3 * i + p] : c->h_pos[3 * i + p] - w[p];
+		m++;
+		i0 = i1 + 1;
+	}
+	return MPMC_OK;
+}

@@ -1,0 +1,200 @@
+// trial.cpp -- per-move delta energies (mpmc_trial_*): the device-side counterpart of the reference's per-pair cache
+// (part of libmpmc_energy.so; shared state and helpers: context.h.  There is no CPU fallback anywhere in this library.)
+#include "context.h"
+
+
+using namespace mpmc;
+
+// ---- trial moves -----------------------------------------------------------------------------------------------
+constexpr size_t kMvBlobBytes = MPMC_TRIAL_MAX_ATOMS * (2 * sizeof(int) + sizeof(double4));
+static int ensure_trial_buffers(mpmc_ctx *c) {
+	int rc;
+	if (!c->d_mv_blob) {
+		if ((rc = dev_alloc(c, &c->d_mv_blob, kMvBlobBytes)) != MPMC_OK) return rc;
+		c->d_mv_new = reinterpret_cast<double4 *>(c->d_mv_blob); // 32-byte records first (alignment), then the two int lists
+		c->d_mv_slot = reinterpret_cast<int *>(c->d_mv_blob + MPMC_TRIAL_MAX_ATOMS * sizeof(double4));
+		c->d_mv_orig = c->d_mv_slot + MPMC_TRIAL_MAX_ATOMS;
+		if ((rc = dev_alloc(c, &c->d_moved_idx, (size_t)c->max_pad)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_delta_out, (size_t)8)) != MPMC_OK) return rc; // 5 doubles + 2 int64 counts
+		c->d_delta_cnt = reinterpret_cast<long long *>(c->d_delta_out + 5);
+		HIP_TRY(c, hipMemset(c->d_moved_idx, 0xff, (size_t)c->max_pad * sizeof(int))); // all -1
+		HIP_TRY(c, hipHostMalloc((void **)&c->h_delta_out, 8 * sizeof(double)));
+		c->h_delta_cnt = reinterpret_cast<long long *>(c->h_delta_out + 5);
+		HIP_TRY(c, hipHostMalloc((void **)&c->h_mv_blob, kMvBlobBytes));
+	}
+	if (c->K > c->cap_sf_trial) {
+		dev_free(c, &c->d_sf_trial, (size_t)c->cap_sf_trial);
+		c->cap_sf_trial = 0;
+		if ((rc = dev_alloc(c, &c->d_sf_trial, (size_t)std::max(c->K, 1))) != MPMC_OK) return rc;
+		c->cap_sf_trial = std::max(c->K, 1);
+	}
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_trial_begin(mpmc_ctx *c, int first, int count, const double *new_pos) {
+	if (!c || !new_pos || first < 0 || count <= 0) return MPMC_ERR_ARG;
+	if (!c->atoms_set || first + count > c->n) return fail(c, MPMC_ERR_ARG, "mpmc_trial_begin: range outside the atom list");
+	if (c->trial_open) return fail(c, MPMC_ERR_ARG, "mpmc_trial_begin: a trial move is already open (accept or reject it first)");
+	if (!c->cache_valid) return fail(c, MPMC_ERR_ARG, "mpmc_trial_begin: no accepted configuration (call mpmc_energy first)");
+	for (int t = 0; t < 3 * count; t++)
+		if (!std::isfinite(new_pos[t])) return fail(c, MPMC_ERR_INVALID_DATUM, "mpmc_trial_begin: non-finite position");
+	c->trial_first = first;
+	c->trial_count = count;
+	c->trial_new.assign(new_pos, new_pos + 3 * (size_t)count);
+	c->trial_old.assign(c->h_pos.begin() + 3 * (size_t)first, c->h_pos.begin() + 3 * (size_t)(first + count));
+	c->trial_open = true;
+	c->trial_evaluated = false;
+	c->trial_enqueued = false;
+	// a "move" that leaves every coordinate as it is (e.g. the box a two-box move does not touch): the trial totals ARE the accepted
+	// totals, nothing is evaluated.  (The reference's bead moves re-centre the whole chain, so they do touch every image.)
+	c->trial_noop = (std::memcmp(new_pos, c->h_pos.data() + 3 * (size_t)first, 3 * (size_t)count * sizeof(double)) == 0);
+	return MPMC_OK;
+}
+
+// the two halves of mpmc_trial_energy: everything up to the last enqueue, then the wait + host arithmetic (P images of a
+// path-integral move overlap on the device when a driver enqueues all of them before the first wait)
+extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
+	if (!c) return MPMC_ERR_ARG;
+	if (!c->trial_open) return fail(c, MPMC_ERR_ARG, "mpmc_trial_energy: no trial move is open");
+	if (c->trial_enqueued) return fail(c, MPMC_ERR_ARG, "mpmc_trial_energy_async: already enqueued");
+	if (c->trial_noop) {
+		c->trial_was_full = false;
+		c->trial_enqueued = true;
+		return MPMC_OK;
+	}
+	const mpmc_options &o = c->opts;
+	const bool polar = o.polarization && !o.rd_only;
+	const int m = c->trial_count;
+	if (polar || m > MPMC_TRIAL_MAX_ATOMS || o.wolf || o.feynman_hibbs) { // (the delta kernels carry the base LJ + Ewald terms only)
+		// the dipole solve couples every atom: evaluate the trial configuration in full (still on the device)
+		c->trial_keep = c->last_full;
+		int rc = mpmc_update_positions(c, c->trial_first, m, c->trial_new.data());
+		if (rc != MPMC_OK) return rc;
+		if ((rc = mpmc_energy_async(c)) != MPMC_OK) return rc;
+		c->trial_was_full = true;
+		c->trial_enqueued = true;
+		return MPMC_OK;
+	}
+	int rc = prepare(c);
+	if (rc != MPMC_OK) return rc;
+	if ((rc = ensure_trial_buffers(c)) != MPMC_OK) return rc;
+	hipStream_t st = c->stream;
+	{ // one pinned staging record, one host-to-device copy
+		double4 *nw = reinterpret_cast<double4 *>(c->h_mv_blob);
+		int *slots = reinterpret_cast<int *>(c->h_mv_blob + MPMC_TRIAL_MAX_ATOMS * sizeof(double4));
+		int *origs = slots + MPMC_TRIAL_MAX_ATOMS;
+		for (int t = 0; t < m; t++) {
+			const int i = c->trial_first + t;
+			origs[t] = i;
+			slots[t] = c->slot_of[i];
+			nw[t] = make_double4(c->trial_new[3 * t], c->trial_new[3 * t + 1], c->trial_new[3 * t + 2], c->h_q[i]);
+		}
+		HIP_TRY(c, hipMemcpyAsync(c->d_mv_blob, c->h_mv_blob, kMvBlobBytes, hipMemcpyHostToDevice, st));
+	}
+	const int do_es = o.rd_only ? 0 : 1;
+	{
+		ProfScope p(c, MPMC_K_PAIR);
+		launch_delta(st, atoms_view(c), c->d_slot_of, c->box, recip_view(c), c->ewald_alpha, do_es, c->d_mv_slot, c->d_mv_orig, c->d_mv_new, m,
+		             c->d_moved_idx, c->d_sf_trial, c->d_block_part, c->d_block_cnt, c->d_delta_out, c->d_delta_cnt);
+	}
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipMemcpyAsync(c->h_delta_out, c->d_delta_out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+	c->trial_was_full = false;
+	c->trial_enqueued = true;
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_trial_energy_wait(mpmc_ctx *c, mpmc_result *out) {
+	if (!c || !out) return MPMC_ERR_ARG;
+	if (!c->trial_open || !c->trial_enqueued) return fail(c, MPMC_ERR_ARG, "mpmc_trial_energy_wait: nothing enqueued");
+	c->trial_enqueued = false;
+	if (c->trial_noop) {
+		c->trial_res = c->last_full;
+		c->trial_evaluated = true;
+		*out = c->trial_res;
+		return MPMC_OK;
+	}
+	if (c->trial_was_full) {
+		int rc = mpmc_energy_wait(c, out);
+		if (rc != MPMC_OK) return rc;
+		c->trial_res = *out;
+		c->last_full = c->trial_keep; // still the ACCEPTED configuration's totals until mpmc_trial_accept
+		c->trial_evaluated = true;
+		return MPMC_OK;
+	}
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	prof_harvest(c);
+	const int do_es = c->opts.rd_only ? 0 : 1;
+	const mpmc_result &a = c->last_full;
+	mpmc_result r = a;
+	r.lj_pairs = a.lj_pairs + c->h_delta_out[0];
+	r.rd_energy = (r.lj_pairs + r.lrc_pair) + r.lrc_self;
+	r.n_lj_in_cutoff = a.n_lj_in_cutoff + c->h_delta_cnt[0];
+	if (do_es) {
+		r.es_real = a.es_real + (c->h_delta_out[1] - c->h_delta_out[2]);
+		r.es_recip = c->h_delta_out[3];
+		r.coulombic_energy = (r.es_real + r.es_recip) + r.es_self;
+		r.n_es_in_cutoff = a.n_es_in_cutoff + c->h_delta_cnt[1];
+	}
+	r.energy = r.rd_energy + r.coulombic_energy + r.polarization_energy + r.vdw_energy + r.three_body_energy;
+	r.NU = r.N * r.energy;
+	c->trial_res = r;
+	c->trial_evaluated = true;
+	*out = r;
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_trial_energy(mpmc_ctx *c, mpmc_result *out) {
+	if (!c || !out) return MPMC_ERR_ARG;
+	int rc = mpmc_trial_energy_async(c);
+	if (rc != MPMC_OK) return rc;
+	return mpmc_trial_energy_wait(c, out);
+}
+
+extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
+	if (!c) return MPMC_ERR_ARG;
+	if (!c->trial_open || !c->trial_evaluated) return fail(c, MPMC_ERR_ARG, "mpmc_trial_accept: no evaluated trial move");
+	HIP_TRY(c, hipSetDevice(c->device));
+	const int m = c->trial_count;
+	if (c->trial_noop) {
+		c->trial_open = false;
+		return MPMC_OK;
+	}
+	if (!c->trial_was_full) {
+		launch_commit_positions(c->stream, c->d_xyzq, c->d_mv_slot, c->d_mv_new, m);
+		HIP_TRY(c, hipGetLastError());
+		std::swap(c->d_sf, c->d_sf_trial); // the trial structure factors become the accepted ones
+		std::swap(c->cap_K, c->cap_sf_trial);
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		for (int t = 0; t < 3 * m; t++) c->h_pos[3 * (size_t)c->trial_first + t] = c->trial_new[t];
+	}
+	c->last_full = c->trial_res;
+	c->cache_valid = true;
+	c->trial_open = false;
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_trial_reject(mpmc_ctx *c) {
+	if (!c) return MPMC_ERR_ARG;
+	if (!c->trial_open) return fail(c, MPMC_ERR_ARG, "mpmc_trial_reject: no trial move is open");
+	if (c->trial_enqueued) { // enqueued but never waited for: drain it first
+		mpmc_result drop;
+		int rc = mpmc_trial_energy_wait(c, &drop);
+		if (rc != MPMC_OK) return rc;
+	}
+	c->trial_open = false;
+	if (c->trial_evaluated && c->trial_was_full) { // the resident configuration is the trial one: put the old positions back
+		const mpmc_result keep = c->last_full;
+		int rc = mpmc_update_positions(c, c->trial_first, c->trial_count, c->trial_old.data());
+		if (rc != MPMC_OK) return rc;
+		c->last_full = keep;
+		c->cache_valid = true;
+		const bool polar = c->opts.polarization && !c->opts.rd_only;
+		if (!polar && !c->opts.wolf) { // the resident structure factors are the trial ones: re-base on the restored configuration
+			mpmc_result tmp;
+			if ((rc = mpmc_energy(c, &tmp)) != MPMC_OK) return rc;
+		}
+	}
+	return MPMC_OK;
+}

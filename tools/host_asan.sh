@@ -1,6 +1,6 @@
 #!/bin/bash
-# Host-side AddressSanitizer + UBSan over csrc/context.cpp (the 1700 lines of pointer work above the kernels): the kernels are compiled as
-# usual, context.cpp by g++ with -fsanitize=address,undefined, linked into mpmcxx_amd/libmpmc_energy_asan.so.  Device code is NOT
+# Host-side AddressSanitizer + UBSan over the host translation units (csrc/context.cpp, evaluate.cpp, trial.cpp, pi.cpp: the 1800 lines of
+# pointer work above the kernels): the kernels are compiled as usual, the host files by g++ with -fsanitize=address,undefined, linked into mpmcxx_amd/libmpmc_energy_asan.so.  Device code is NOT
 # instrumented (GPU ASan / xnack+ are not available on the pool).
 #   here:      bash tools/host_asan.sh build
 #   GPU box:   gpurun -- 'bash tools/host_asan.sh run'      -> gpurun_out/asan_tests.log, gpurun_out/*san_report* (none = clean)
@@ -11,8 +11,10 @@ if [ "$1" = build ]; then
 	for f in kernels kernels_sym kernels_delta kernels_gs kernels_dense; do
 		/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-function -c $root/mpmcxx_amd/csrc/$f.hip -o $tmp/$f.o &
 	done
-	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$root/include \
-		-c $root/mpmcxx_amd/csrc/context.cpp -o $tmp/context.o
+	for f in context evaluate trial pi; do
+		g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$root/include \
+			-c $root/mpmcxx_amd/csrc/$f.cpp -o $tmp/host_$f.o &
+	done
 	wait
 	g++ -shared -fPIC -fsanitize=address,undefined $tmp/*.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -o $root/mpmcxx_amd/libmpmc_energy_asan.so
 	echo built $root/mpmcxx_amd/libmpmc_energy_asan.so
