@@ -69,3 +69,26 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "mpmc_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_library_keeps_its_internals_out_of_the_global_namespace():
+    """Everything the library defines is either a C-ABI entry point (mpmc_*), mangled inside namespace mpmc, a template instantiation of
+    the standard library (weak), or HIP's own registration data -- a host program's `prepare` or `fail` cannot collide with ours.  Also:
+    bench.py reaches into oracle/ only inside its CPU-baseline leg."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", mbuild.build_library()], stdout=subprocess.PIPE, text=True, check=True).stdout
+    strays = []
+    for line in out.splitlines():
+        parts = line.split()
+        kind, name = parts[-2], parts[-1]
+        if name.startswith(("mpmc_", "_ZN4mpmc", "_ZNK4mpmc", "_ZTHN4mpmc", "_ZTWN4mpmc", "__hip_")) or kind in ("W", "V", "u"):
+            continue
+        if "4mpmc" in name:  # kernels and their stubs: templates over mpmc:: types
+            continue
+        strays.append(line)
+    assert not strays, strays
+    src = open(os.path.join(util.ROOT, "bench.py")).read()
+    head, leg = src.split("def cpu_baseline(", 1)
+    leg_body, rest = leg.split("\ndef main(", 1)
+    assert "from oracle import" not in head and "from oracle import" not in rest and "import oracle" not in rest
