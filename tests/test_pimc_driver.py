@@ -85,6 +85,10 @@ def test_driver_refuses_what_it_does_not_cover(pimc_check, tmp_path):
     p.write_text(src.replace("PI_trial_chain_length          4", "PI_trial_chain_length 8").replace("Ar-Ar-4A.pqr", os.path.join(util.GOLDEN, "pi001", "Ar-Ar-4A.pqr")))
     out = subprocess.run([pimc_check, str(p), "8", str(tmp_path)], stdout=subprocess.PIPE, text=True)
     assert out.returncode == 1 and json.loads(out.stdout)["error"] == 4001  # invalid_setting: chain length must be in [1, P-1]
+    p = tmp_path / "orient.in"
+    p.write_text(src.replace("Ar-Ar-4A.pqr", os.path.join(util.GOLDEN, "pi001", "Ar-Ar-4A.pqr")) + "\nsorbate_bondlength Ar 0.742\n")
+    out = subprocess.run([pimc_check, str(p), "8", str(tmp_path)], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 1 and json.loads(out.stdout)["error"] == 4004  # orientational bead moves are refused, not silently skipped
     out = subprocess.run([pimc_check, os.path.join(util.GOLDEN, "pi001", "equilibrate.in"), "6", str(tmp_path)], stdout=subprocess.PIPE, text=True)
     assert out.returncode == 1 and json.loads(out.stdout)["error"] == 9003  # the Trotter number must be a power of two >= 4
 
