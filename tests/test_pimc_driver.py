@@ -21,6 +21,7 @@ CASES = {
     # name: (input file, P, job name, expected acceptance: (AR, displace, bead))
     "pi001": ("equilibrate.in", 8, "ArAr2K"),
     "pi_ion27": ("input.in", 4, "ion27"),
+    "pi_h2": ("input.in", 4, "h2pi"),  # 8 rigid diatomics (LJ sites): the quaternion rotation of PI_displace, rigid translation in the bead moves
     "pi_ion1000": ("input.in", 4, "ion1000"),  # 1000 polarizable ions, 12 steps: rows and acceptance rates only (no final geometries kept)
 }
 LIBDIR = os.path.join(util.ROOT, "mpmcxx_amd")
