@@ -86,3 +86,17 @@ def test_pi_1000_ion_box_stock_driver_checks_every_call(tmp_path):
     p = run_case(tmp_path, "pi_ion1000", "input.in", 4, "both")
     compare_energy_dat(os.path.join(tmp_path, "ion1000.energy.dat"), os.path.join(util.GOLDEN, "pi_ion1000", "golden_energy.dat"), 1e-9)
     assert "MISMATCH" not in p.stderr
+
+
+@pytest.mark.parametrize("mode", ["gpu", "both"])
+@pytest.mark.parametrize("case,job", [("pi_h2", "h2pi"), ("pi_water64", "water64")])
+def test_pi_molecular_boxes_through_the_stock_driver(tmp_path, case, job, mode):
+    """Rigid molecules through the stock driver (rotation + translation moves, wrapall): 8 LJ diatomics, and 64 three-site polarizable
+    molecules with a neutral polarizable atom (intramolecular exclusions, the erf form of the field for chargeless partners, Ewald,
+    Thole).  In mode `both` the reference evaluates every configuration too and the adapter aborts on a 1e-9 difference."""
+    p = run_case(tmp_path, case, "input.in", 4, mode)
+    compare_energy_dat(os.path.join(tmp_path, f"{job}.energy.dat"), os.path.join(util.GOLDEN, case, "golden_energy.dat"), 1e-9)
+    assert "MISMATCH" not in p.stderr
+    gold = open(os.path.join(util.GOLDEN, case, "golden_final_averages.txt")).read().strip().splitlines()
+    for line in gold[-4:]:
+        assert line in p.stdout, line

@@ -22,6 +22,7 @@ CASES = {
     "pi001": ("equilibrate.in", 8, "ArAr2K"),
     "pi_ion27": ("input.in", 4, "ion27"),
     "pi_h2": ("input.in", 4, "h2pi"),  # 8 rigid diatomics (LJ sites): the quaternion rotation of PI_displace, rigid translation in the bead moves
+    "pi_water64": ("input.in", 4, "water64"),  # 64 rigid 3-site polarizable molecules + a neutral atom: exclusions, rotation, Ewald, Thole together
     "pi_ion1000": ("input.in", 4, "ion1000"),  # 1000 polarizable ions, 12 steps: rows and acceptance rates only (no final geometries kept)
 }
 LIBDIR = os.path.join(util.ROOT, "mpmcxx_amd")
