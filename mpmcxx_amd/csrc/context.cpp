@@ -486,14 +486,14 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 		if ((rc = dev_alloc(c, &c->d_cls, ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_tp_shift, ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_lists, 2 * ntp + 2)) != MPMC_OK) return rc;
-		HIP_TRY(c, hipMemset(c->d_cls, 0, ntp * sizeof(int)));
 		c->cap_tile_pairs = ntp;
 	}
 	std::vector<int2> tp;
 	tp.reserve(ntp);
 	for (int I = 0; I < nt; I++)
 		for (int J = I; J < nt; J++) tp.push_back(make_int2(I, J));
-	HIP_TRY(c, hipMemcpy(c->d_tile_pairs, tp.data(), ntp * sizeof(int2), hipMemcpyHostToDevice));
+	HIP_TRY(c, hipMemcpyAsync(c->d_tile_pairs, tp.data(), ntp * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream)); // `tp` dies with this function
 	c->n_tile_pairs = (int)ntp;
 
 	// j-range split of the per-atom (row) kernels: aim for >= ~4096 one-wave blocks
@@ -601,7 +601,8 @@ extern "C" int mpmc_get_tile_stats(mpmc_ctx *c, int64_t out4[4]) {
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	std::vector<int> cls((size_t)c->n_tile_pairs);
-	HIP_TRY(c, hipMemcpy(cls.data(), c->d_cls, cls.size() * sizeof(int), hipMemcpyDeviceToHost));
+	HIP_TRY(c, hipMemcpyAsync(cls.data(), c->d_cls, cls.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	out4[0] = c->n_tile_pairs;
 	out4[1] = out4[2] = out4[3] = 0;
 	for (int v : cls) {

@@ -165,7 +165,14 @@ namespace mpmc { // internal helpers: mangled names, nothing here can collide wi
 
 template <typename T>
 inline int dev_alloc(mpmc_ctx *c, T **p, size_t count) {
-	HIP_TRY(c, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+	const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+	HIP_TRY(c, hipMalloc((void **)p, bytes));
+	// Every buffer starts from zeros: what a kernel finds in a slot it has not written yet must not depend on what an earlier process
+	// left in that memory.  The fill is WAITED for -- buffers are also allocated in the middle of an evaluation, after the side stream
+	// was forked, and the first writer may be a side-stream kernel that is not ordered behind a fill on the main stream (seen: structure
+	// factors zeroed under the reciprocal-space kernels).  Allocations happen once per context, the wait costs nothing in steady state.
+	HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	c->bytes_total += (int64_t)(count * sizeof(T));
 	return MPMC_OK;
 }

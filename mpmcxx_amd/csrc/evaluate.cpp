@@ -46,10 +46,12 @@ static int build_k_tables(mpmc_ctx *c) {
 		c->cap_K = K;
 	}
 	if (K > 0) {
-		HIP_TRY(c, hipMemcpy(c->d_kvec, kvec.data(), K * sizeof(double4), hipMemcpyHostToDevice));
-		HIP_TRY(c, hipMemcpy(c->d_kw, kw.data(), K * sizeof(double4), hipMemcpyHostToDevice));
-		HIP_TRY(c, hipMemcpy(c->d_lvec, lvec.data(), K * sizeof(int4), hipMemcpyHostToDevice));
-		HIP_TRY(c, hipMemcpy(c->d_w_en, wen.data(), K * sizeof(double), hipMemcpyHostToDevice));
+		// on the context's stream (ordered against whatever it still runs), then waited for: the staging vectors die with this scope
+		HIP_TRY(c, hipMemcpyAsync(c->d_kvec, kvec.data(), K * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_kw, kw.data(), K * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_lvec, lvec.data(), K * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_w_en, wen.data(), K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
 	}
 	c->K = K;
 	return MPMC_OK;
@@ -65,11 +67,8 @@ static int ensure_polar_buffers(mpmc_ctx *c) {
 		if ((rc = dev_alloc(c, &c->d_e_induced, 3 * np)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_rrms, np)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_e_recip_part, (size_t)kKSplit * 3 * np)) != MPMC_OK) return rc;
-		HIP_TRY(c, hipMemset(c->d_e_static, 0, 3 * np * sizeof(double)));
-		HIP_TRY(c, hipMemset(c->d_mu[0], 0, 3 * np * sizeof(double)));
-		HIP_TRY(c, hipMemset(c->d_mu[1], 0, 3 * np * sizeof(double)));
-		HIP_TRY(c, hipMemset(c->d_e_induced, 0, 3 * np * sizeof(double)));
-		HIP_TRY(c, hipMemset(c->d_rrms, 0, np * sizeof(double)));
+		// (dev_alloc zero-fills on the context's stream; nothing in this library touches the null stream, which is unordered against
+		// our non-blocking streams)
 	}
 	// per-atom partial slots: one per source tile (symmetric kernels) -- also covers the n_split <= n_tiles slots
 	// of the matrix-free row kernel
@@ -491,7 +490,8 @@ extern "C" int mpmc_polar(mpmc_ctx *c, double *out) {
 // device per-atom vectors are in slot order; everything handed to the caller is in original atom order
 static int fetch_atoms3(mpmc_ctx *c, const double *d_src, double *out) {
 	std::vector<double> tmp(3 * (size_t)c->n);
-	HIP_TRY(c, hipMemcpy(tmp.data(), d_src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+	HIP_TRY(c, hipMemcpyAsync(tmp.data(), d_src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	for (int k = 0; k < c->n; k++) {
 		const int i = c->perm[k];
 		out[3 * (size_t)i] = tmp[3 * (size_t)k];

@@ -234,6 +234,22 @@ extern "C" double __wrap__ZN6System6energyEv(System *s) {
 		    (s->polarization && r.iterator_failed != ref_failed)) {
 			std::fprintf(stderr, "ref_adapter: MISMATCH at call %ld: gpu %.17g ref %.17g (rd %.17g/%.17g es %.17g/%.17g pol %.17g/%.17g)\n", call,
 			             e_gpu, e_ref, rd, ref_obs.rd_energy, es, ref_obs.coulombic_energy, pol, ref_obs.polarization_energy);
+			{ // diagnostics: is the difference a property of the context's state or of that one evaluation?
+				mpmc_result again, fresh;
+				int rc2 = mpmc_energy(c, &again);
+				std::fprintf(stderr, "ref_adapter:   same context, evaluated again (rc %d): pol %.17g iterations %d (first: %d) fresh_ctx %d\n", rc2,
+				             again.polarization_energy, again.polar_iterations, r.polar_iterations, (int)fresh_ctx);
+				mpmc_ctx *f = nullptr;
+				if (mpmc_ctx_create(device_for(s), n, &f) == MPMC_OK) {
+					mpmc_set_box(f, &s->pbc.basis[0][0], &s->pbc.reciprocal_basis[0][0], s->pbc.volume, s->pbc.cutoff);
+					mpmc_set_options(f, &o);
+					mpmc_set_atoms(f, n, pos.data(), q.data(), alpha.data(), eps.data(), sig.data(), mol.data(), frozen.data(), disp.data(), mass.data());
+					rc2 = mpmc_energy(f, &fresh);
+					std::fprintf(stderr, "ref_adapter:   fresh context (rc %d): pol %.17g rd %.17g es %.17g\n", rc2, fresh.polarization_energy, fresh.rd_energy,
+					             fresh.coulombic_energy);
+					mpmc_ctx_destroy(f);
+				}
+			}
 			std::abort();
 		}
 		*s->observables = ref_obs;
