@@ -9,6 +9,7 @@ for i in $(seq 1 $n); do
   cp $root/tests/golden/pi_ion1000/input.in $root/tests/golden/pi_ion1000/*.pqr $d/
   (cd $d && MPMC_WRAP_MODE=both OMP_NUM_THREADS=$thr timeout 300 $root/oracle/_ref/mpmcxx_wrapped -P 4 input.in > out.log 2> err.log)
   rc=$?
+  [ $((i % 10)) -eq 0 ] && echo "  ... $i runs, $bad failures"
   if [ $rc -ne 0 ]; then bad=$((bad+1)); echo "run $i rc=$rc"; grep -h "ref_adapter" $d/err.log | cut -c1-300; fi
 done
 echo "runs $n, failures $bad"
