@@ -549,9 +549,11 @@ extern "C" int mpmc_update_positions(mpmc_ctx *c, int first, int count, const do
 		return MPMC_OK;
 	}
 	for (int t = 0; t < count; t++) { // the moved atoms keep their slots (the order only matters for speed)
-		const int i = first + t;
-		const double4 v = make_double4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], c->h_q[i]);
-		HIP_TRY(c, hipMemcpyAsync(c->d_xyzq + c->slot_of[i], &v, sizeof(double4), hipMemcpyHostToDevice, c->stream));
+		const int i = first + t, k = c->slot_of[i];
+		// through the slot-ordered host mirror: a later bulk update uploads that mirror as a whole, and the source of an asynchronous
+		// copy has to outlive the call
+		c->h_xyzq[k] = make_double4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], c->h_q[i]);
+		HIP_TRY(c, hipMemcpyAsync(c->d_xyzq + k, &c->h_xyzq[k], sizeof(double4), hipMemcpyHostToDevice, c->stream));
 	}
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return MPMC_OK;
@@ -570,6 +572,10 @@ extern "C" int mpmc_set_positions_device(mpmc_ctx *c, const double *pos_device) 
 	// keep the host mirror coherent (update_com / later partial updates read it)
 	HIP_TRY(c, hipMemcpyAsync(c->h_pos.data(), pos_device, 3 * (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	for (int i = 0; i < c->n; i++) { // ... and the slot-ordered mirror a later bulk mpmc_update_positions uploads as a whole
+		double4 &v = c->h_xyzq[c->slot_of[i]];
+		v.x = c->h_pos[3 * (size_t)i], v.y = c->h_pos[3 * (size_t)i + 1], v.z = c->h_pos[3 * (size_t)i + 2];
+	}
 	return MPMC_OK;
 }
 

@@ -168,6 +168,10 @@ extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
 		std::swap(c->cap_K, c->cap_sf_trial);
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		for (int t = 0; t < 3 * m; t++) c->h_pos[3 * (size_t)c->trial_first + t] = c->trial_new[t];
+		for (int t = 0; t < m; t++) { // the slot-ordered mirror follows (a later bulk position update uploads it as a whole)
+			double4 &v = c->h_xyzq[c->slot_of[c->trial_first + t]];
+			v.x = c->trial_new[3 * t], v.y = c->trial_new[3 * t + 1], v.z = c->trial_new[3 * t + 2];
+		}
 	}
 	c->last_full = c->trial_res;
 	c->cache_valid = true;

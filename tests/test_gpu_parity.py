@@ -123,6 +123,32 @@ def test_bulk_position_update_from_host_buffers():
     S.close()
 
 
+def test_partial_bulk_update_after_small_updates_and_accepted_trials():
+    """A bulk update of PART of the atoms (256 < count < n) uploads the library's slot-ordered host mirror as a whole: atoms outside the
+    range that were moved before -- by a small update, by an accepted trial move, through a device pointer -- must be in that mirror."""
+    S, atoms, basis, opts = make("ion1000_polar")
+    opts_np = dict(opts, polarization=0, polar_iterative=0)
+    S.set_options(opts_np)
+    S.energy()
+    rng = np.random.default_rng(3)
+    pos = atoms["pos"].copy()
+    pos[900:903] += rng.normal(scale=0.1, size=(3, 3))
+    S.update_positions(900, pos[900:903])  # small update outside the later bulk range
+    S.energy()
+    trial = pos[950:951] + 0.15
+    S.trial_energy(950, trial)
+    S.accept()  # accepted delta-energy move, also outside the bulk range
+    pos[950:951] = trial
+    pos[100:500] += rng.normal(scale=0.05, size=(400, 3))
+    S.update_positions(100, pos[100:500])  # 400 atoms: the bulk path
+    e = S.energy()
+    T = energy.System(dict(atoms, pos=pos), basis, opts_np)
+    assert util.close(e, T.energy(), 1e-11)
+    assert int(S.observables["n_lj_in_cutoff"]) == int(T.observables["n_lj_in_cutoff"])
+    S.close()
+    T.close()
+
+
 @pytest.mark.parametrize("solver", ["matrix_free", "compact", "dense"])
 @pytest.mark.parametrize("name", ["ion216_polar", "water64_polar", "ion216_triclinic", "ion1000_polar", "ion216_precision"])
 def test_every_dipole_solver_reproduces_the_reference(name, solver):
