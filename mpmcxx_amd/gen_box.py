@@ -226,6 +226,13 @@ def fixture(name: str):
         return lattice_box(216, 24.0, 7), basis, dict(POLAR_OPTS)
     if name == "ion216_frozen":  # every 5th atom frozen (quirk 4: frozen handling differs per term)
         return lattice_box(216, 24.0, 7, frozen_every=5), cubic(24.0), dict(POLAR_OPTS)
+    if name == "ion216_framework":  # the usual MPMC layout: ONE frozen molecule (150 sites spanning three 64-atom tiles) + 66 mobile atoms
+        rows = lattice_box(216, 24.0, 7)
+        for r in rows[:150]:
+            r.flag, r.mol_id, r.moltype = "F", 1, "MOF"
+        for k, r in enumerate(rows[150:]):
+            r.mol_id = 2 + k
+        return rows, cubic(24.0), dict(POLAR_OPTS)
     if name == "ion216_precision":  # precision-terminated solve
         o = dict(POLAR_OPTS)
         del o["polar_max_iter"]
@@ -285,7 +292,7 @@ def fixture(name: str):
 SMALL_FIXTURES = [
     "ar2", "lj64", "ion64_es", "ion216_polar", "ion216_polar_nopbc", "ion216_triclinic", "ion216_frozen",
     "ion216_precision", "ion216_gamma", "ion216_alpha", "water64_polar", "lj1000", "ion1000_polar",
-    "ion216_wolf", "water64_fh2", "water64_fh4", "ion216_fh4_polar", "ion216_gs", "water64_gs_precision", "ion1000_gs",
+    "ion216_wolf", "water64_fh2", "water64_fh4", "ion216_fh4_polar", "ion216_gs", "water64_gs_precision", "ion1000_gs", "ion216_framework",
 ]
 LARGE_FIXTURES = ["ion10k_es", "ion10k_polar"]
 

@@ -41,7 +41,7 @@ def test_energy_matches_reference_golden(name):
     S.close()
 
 
-@pytest.mark.parametrize("name", ["ion216_polar", "water64_polar", "ion216_triclinic", "ion216_frozen"])
+@pytest.mark.parametrize("name", ["ion216_polar", "water64_polar", "ion216_triclinic", "ion216_frozen", "ion216_framework"])
 def test_component_entry_points_match_oracle(name):
     from oracle import OracleSystem
 

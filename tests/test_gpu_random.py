@@ -226,3 +226,31 @@ def test_random_mid_size_systems(seed):
     opts.update(rd_only=0, polarization=1, polar_iterative=1, polar_damp=float(rng.uniform(1.5, 2.6)), polar_ewald=int(seed != 1),
                 polar_max_iter=int(rng.integers(2, 5)), polar_gs=0)
     check(atoms, basis, opts, f"mid seed {seed} n {n} {cell} {opts}")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_one_big_frozen_framework_molecule_with_mobile_sorbates(seed):
+    """The usual MPMC input: ONE frozen molecule of several hundred charged polarizable sites (a framework: every framework pair is
+    intramolecular AND frozen, the molecule spans many 64-atom tiles) plus mobile molecules of 1-4 sites; also a big MOBILE rigid molecule
+    (seed 3) whose intramolecular pairs cross tile boundaries."""
+    rng = np.random.default_rng(8100 + seed)
+    n_frame = [300, 517, 130, 0][seed]
+    atoms, basis = random_system(rng, n_frame + 150, ["cubic", "ortho", "triclinic", "cubic"][seed])
+    n = len(atoms["charge"])
+    order = np.arange(n)
+    if n_frame:  # the first n_frame atoms become one frozen molecule; keep molecules contiguous and ids dense
+        atoms["mol_id"][:n_frame] = 0
+        atoms["frozen"][:n_frame] = 1
+        atoms["mol_id"][n_frame:] = 1 + np.unique(atoms["mol_id"][n_frame:], return_inverse=True)[1]
+        # a molecule that straddled the cut keeps its frozen flag per atom; make the tail molecules movable
+        atoms["frozen"][n_frame:] = 0
+    else:  # one big mobile molecule of 150 sites
+        atoms["mol_id"][:150] = 0
+        atoms["frozen"][:150] = 0
+        atoms["mol_id"][150:] = 1 + np.unique(atoms["mol_id"][150:], return_inverse=True)[1]
+    atoms["mol_id"] = atoms["mol_id"].astype(np.int32)
+    for mode in ("es", "polar_ewald", "polar_nopbc"):
+        opts = random_options(rng)
+        opts.update(rd_only=0, polarization=int(mode != "es"), polar_iterative=int(mode != "es"), polar_ewald=int(mode == "polar_ewald"),
+                    polar_damp=2.1304, polar_max_iter=6, polar_precision=0.0)
+        check(atoms, basis, opts, (seed, mode))
