@@ -254,3 +254,16 @@ def test_one_big_frozen_framework_molecule_with_mobile_sorbates(seed):
         opts.update(rd_only=0, polarization=int(mode != "es"), polar_iterative=int(mode != "es"), polar_ewald=int(mode == "polar_ewald"),
                     polar_damp=2.1304, polar_max_iter=6, polar_precision=0.0)
         check(atoms, basis, opts, (seed, mode))
+
+
+@pytest.mark.parametrize("kmax", [1, 2, 9, 15, 16, 21])
+def test_reciprocal_space_cutoffs_on_both_sides_of_the_phase_table_limit(kmax):
+    """ewald_kmax up to 15 uses the factorised phase tables in LDS, above that one sincos per (k, atom): both against the oracle, with and
+    without the polarization field (K = 27 ... 19 000 k-vectors)."""
+    rng = np.random.default_rng(9000 + kmax)
+    atoms, basis = random_system(rng, 150, "ortho" if kmax % 2 else "triclinic")
+    for polar in (0, 1):
+        opts = random_options(rng)
+        opts.update(rd_only=0, ewald_kmax=kmax, polarization=polar, polar_iterative=polar, polar_ewald=polar, polar_damp=2.1304, polar_max_iter=4,
+                    polar_precision=0.0)
+        check(atoms, basis, opts, (kmax, polar))

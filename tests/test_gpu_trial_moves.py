@@ -25,7 +25,7 @@ def nonpolar(opts):
 
 
 @pytest.mark.parametrize("name,polar", [("lj64", False), ("ion64_es", False), ("water64_polar", False), ("ion216_triclinic", False),
-                                        ("ion216_frozen", False), ("water64_polar", True)])
+                                        ("ion216_frozen", False), ("water64_polar", True), ("ion216_wolf", False), ("water64_fh2", False)])
 def test_trial_moves_track_full_evaluations(name, polar):
     from oracle import OracleSystem
 
