@@ -209,6 +209,14 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 // ---- box / options ---------------------------------------------------------------------------------------
 extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *reciprocal, double volume, double cutoff) {
 	if (!c || !basis) return MPMC_ERR_ARG;
+	// the same cell again (a caller that hands the box over before every evaluation): nothing to invalidate
+	double in[20];
+	std::memcpy(in, basis, 9 * sizeof(double));
+	if (reciprocal) std::memcpy(in + 9, reciprocal, 9 * sizeof(double));
+	else std::memset(in + 9, 0, 9 * sizeof(double));
+	in[18] = volume;
+	in[19] = cutoff;
+	if (c->box_set && c->box_in_has_recip == (reciprocal != nullptr) && std::memcmp(in, c->box_in, sizeof(in)) == 0) return MPMC_OK;
 	double R[9], vol = 0, cut = 0;
 	int rc = mpmc_pbc_compute(basis, R, &vol, &cut);
 	if (rc != MPMC_OK) return fail(c, MPMC_ERR_BOX, "mpmc_set_box: non-positive cell volume");
@@ -229,6 +237,8 @@ extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *re
 		for (int j = 0; j < 3; j++)
 			if (i != j && (basis[3 * i + j] != 0.0 || R[3 * i + j] != 0.0)) c->box.ortho = 0;
 	c->box_set = true;
+	std::memcpy(c->box_in, in, sizeof(in)); // (only a call that was accepted is remembered)
+	c->box_in_has_recip = (reciprocal != nullptr);
 	c->k_dirty = true;
 	c->atoms_dirty = true; // the spatial order depends on the cell
 	c->cache_valid = false;

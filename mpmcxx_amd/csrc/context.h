@@ -118,6 +118,8 @@ struct mpmc_ctx {
 	bool no_classes = false; // MPMC_NO_CLASSES=1: treat every tile pair as near (A/B comparisons only)
 
 	Box box{};
+	double box_in[20] = {0}; // what mpmc_set_box was last called with (basis, reciprocal, volume, cutoff): an identical call is a no-op
+	bool box_in_has_recip = false;
 	bool box_set = false, atoms_set = false, opts_set = false, k_dirty = true;
 	mpmc_options opts{};
 	double ewald_alpha = 0, polar_ewald_alpha = 0;
