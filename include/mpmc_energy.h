@@ -174,7 +174,9 @@ int mpmc_set_atoms(mpmc_ctx *ctx, int n, const double *pos /*[n][3]*/, const dou
                    const int32_t *has_disp, const double *mass);
 /* after a Monte Carlo move: overwrite positions of atoms [first, first+count) */
 int mpmc_update_positions(mpmc_ctx *ctx, int first, int count, const double *pos /*[count][3]*/);
-/* same, positions already in device memory ([n][3] fp64, e.g. a torch tensor's data_ptr) */
+/* same, positions already in device memory ([n][3] fp64, e.g. a torch tensor's data_ptr).  The library reads them on the context's own
+ * stream, which is not ordered against the caller's streams: the data must be complete when this is called (synchronize the stream that
+ * produced it first), and it is consumed before the call returns. */
 int mpmc_set_positions_device(mpmc_ctx *ctx, const double *pos_device /*[n][3]*/);
 
 /* ---- double System::energy() -------------------------------------------------------------------------- */

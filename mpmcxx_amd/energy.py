@@ -238,6 +238,8 @@ class System:
         self._check(self._L.mpmc_update_positions(self._h, int(first), p.size // 3, _dp(p)))
 
     def set_positions_device(self, data_ptr: int):
+        """positions from device memory ([n][3] fp64).  The caller synchronizes the stream that produced them first (torch: `torch.cuda.current_stream().synchronize()`);
+        the library reads them on its own stream and is done with the buffer when this returns."""
         self._check(self._L.mpmc_set_positions_device(self._h, C.c_void_p(data_ptr)))
 
     # -- double System::energy() (reference src/System.Energy.cpp:19) ---------------------------------------------
