@@ -1,0 +1,33 @@
+"""GPU (one MI355X): the multi-rank path of bench.py rehearsed with two ranks that share the one GPU (gloo for the 4-doubles-per-bead
+combine; the driver's 8-GPU run uses nccl = RCCL on one rank per GPU).  The whole-job result must carry the contract's fields and the
+ensemble potential must equal the single-process value bit for bit (the combine adds the per-bead terms in bead order)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+ARGS = ["--beads", "4", "--natoms", "1000", "--steps", "2", "--warmup", "1", "--cpu-baseline", "none"]
+
+
+def last_json(txt):
+    return json.loads([ln for ln in txt.splitlines() if ln.startswith("{")][-1])
+
+
+def test_two_ranks_on_one_gpu_give_the_single_process_result():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, cwd=util.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+                          "bench.py", "--gpus", "2", "--dist-backend", "gloo", "--force-device", "0"] + ARGS,
+                         cwd=util.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = last_json(one.stdout), last_json(two.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in a and k in b, k
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["value"] > 0 and b["config"]["beads_per_gpu"] == 2
+    assert a["V_mean_K"] == b["V_mean_K"] and a["obs_rd_es_pol_vdw"] == b["obs_rd_es_pol_vdw"]  # same beads, same per-bead energies, summed in bead order
