@@ -57,6 +57,8 @@ static int build_k_tables(mpmc_ctx *c) {
 	return MPMC_OK;
 }
 
+constexpr int kDenseChunks = 16; // row chunks (= partial slots) of the dense matrix-vector product
+
 static int ensure_polar_buffers(mpmc_ctx *c) {
 	const size_t np = (size_t)c->max_pad;
 	int rc;
@@ -70,9 +72,10 @@ static int ensure_polar_buffers(mpmc_ctx *c) {
 		// (dev_alloc zero-fills on the context's stream; nothing in this library touches the null stream, which is unordered against
 		// our non-blocking streams)
 	}
-	// per-atom partial slots: one per source tile (symmetric kernels) -- also covers the n_split <= n_tiles slots
-	// of the matrix-free row kernel
-	const size_t need = (size_t)c->n_tiles * c->n_pad * 3;
+	// per-atom partial slots: one per source tile (symmetric kernels) -- also covers the n_split <= n_tiles slots of the matrix-free
+	// row kernel -- and never fewer than the kDenseChunks row chunks the dense matrix-vector product writes (small systems have fewer
+	// tiles than that: the dense solver used to write past the end of this buffer, into the matrix that was allocated right behind it)
+	const size_t need = (size_t)std::max(c->n_tiles, kDenseChunks) * c->n_pad * 3;
 	if (need > c->cap_part) {
 		dev_free(c, &c->d_part, c->cap_part);
 		c->cap_part = 0;
@@ -286,7 +289,6 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		const int want_rrms = (o.polar_rrms || o.polar_precision > 0) ? 1 : 0;
 		const double allowed = by_precision ? o.polar_precision * o.polar_precision * kDebye2SKA * kDebye2SKA : 0.0;
 		const bool dense = (c->solver_used == MPMC_SOLVER_DENSE) && !o.polar_gs;
-		constexpr int kDenseChunks = 16;
 		const int iter_slots = dense ? kDenseChunks : c->n_tiles;
 		if (dense) { // thole_amatrix into device memory, once per evaluation (the positions changed)
 			ProfScope p(c, MPMC_K_TENSOR);
