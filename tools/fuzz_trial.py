@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Fuzz of the trial-move (delta energy) path: random non-polarizable systems (LJ / LJ + Ewald, molecules of 1-4 sites, frozen and
+chargeless sites, all cell shapes), random sequences of molecule moves with accept / reject; every trial energy against a fresh
+context on the same configuration (1e-11), the final accumulated totals against the oracle (1e-9).
+usage: python tools/fuzz_trial.py [first_seed] [count]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import test_gpu_random as T
+import util
+from mpmcxx_amd import energy
+from oracle import OracleSystem
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+bad = 0
+t0 = time.time()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(70000 + seed)
+    n = int(rng.choice([2, 5, 40, 64, 65, 130, 200, 300]))
+    cell = str(rng.choice(["cubic", "ortho", "triclinic"]))
+    atoms, basis = T.random_system(rng, n, cell)
+    opts = T.random_options(rng)
+    opts.update(polarization=0, polar_iterative=0, polar_ewald=0, rd_only=int(rng.random() < 0.3))
+    ids = atoms["mol_id"]
+    starts = [0] + [i for i in range(1, len(ids)) if ids[i] != ids[i - 1]] + [len(ids)]
+    mols = [(starts[k], starts[k + 1]) for k in range(len(starts) - 1)]
+    try:
+        S = energy.System(atoms, basis, opts)
+        e_acc = S.energy()
+        if not np.isfinite(e_acc):
+            S.close(); continue
+        pos = atoms["pos"].copy()
+        for step in range(8):
+            a, b = mols[rng.integers(len(mols))]
+            trial = pos[a:b] + rng.normal(scale=0.3, size=(b - a, 3)) + (basis[rng.integers(3)] if rng.random() < 0.1 else 0.0)
+            e_trial = S.trial_energy(a, trial)
+            full = pos.copy(); full[a:b] = trial
+            F = energy.System(dict(atoms, pos=full), basis, opts)
+            e_full = F.energy()
+            for k in ("energy", "rd_energy", "coulombic_energy", "es_real", "es_recip", "lj_pairs"):
+                x, y = S.trial_observables[k], F.observables[k]
+                assert abs(x - y) <= 1e-11 * max(abs(y), abs(F.observables["energy"]) * 1e-3) + 1e-9, (step, k, x, y)
+            assert S.trial_observables["n_lj_in_cutoff"] == F.observables["n_lj_in_cutoff"], (step, "n_lj")
+            if not opts["rd_only"]:
+                assert S.trial_observables["n_es_in_cutoff"] == F.observables["n_es_in_cutoff"], (step, "n_es")
+            F.close()
+            if rng.random() < 0.5:
+                S.accept(); pos = full; e_acc = e_trial
+            else:
+                S.reject()
+        ref = OracleSystem(dict(atoms, pos=pos), basis, opts).energy()
+        assert util.close(S.energy(), ref["energy"]) and util.close(e_acc, ref["energy"], 1e-9), ("final", e_acc, ref["energy"])
+        S.close()
+    except Exception as e:  # noqa: BLE001
+        bad += 1
+        print(f"FAIL seed {seed} n {n} {cell} rd_only {opts['rd_only']}: {type(e).__name__}: {str(e)[:300]}", flush=True)
+    if (seed - first + 1) % 20 == 0:
+        print(f"  ... {seed - first + 1} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
+print(f"fuzz_trial: {count} cases from seed {first}: {bad} failures")
+sys.exit(1 if bad else 0)
