@@ -4,7 +4,9 @@
   insertion (growth past the capacity hint), option changes (polarization on / off, solver)
 and after EVERY operation its energy must equal that of a fresh context built from the host-side truth (1e-10: same arithmetic, other
 atom order), and at the end the oracle's (1e-9).
-usage: python tools/fuzz_state.py [first_seed] [count]"""
+usage: python tools/fuzz_state.py [first_seed] [count] [threads]
+threads > 1: the seeds are spread over that many host threads working at the same time, each on its own contexts (the oracle check at
+the end of a sequence is left out there: the comparison with fresh contexts is the test of cross-context interference)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -14,9 +16,14 @@ import util
 from mpmcxx_amd import energy
 from oracle import OracleSystem
 
+import threading
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 bad = 0
+done = 0
+lock = threading.Lock()
 t0 = time.time()
 
 
@@ -25,7 +32,8 @@ def mol_ranges(ids):
     return [(starts[k], starts[k + 1]) for k in range(len(starts) - 1)]
 
 
-for seed in range(first, first + count):
+def run_seed(seed):
+    global bad, done
     rng = np.random.default_rng(90000 + seed)
     n = int(rng.choice([40, 130, 300, 520, 700]))
     atoms, basis = T.random_system(rng, n, str(rng.choice(["cubic", "ortho", "triclinic"])))
@@ -96,14 +104,29 @@ for seed in range(first, first + count):
             ok = ok and int(S.observables["n_lj_in_cutoff"]) == int(F.observables["n_lj_in_cutoff"])
             F.close()
             assert ok, (step, op, e, ef)
-        ref = OracleSystem(atoms, basis, opts).energy()
-        if np.isfinite(ref["energy"]):
-            assert util.close(S.energy(), ref["energy"]), ("final vs oracle", S.observables["energy"], ref["energy"])
+        if threads == 1:
+            ref = OracleSystem(atoms, basis, opts).energy()
+            if np.isfinite(ref["energy"]):
+                assert util.close(S.energy(), ref["energy"]), ("final vs oracle", S.observables["energy"], ref["energy"])
         S.close()
     except Exception as e:  # noqa: BLE001
-        bad += 1
+        with lock:
+            bad += 1
         print(f"FAIL seed {seed} n {n} ops {log}: {type(e).__name__}: {str(e)[:300]}", flush=True)
-    if (seed - first + 1) % 10 == 0:
-        print(f"  ... {seed - first + 1} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
-print(f"fuzz_state: {count} cases from seed {first}: {bad} failures")
+    with lock:
+        done += 1
+        if done % 10 == 0:
+            print(f"  ... {done} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
+
+
+def worker(k):
+    for seed in range(first + k, first + count, threads):
+        run_seed(seed)
+
+
+energy.lib()
+ths = [threading.Thread(target=worker, args=(k,)) for k in range(threads)]
+[t.start() for t in ths]
+[t.join() for t in ths]
+print(f"fuzz_state: {count} cases from seed {first} on {threads} thread(s): {bad} failures")
 sys.exit(1 if bad else 0)
