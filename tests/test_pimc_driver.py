@@ -25,6 +25,7 @@ CASES = {
     "pi_water64": ("input.in", 4, "water64"),  # 64 rigid 3-site polarizable molecules + a neutral atom: exclusions, rotation, Ewald, Thole together
     "pi_frozen": ("input.in", 4, "frozen"),  # frozen charged framework (27 sites) + 6 mobile polar diatomics: frozen pairs, only movable molecules are picked
     "pi_tri": ("input.in", 4, "tri"),  # triclinic cell; Jacobi iteration terminated by polar_precision
+    "pi_nopbc": ("input.in", 4, "nopbc"),  # polar_ewald off (thole_field_nopbc), polar_gamma 1.03, dipole rrms
     "pi_gs": ("input.in", 4, "gs"),  # Gauss-Seidel sweeps, dipole rrms
     "pi_ion1000": ("input.in", 4, "ion1000"),  # 1000 polarizable ions, 12 steps: rows and acceptance rates only (no final geometries kept)
 }
