@@ -73,6 +73,8 @@ inline PimcSettings read_pimc_settings(const std::string &path) {
 		} else if (k == "parallel_restarts") c.parallel_restarts = onoff(t[1]) != 0;
 		else if (k == "spinflip_probability" || k == "simulated_annealing") {
 			if (!to_double(t[1], v) || v != 0.0) throw 4004;
+		} else if (k == "feynman_hibbs") {
+			if (onoff(t[1])) throw 3000; // invalid_input: the reference refuses Feynman-Hibbs corrections in a path-integral run (SimulationControl.cpp:1938-1944)
 		} else if (k == "sorbate_orientation_site" || k == "sorbate_bondlength" || k == "sorbate_reducedmass") {
 			throw 4004; // orientational bead moves (:1559-1698) are not mirrored: the reference itself never accepts one
 		} else if (k == "numsteps" || k == "corrtime" || k == "seed" || k == "move_factor" || k == "rot_factor" || k == "bead_perturb_probability" ||

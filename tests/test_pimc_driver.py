@@ -26,6 +26,7 @@ CASES = {
     "pi_frozen": ("input.in", 4, "frozen"),  # frozen charged framework (27 sites) + 6 mobile polar diatomics: frozen pairs, only movable molecules are picked
     "pi_tri": ("input.in", 4, "tri"),  # triclinic cell; Jacobi iteration terminated by polar_precision
     "pi_nopbc": ("input.in", 4, "nopbc"),  # polar_ewald off (thole_field_nopbc), polar_gamma 1.03, dipole rrms
+    "pi_wolf": ("input.in", 4, "wolf"),  # Wolf electrostatics, rd_lrc off
     "pi_gs": ("input.in", 4, "gs"),  # Gauss-Seidel sweeps, dipole rrms
     "pi_ion1000": ("input.in", 4, "ion1000"),  # 1000 polarizable ions, 12 steps: rows and acceptance rates only (no final geometries kept)
 }
@@ -91,6 +92,10 @@ def test_driver_refuses_what_it_does_not_cover(pimc_check, tmp_path):
     p.write_text(src.replace("PI_trial_chain_length          4", "PI_trial_chain_length 8").replace("Ar-Ar-4A.pqr", os.path.join(util.GOLDEN, "pi001", "Ar-Ar-4A.pqr")))
     out = subprocess.run([pimc_check, str(p), "8", str(tmp_path)], stdout=subprocess.PIPE, text=True)
     assert out.returncode == 1 and json.loads(out.stdout)["error"] == 4001  # invalid_setting: chain length must be in [1, P-1]
+    p = tmp_path / "fh.in"
+    p.write_text(src.replace("Ar-Ar-4A.pqr", os.path.join(util.GOLDEN, "pi001", "Ar-Ar-4A.pqr")) + "\nfeynman_hibbs on\n")
+    out = subprocess.run([pimc_check, str(p), "8", str(tmp_path)], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 1 and json.loads(out.stdout)["error"] == 3000  # as the reference: no Feynman-Hibbs corrections in a PI run
     p = tmp_path / "orient.in"
     p.write_text(src.replace("Ar-Ar-4A.pqr", os.path.join(util.GOLDEN, "pi001", "Ar-Ar-4A.pqr")) + "\nsorbate_bondlength Ar 0.742\n")
     out = subprocess.run([pimc_check, str(p), "8", str(tmp_path)], stdout=subprocess.PIPE, text=True)
