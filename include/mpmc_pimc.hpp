@@ -90,6 +90,7 @@ inline PimcSettings read_pimc_settings(const std::string &path) {
 			else c.PI_trial_chain_length = (int)v;
 		}
 	}
+	if (c.bead_perturb_probability > 1.0) throw 3000; // "probabilities for all MC moves sum to a value greater than 1.0" (SimulationControl.cpp:1946-1949)
 	return c;
 }
 
