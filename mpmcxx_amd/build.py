@@ -35,10 +35,27 @@ def stale() -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # several ranks of one job may arrive here at once (torch.distributed.run starts N processes): one of them builds, into a
+    # temporary file that is renamed over the library when complete; the others wait on the lock and find the library fresh
+    import fcntl
+
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not stale():
+                return LIB
+            tmp = f"{LIB}.tmp.{os.getpid()}"
+            cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
