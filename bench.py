@@ -5,17 +5,22 @@ Workload (BASELINE.json configs[3] sharded as configs[4]): a P = 32 bead path-in
 polarizable box (LJ + LRC, Ewald real/reciprocal/self with kmax 7, Thole static field + 10 Jacobi dipole
 iterations, polar_ewald on).  One "step" = one SimulationControl::PI_calculate_potential
 (reference PathIntegral.cpp:752-805): a full stateless energy() of every bead + the 4-scalar combine.
-Beads are sharded round-robin over the ranks (one process per GPU); the combine is ONE collective of 4 fp64 per
-bead over torch.distributed (backend nccl = RCCL over xGMI).  Total work is fixed => "scaling": "strong".
+Beads are sharded round-robin over the ranks (one process per GPU); the combine is ONE all-gather of 4 fp64 per
+bead on RCCL over xGMI -- inside libmpmc_energy.so (mpmc_pi_gather_beads; --combine-impl cabi, the default) or through
+torch.distributed (--combine-impl torch) -- followed by the reference's ordered sum.  Total work is fixed => "scaling": "strong".
 At --gpus 1 all 32 beads run on the one GPU, i.e. 32 evaluations of the config-4 box per step.
 
 value = (P * steps) / wall  [energy evaluations / s, whole job], inputs resident in HBM before the timed region.
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel (the Thole dipole-iteration kernel, one launch per Jacobi iteration), timed with
-                  HIP events on the stream it is launched on (mpmc_set_profiling / mpmc_get_timings).
-  cpu_baseline -- ONE evaluation of the same 10k box on one core of this host: by the reference's own object code (kind "reference",
-                  oracle/_ref/ref_harness, the default wherever that binary was built) or by the C port of the oracle (kind "port").
+  roofline     -- dominant kernel (the Thole dipole-iteration kernel, one launch per Jacobi iteration).  PRIMARY figures: the kernel
+                  ALONE on the GPU (HIP events on the stream it is launched on, extra pass right after the timed region), the
+                  duration that rocprofv3 --kernel-trace reports for a serial run (profiles/).  The duration the same kernel shows
+                  INSIDE the timed region (beads overlap on 32 streams, so it is stretched by the neighbours) is kept under
+                  "in_timed_region".  `consistent` = avg_launch_ms x launches per step <= ms_per_step.
+  cpu_baseline -- ONE evaluation of bead 0 of the same ensemble on one core of this host: by the reference's own object code (kind
+                  "reference", oracle/_ref/ref_harness, the default wherever that binary was built) or by the C port of the oracle
+                  (kind "port"); `parity_rel_err` = |E_gpu(bead 0) - E_cpu(bead 0)| / |E_cpu|.
 """
 from __future__ import annotations
 
@@ -39,7 +44,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 #   pair sweep: d + minimum image 12, r^2 5, 1/r 8 = 25 for every pair; inside the cutoff (52.3 % of the pairs of the benchmark box)
 #     LJ 11, erfc(x) exp(-x^2) 85 (two Horner polynomials of 20 + 11 FMA, range reduction, one reciprocal), Coulomb 4, field factor and
 #     both atoms 20 = 120; Thole damping + (a, b) 49 for the pairs of the stored tile pairs (36 %)          25 + 0.523 x 120 + 0.36 x 49 = 105
+#   reciprocal space: K N (6 + ~40) for the structure factors, the same again for the field                      2 x 0.33 GFLOP
 FLOP_PAIR_STORED, FLOP_PAIR_FAR, FLOP_PAIR_SWEEP = 48.0, 64.0, 105.0
+FLOP_RECIP_PER_K_ATOM = 2 * 46.0
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec)
 
 
@@ -61,46 +68,74 @@ def build_case(natoms: int, workdir: str):
 
 
 def bead_positions(pos: np.ndarray, bead: int) -> np.ndarray:
-    """bead b = base positions + Gaussian bead displacement (sigma 0.05 A), numpy default_rng(17) stream per bead."""
-    rng = np.random.default_rng([17, bead])
-    return pos + rng.normal(scale=0.05, size=pos.shape)
+    """bead b = base positions + Gaussian bead displacement (sigma 0.05 A), numpy default_rng([17, b]), on the
+    6-decimal grid of a PQR file: exactly the boxes tests/golden/ion10k_polar_bead{0,1}.json hold reference energies for."""
+    from mpmcxx_amd import gen_box
+
+    return gen_box.bead_positions(pos, bead)
 
 
-def cpu_baseline(kind: str, atoms, basis, opts, workdir: str):
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(kind: str, atoms, basis, opts, workdir: str, gpu_bead0):
+    """bead 0 of the ensemble on one host core.  gpu_bead0: what the HIP path returned for the same configuration."""
     if kind == "none":
         return None
     if kind == "auto":
         kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_harness")) else "port"
     n = atoms["pos"].shape[0]
+    common = {"unit": "energy-evals/s", "cores": 1, "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
     if kind == "reference":
         import subprocess
+
+        from mpmcxx_amd import gen_box
 
         harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
         if not os.path.exists(harness):
             raise RuntimeError("oracle/_ref/ref_harness is not present (built only where /root/reference exists)")
-        name = "ion10k_polar.in" if n == 10000 else "box.in"
+        # bead 0 through the reference's own file formats
+        rows = gen_box.lattice_box(n, float(np.asarray(basis)[0][0]), 13)
+        for r, (x, y, z) in zip(rows, atoms["pos"]):
+            r.x, r.y, r.z = float(x), float(y), float(z)
+        gen_box.write_pqr(os.path.join(workdir, "bead0.pqr"), rows)
+        gen_box.write_input(os.path.join(workdir, "bead0.in"), "bead0.pqr", np.asarray(basis).tolist(), dict(gen_box.POLAR_OPTS))
         t0 = time.time()
-        p = subprocess.run([harness, name, "--time", "1"], cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        p = subprocess.run([harness, "bead0.in", "--time", "1"], cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         txt = p.stdout
         res = json.loads(txt[txt.rfind("\n{") + 1:])
         sec = res["time_mean_s"]
-        return {"value": 1.0 / sec, "unit": "energy-evals/s", "cores": 1, "kind": "reference",
-                "sample": f"1 steady-state full-recompute System::energy() of the same {n}-atom box by the reference's object code "
+        out = dict(common, value=1.0 / sec, kind="reference",
+                   sample=f"1 steady-state full-recompute System::energy() of bead 0 of the ensemble ({n} atoms) by the reference's object code "
                           f"(oracle/_ref/ref_harness; {sec:.2f} s; harness wall incl. pair-list setup {time.time() - t0:.0f} s)",
-                "energy": res["total"]}
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))  # the checker: this leg is the only place bench.py touches oracle/
-    from oracle import OracleSystem
+                   energy=res["total"])
+        ref = {"energy": res["total"], "rd_energy": res["rd"], "coulombic_energy": res["es"], "polarization_energy": res["polar"]}
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))  # the checker: this leg is the only place bench.py touches oracle/
+        from oracle import OracleSystem
 
-    S = OracleSystem(atoms, basis, opts)
-    stride = 1  # every row: ONE full evaluation (~13 s of one host core at 10 000 atoms), the bounded CPU sample of the default run
-    est, wall = S.time_sample(stride)
-    sec = float(est[6])
-    names = ["lj+lrc", "coulombic_real", "coulombic_reciprocal+self", "thole_amatrix", "thole_field", "thole_iterative"]
-    return {"value": 1.0 / sec, "unit": "energy-evals/s", "cores": 1, "kind": "port",
-            "sample": f"scalar C oracle (oracle/mpmc_oracle.c, dense-A algorithm of the reference) on the same {n}-atom box: every O(N^2) stage "
-                      f"of ONE evaluation, rows i = 0, {stride}, {2 * stride}, ... (1/{stride} of the pair work; reciprocal-space and O(N) "
-                      f"stages in full), each stage scaled by its exact work ratio; {wall:.1f} s of CPU work -> {sec:.1f} s per full evaluation",
-            "seconds_per_eval_by_stage": {k: round(float(v), 3) for k, v in zip(names, est[:6])}}
+        S = OracleSystem(atoms, basis, opts)
+        t0 = time.time()
+        r = S.energy(want_atoms=False)  # ONE full evaluation (~10 s of one host core at 10 000 atoms): the bounded CPU sample of the default run
+        sec = time.time() - t0
+        out = dict(common, value=1.0 / sec, kind="port",
+                   sample=f"1 full evaluation of bead 0 of the ensemble ({n} atoms) by the scalar C oracle (oracle/mpmc_oracle.c, the dense-A algorithm "
+                          f"of the reference; {sec:.1f} s)", energy=r["energy"])
+        ref = r
+    if gpu_bead0 is not None:
+        errs = {k: abs(gpu_bead0[k] - ref[k]) / abs(ref[k]) for k in ("energy", "rd_energy", "coulombic_energy", "polarization_energy") if ref.get(k)}
+        out["parity_rel_err"] = max(errs.values())
+        out["parity_rel_err_by_term"] = errs
+        out["gpu_energy_same_configuration"] = gpu_bead0["energy"]
+    return out
 
 
 def main():
@@ -116,11 +151,15 @@ def main():
     ap.add_argument("--cpu-baseline", choices=["auto", "port", "reference", "none"], default="auto",
                     help="auto: the reference's own object code (oracle/_ref/ref_harness, ~25 s) where it was built, else the C port of the oracle")
     ap.add_argument("--combine", choices=["gather", "reduce"], default="gather")
+    ap.add_argument("--combine-impl", choices=["cabi", "torch"], default="cabi",
+                    help="cabi: ncclAllGather inside libmpmc_energy.so (mpmc_pi_gather_beads; falls back to torch if RCCL cannot be initialised "
+                         "below Python, recorded in config.combine_impl); torch: torch.distributed")
     ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="diagnostic: leave the per-kernel HIP events off in the timed region (the roofline entry is then empty)")
+                    help="diagnostic: leave the per-kernel HIP events off in the timed region")
+    ap.add_argument("--no-extra-passes", action="store_true", help="diagnostic: skip the isolated-kernel and PCIe-inclusive passes after the timed region")
     ap.add_argument("--host-positions", action="store_true",
-                    help="also re-upload every bead's positions from host buffers inside each timed step (the PCIe-inclusive rate "
-                         "noted in DESIGN.md §6; never the headline value)")
+                    help="re-upload every bead's positions from host buffers inside each timed step (the PCIe-inclusive rate; the default run "
+                         "measures it in a short extra pass and reports it as pcie_inclusive_value, never as value)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the multi-rank path on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this device")
@@ -150,6 +189,37 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    # ---- the collective of the combine ------------------------------------------------------------------------------------
+    comm = None
+    combine_impl = "none (one rank)" if world == 1 else "torch.distributed"
+    rccl_ver = None
+    try:
+        rccl_ver = energy.rccl_version()
+    except energy.MpmcError:
+        pass
+    if world > 1 and args.combine_impl == "cabi" and args.dist_backend == "nccl" and args.combine == "gather":
+        # rank 0 makes the RCCL unique id, the launcher's channel (torch.distributed) carries its 128 bytes, every rank joins
+        ok = 1
+        try:
+            uid = [energy.Comm.unique_id() if rank == 0 else None]
+        except energy.MpmcError:
+            uid, ok = [None], 0
+        dist.broadcast_object_list(uid, src=0)
+        if uid[0] is not None:
+            try:
+                comm = energy.Comm(world, rank, uid[0], local_rank)
+            except energy.MpmcError as e:
+                print(f"[rank {rank}] mpmc_comm_init_rank failed ({e}); falling back to torch.distributed", file=sys.stderr)
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:  # all ranks or none
+            if comm is not None:
+                comm.close()
+            comm = None
+        else:
+            combine_impl = "libmpmc_energy.so: mpmc_pi_gather_beads (ncclAllGather, communicator from mpmc_comm_init_rank)"
+
     P = args.beads
     if P % world:
         raise SystemExit("--beads must be a multiple of --gpus")
@@ -166,10 +236,11 @@ def main():
         a["pos"] = bead_positions(atoms["pos"], b)
         beads.append(energy.System(a, basis, opts, device=local_rank))
 
-    host_pos = [np.ascontiguousarray(bead_positions(atoms["pos"], b)) for b in mine] if args.host_positions else None
+    host_pos = [np.ascontiguousarray(bead_positions(atoms["pos"], b)) for b in mine]
+    state = {"host_positions": bool(args.host_positions), "per": None}
 
     def local_eval():
-        if host_pos is not None:  # the boundary as the reference's adapter uses it: positions arrive in host memory every call
+        if state["host_positions"]:  # the boundary as the reference's adapter uses it: positions arrive in host memory every call
             for s, hp in zip(beads, host_pos):
                 s.update_positions(0, hp)
         if args.concurrency == "async":
@@ -179,18 +250,32 @@ def main():
             for s in beads:
                 s.energy()
                 per.append(s.observables)
+        state["per"] = per
         return np.array([[p["rd_energy"], p["coulombic_energy"], p["polarization_energy"], p["vdw_energy"]] for p in per])
 
     coll_dev = dev if args.dist_backend == "nccl" else "cpu"
 
     def step():
-        return pi.pi_calculate_potential(local_eval, P, rank, world, mode=args.combine, device=coll_dev)
+        return pi.pi_calculate_potential(local_eval, P, rank, world, mode=args.combine, device=coll_dev, comm=comm)
 
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed(k):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            vv, oo = step()
+        fence()
+        d = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([d], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d, vv, oo
 
     for _ in range(args.warmup):
         v, obs = step()
@@ -200,213 +285,217 @@ def main():
     for k, s in enumerate(beads):
         s.set_profiling((k == 0) and not args.no_kernel_timing)
         s.timings(reset=True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        v, obs = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, v, obs = timed(args.steps)
+    gpu_bead0 = dict(state["per"][0]) if (rank == 0 and state["per"]) else None
 
-    def collect():
+    def collect(systems):
         agg = {}
-        for s in beads:
+        for s in systems:
             for k, tv in s.timings(reset=True).items():
                 a = agg.setdefault(k, {"ms": 0.0, "launches": 0})
                 a["ms"] += tv["ms"]
                 a["launches"] += tv["launches"]
         return agg
 
-    # per-kernel device time from HIP events on each bead's stream, over the timed region
-    agg = collect()
+    agg = collect(beads)  # per-kernel device time from HIP events over the timed region (instrumented bead)
+    for s in beads:
+        s.set_profiling(False)
     iters = int(beads[0].observables.get("polar_iterations", 0)) if beads else 0
     mem_total, mem_tensor = beads[0].memory_usage() if beads else (0, 0)
     tiles = beads[0].tile_stats() if beads else {"tile_pairs": 0, "thole_stored": 0, "thole_far": 0, "beyond_cutoff": 0}
 
-    # the same kernels with NOTHING else on the GPU: one extra, untimed pass, one bead at a time (HIP events again).
-    # In the timed region up to 32 beads are in flight on 32 streams, so an event pair there brackets a kernel that shares
-    # the GPU with other beads' kernels.
-    iso = None
-    if rank == 0:
-        # two fresh contexts with the Jacobi contraction as two kernels (MPMC_JACOBI=split): k_dipole_iter_stream is the pure
-        # HBM-streaming part, k_dipole_iter_far the pure fp64 part of the default single-launch kernel
-        old = os.environ.get("MPMC_JACOBI")
-        old1 = os.environ.get("MPMC_ONE_STREAM")
-        os.environ["MPMC_JACOBI"] = "split"
-        os.environ["MPMC_ONE_STREAM"] = "1"  # no side stream either: every kernel of these contexts runs alone
-        try:
-            iso_beads = []
-            for b in mine[:2]:
-                a = dict(atoms)
-                a["pos"] = bead_positions(atoms["pos"], b)
-                iso_beads.append(energy.System(a, basis, opts, device=local_rank))
-        finally:
-            for k_, v_ in (("MPMC_JACOBI", old), ("MPMC_ONE_STREAM", old1)):
-                if v_ is None:
-                    os.environ.pop(k_, None)
-                else:
-                    os.environ[k_] = v_
-        for s in iso_beads:
-            s.energy()  # warm-up (uploads, buffers)
-        for s in iso_beads:
-            s.set_profiling(True)
-        for _ in range(2):
-            for s in iso_beads:
-                s.energy()
-        iso = {}
-        for s in iso_beads:
-            for k, tv in s.timings(reset=True).items():
-                a = iso.setdefault(k, {"ms": 0.0, "launches": 0})
-                a["ms"] += tv["ms"]
-                a["launches"] += tv["launches"]
-            s.close()
-        # and the production (single-launch) contraction itself, alone on the GPU: one more context, default kernels, one stream
-        old1 = os.environ.get("MPMC_ONE_STREAM")
-        os.environ["MPMC_ONE_STREAM"] = "1"
-        try:
-            a1 = dict(atoms)
-            a1["pos"] = bead_positions(atoms["pos"], mine[0])
-            s1 = energy.System(a1, basis, opts, device=local_rank)
-        finally:
-            if old1 is None:
-                os.environ.pop("MPMC_ONE_STREAM", None)
-            else:
-                os.environ["MPMC_ONE_STREAM"] = old1
-        s1.energy()
-        s1.set_profiling(True)
-        for _ in range(2):
-            s1.energy()
-        iso_hybrid = s1.timings(reset=True)
-        s1.close()
+    # ---- PCIe-inclusive rate: the same step with every bead's positions handed over in host memory (short extra pass, all ranks) ----
+    pcie = None
+    if not args.no_extra_passes and not args.host_positions:
+        state["host_positions"] = True
+        step()
+        k_pcie = max(2, min(args.steps, 5))
+        d2, _, _ = timed(k_pcie)
+        state["host_positions"] = False
+        pcie = {"value": P * k_pcie / d2, "steps": k_pcie,
+                "what": "the same step with every bead's 10 000 positions handed over in host memory (mpmc_update_positions: one 320 KB upload per "
+                        "bead) inside every timed step -- the boundary as the reference-side adapter uses it"}
+
+    # ---- the kernels with NOTHING else on the GPU: untimed passes, one bead at a time on one stream (HIP events again) ----------
+    iso = iso_split = None
+    if rank == 0 and not args.no_extra_passes:
+        def fresh(env, count):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                out = []
+                for b in mine[:count]:
+                    a = dict(atoms)
+                    a["pos"] = bead_positions(atoms["pos"], b)
+                    out.append(energy.System(a, basis, opts, device=local_rank))
+            finally:
+                for k_, v_ in old.items():
+                    if v_ is None:
+                        os.environ.pop(k_, None)
+                    else:
+                        os.environ[k_] = v_
+            return out
+
+        def run_iso(systems, reps=3):
+            for s in systems:
+                s.energy()  # warm-up (uploads, buffers)
+                s.set_profiling(True)
+            for _ in range(reps):
+                for s in systems:
+                    s.energy()
+            t = collect(systems)
+            for s in systems:
+                s.close()
+            return t
+
+        iso = run_iso(fresh({"MPMC_ONE_STREAM": "1"}, 1))  # production kernels, one stream: every kernel alone on the GPU
+        # the Jacobi contraction as two kernels (MPMC_JACOBI=split): k_dipole_iter_stream is the pure HBM-streaming part,
+        # k_dipole_iter_far the pure fp64 part of the default single-launch kernel
+        iso_split = run_iso(fresh({"MPMC_JACOBI": "split", "MPMC_ONE_STREAM": "1"}, 1), reps=2)
     if world > 1:
         dist.barrier()
 
-    hybrid_default = not agg.get("dipole_far", {}).get("launches")
     try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            pmc_traffic = json.load(f)
-    except OSError:
+        pmc_traffic = {}
+        for rnd in ("r01", "r02"):
+            pth = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
+            if os.path.exists(pth):
+                with open(pth) as f:
+                    pmc_traffic.update(json.load(f))
+    except (OSError, ValueError):
         pmc_traffic = {}
     n_pairs_all = n * (n - 1) // 2
     n_pairs_stored = tiles["thole_stored"] * 4096
     n_pairs_far = tiles["thole_far"] * 4096
+    K = 709 if int(opts.get("ewald_kmax", 7)) == 7 else None
+    flops_jacobi = FLOP_PAIR_STORED * n_pairs_stored + FLOP_PAIR_FAR * n_pairs_far
+    flops_pair = FLOP_PAIR_SWEEP * n_pairs_all
+    flops_eval = flops_pair + iters * flops_jacobi + (FLOP_RECIP_PER_K_ATOM * K * n if K else 0.0)
+    bytes_jacobi = 16.0 * n_pairs_stored + n * 80.0
 
-    # the Jacobi iterations of the beads of one rank run in lockstep: one launch carries `batch` systems (mpmc_last_batch_size)
-    batch = beads[0].last_batch_size() if (beads and args.concurrency == "async") else 1
-
-    def roofline_of(name, tv, label, hybrid=None, per_launch=1):
-        hybrid = hybrid_default if hybrid is None else hybrid
-        """roofline of one kernel class from its HIP-event time.  Algorithmic figures (DESIGN.md §3):
-        dipole_iter (k_dipole_iter_stream): HBM -- 16 B per stored unordered pair + 80 B per atom (positions, dipoles in, field out)
-        dipole_far  (k_dipole_iter_far)   : fp64 -- FLOP_PAIR_FAR per far-field pair
-        pair        (k_pair_fused)        : fp64 -- FLOP_PAIR_SWEEP per pair (breakdowns next to the constants at the top of this file)"""
-        avg_ms = tv["ms"] / max(tv["launches"], 1)
-        sec = avg_ms * 1e-3
-        if name == "dipole_iter" and args.solver == "dense":  # the reference's 3N x 3N layout, contraction on v_mfma_f64_16x16x4_f64
-            n3 = 3 * ((n + 63) // 64 * 64)
-            alg = 8.0 * n3 * n3
-            ach = alg / sec / 1e9 if sec > 0 else 0.0
-            issued = 2.0 * n3 * n3 * 16 / sec / 1e12 if sec > 0 else 0.0
-            return {"bound": "hbm", "kernel": "k_dense_matvec", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None, "avg_launch_ms": avg_ms, "launches": tv["launches"], "algorithmic_bytes_per_launch": alg, "measured": label,
-                    "mfma_side": {"issued_tflops": issued, "peak_tflops": FP64_VALU_PEAK_TFLOPS, "frac": issued / FP64_VALU_PEAK_TFLOPS,
-                                  "useful_fraction": 1.0 / 16.0},
-                    "note": "dense (3N)^2 x 8 B matrix-vector product: the vector is replicated over the 16 rows of the MFMA's A operand, no operand reuse"}
-        if name == "dipole_iter":
-            alg = (16.0 * n_pairs_stored + n * 80.0) * per_launch
-            ach = alg / sec / 1e9 if sec > 0 else 0.0
-            hbm = {"bound": "hbm", "kernel": "k_dipole_iter_hybrid" if hybrid else "k_dipole_iter_stream", "achieved": ach, "peak": HBM_PEAK_GBS,
-                   "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": tv["launches"],
-                   "algorithmic_bytes_per_launch": alg, "measured": label}
-            tr = pmc_traffic.get(hbm["kernel"])
-            if tr and tr.get("natoms") == n:
-                hbm["traffic"] = tr["hbm_bytes_per_launch"]
-                hbm["traffic_source"] = tr["source"]
-            if not hybrid:
-                return hbm
-            # the single-launch form walks ALL tile pairs: the stored ones stream 16 B/pair, the far ones recompute the bare dipole
-            # tensor.  fp64 issue is what binds it (measured on MI355X: sending every off-diagonal tile pair down the recompute path
-            # leaves the launch time unchanged, dropping the HBM loads saves 8 %; DESIGN.md §6), so the compute roof is the primary
-            # entry and the bytes are reported beside it.
-            fl = (FLOP_PAIR_STORED * n_pairs_stored + FLOP_PAIR_FAR * n_pairs_far) * per_launch
-            tf = fl / sec / 1e12 if sec > 0 else 0.0
-            if hbm["traffic"] is not None:
-                hbm["traffic"] *= per_launch
-            out = {"bound": "mfma", "kernel": "k_dipole_iter_hybrid_b" if per_launch > 1 else "k_dipole_iter_hybrid", "systems_per_launch": per_launch, "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": hbm["traffic"], "avg_launch_ms": avg_ms, "launches": tv["launches"],
-                   "algorithmic_flops_per_launch": fl, "measured": label,
-                   "hbm_side": {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "traffic")},
-                   "note": ("fp64 VALU bound (MI355X fp64 vector and matrix peaks are both 78.6 TFLOP/s; the kernel issues v_fma_f64).  In the default "
-                            "(async) mode the beads run on independent streams and this launch shares the GPU with other beads' kernels, so its "
-                            "duration in the timed region is about twice what it needs alone: `isolated` holds the same kernels one at a time, "
-                            "MPMC_PI_LOCKSTEP=1 runs all beads' iterations in one launch per iteration (clean durations, 9 % lower whole-job rate).  "
-                            "One launch per Jacobi "
-                            "iteration over ALL tile pairs: 48 flop per streamed pair (16 B of stored tensor), 64 flop per recomputed far-field pair (FMA = 2).  "
-                            "Sustained v_fma_f64 issue measured on this pool (tools/microbench_f64.hip): 59 TFLOP/s, and the kernel's instruction mix "
-                            "(FMA 41 %, MUL 29 %, DPP/int 17 %, ADD/RNDNE 11 %, RSQ 2 %) runs at ~80 % of the rate that mix sustains.  "
-                            "MPMC_JACOBI=split runs the two halves as separate kernels (k_dipole_iter_stream HBM-bound, k_dipole_iter_far fp64-bound).")}
-            if hbm.get("traffic_source"):
-                out["traffic_source"] = hbm["traffic_source"]
-            return out
-        flops = FLOP_PAIR_FAR * n_pairs_far if name == "dipole_far" else FLOP_PAIR_SWEEP * n_pairs_all
-        ach = flops / sec / 1e12 if sec > 0 else 0.0
-        return {"bound": "mfma", "kernel": "k_dipole_iter_far" if name == "dipole_far" else "k_pair_fused", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches": tv["launches"],
-                "algorithmic_flops_per_launch": flops, "measured": label,
-                "note": "fp64 compute bound: MI355X fp64 matrix (v_mfma_f64) and vector peaks are both 78.6 TFLOP/s; the kernel issues v_fma_f64"}
+    def avg_ms(t, k):
+        tv = (t or {}).get(k, {"ms": 0.0, "launches": 0})
+        return tv["ms"] / tv["launches"] if tv["launches"] else None
 
     if rank == 0:
         evals = P * args.steps
         value = evals / dt
+        ms_per_step = dt / args.steps * 1e3
+        n_local = len(beads)
         solver_used = "dense" if args.solver == "dense" else ("compact" if mem_tensor > 0 else "matrix_free")
-        label = f"HIP events on one bead's stream over the timed region ({args.concurrency}: {len(beads)} beads in flight on this GPU)"
-        cand = [k for k in ("dipole_iter", "dipole_far", "pair") if agg.get(k, {}).get("launches")]
-        dom = max(cand, key=lambda k: agg[k]["ms"]) if cand else "dipole_iter"
-        roof = roofline_of(dom, agg.get(dom, {"ms": 0.0, "launches": 0}), label, per_launch=batch if dom == "dipole_iter" else 1)
-        # classes launched once per bead are seen on the instrumented bead only, the lockstep launches cover all `batch` beads
-        scaled = {k: v["ms"] * (1 if (batch > 1 and k == "dipole_iter") else max(batch, 1)) for k, v in agg.items()}
-        roof["share_of_device_time"] = scaled[dom] / max(sum(scaled.values()), 1e-30) if cand else 0.0
+        in_region = {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in agg.items() if tv["launches"]}
+        alone = {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in (iso or {}).items() if tv["launches"]}
+        split = {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in (iso_split or {}).items() if tv["launches"]}
+
+        def compute_entry(kernel, ms, flops, launches_per_step, extra=None):
+            ach = flops / (ms * 1e-3) / 1e12
+            e = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
+                 "traffic": None, "avg_launch_ms": ms, "launches_per_step": launches_per_step, "algorithmic_flops_per_launch": flops,
+                 "consistent": bool(ms * launches_per_step <= ms_per_step)}
+            if extra:
+                e.update(extra)
+            return e
+
+        # dominant kernel: the one with the largest share of the device time of an evaluation (alone-on-the-GPU durations)
+        src = alone if alone else in_region
+        share = {"dipole_iter": (src.get("dipole_iter") or 0.0) * iters, "pair": src.get("pair") or 0.0}
+        dom = max(share, key=share.get) if any(share.values()) else "dipole_iter"
+        jac_kernel = "k_dense_matvec" if solver_used == "dense" else "k_dipole_iter_hybrid"
+        if solver_used == "dense":  # the reference's 3N x 3N layout, contraction on v_mfma_f64_16x16x4_f64: HBM-bound
+            n3 = 3 * ((n + 63) // 64 * 64)
+            ms = src.get("dipole_iter") or 1e30
+            alg = 8.0 * n3 * n3
+            ach = alg / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": jac_kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": ms, "launches_per_step": iters * n_local, "algorithmic_bytes_per_launch": alg,
+                    "consistent": bool(ms * iters * n_local <= ms_per_step),
+                    "mfma_side": {"issued_tflops": 2.0 * n3 * n3 * 16 / (ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS, "useful_fraction": 1.0 / 16.0}}
+        elif dom == "pair":
+            roof = compute_entry("k_pair_fused", src["pair"], flops_pair, n_local)
+        else:
+            ms = src.get("dipole_iter") or 1e30
+            roof = compute_entry(jac_kernel, ms, flops_jacobi, iters * n_local)
+            tr = pmc_traffic.get("k_dipole_iter_hybrid")
+            if tr and tr.get("natoms") == n:
+                roof["traffic"] = tr["hbm_bytes_per_launch"]
+                roof["traffic_source"] = tr["source"]
+            roof["hbm_side"] = {"achieved": bytes_jacobi / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": bytes_jacobi / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_jacobi}
+        roof["measured"] = ("HIP events on the stream the kernel is launched on, extra pass right after the timed region: one bead, one stream, the kernel "
+                            "ALONE on the GPU (the duration rocprofv3 --kernel-trace reports for a serial run, profiles/)" if alone else
+                            "HIP events on one bead's stream over the timed region (beads overlap: stretched durations)")
+        if not roof["consistent"]:  # cannot happen while other kernels share the step; if it does, the whole-step figure is the honest one
+            roof["note_inconsistent"] = "avg_launch_ms x launches_per_step exceeds ms_per_step: use whole_step"
         roof["tile_pairs"] = tiles
-        roof["other_kernels"] = {k: roofline_of(k, agg[k], label, per_launch=batch if k == "dipole_iter" else 1) for k in cand if k != dom}
-        if iso is not None:
-            lab2 = ("HIP events, extra untimed pass after the timed region: one bead at a time (each kernel alone on the GPU), Jacobi contraction "
-                    "as two kernels on one stream (MPMC_JACOBI=split MPMC_ONE_STREAM=1)")
-            roof["isolated"] = {k: roofline_of(k, iso[k], lab2, hybrid=False) for k in ("dipole_iter", "dipole_far", "pair") if iso.get(k, {}).get("launches")}
-            roof["isolated_kernel_ms"] = {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in iso.items() if tv["launches"]}
-            # the production kernel with nothing else on the GPU: what it reaches when other beads' kernels do not stretch its duration
-            ih = iso_hybrid.get("dipole_iter", {"ms": 0.0, "launches": 0})
-            if ih["launches"] and not ("dipole_far" in iso_hybrid and iso_hybrid["dipole_far"]["launches"]):
-                it_ms = ih["ms"] / ih["launches"]
-                fl = FLOP_PAIR_STORED * n_pairs_stored + FLOP_PAIR_FAR * n_pairs_far
-                roof["alone_on_the_gpu"] = {"kernel": "k_dipole_iter_hybrid", "avg_launch_ms": it_ms, "achieved": fl / (it_ms * 1e-3) / 1e12,
-                                            "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (it_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                            "hbm_GBps": (16.0 * n_pairs_stored + n * 80.0) / (it_ms * 1e-3) / 1e9,
-                                            "measured": "HIP events, extra untimed pass after the timed region, one bead, one stream"}
-        cpu = cpu_baseline(args.cpu_baseline, {**atoms, "pos": bead_positions(atoms["pos"], 0)}, basis, opts, workdir) if world == 1 else None
+        roof["share_of_device_time_alone"] = share[dom] / max(sum((src.get(k) or 0.0) * (iters if k in ("dipole_iter", "reduce") else 1) for k in src), 1e-30)
+        # whole-step view, which overlap cannot distort: algorithmic flops of one evaluation x evaluations per second per GPU
+        roof["whole_step"] = {"algorithmic_flops_per_eval": flops_eval, "achieved": flops_eval * value / world / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": flops_eval * value / world / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                              "what": "pair sweep + iterations x Jacobi contraction + reciprocal space, x evaluations/s per GPU"}
+        # secondary: the same kernels inside the timed region (other beads' kernels share the GPU) and the other big kernel
+        roof["in_timed_region"] = {"kernel_ms": in_region,
+                                   "note": f"{args.concurrency}: {n_local} beads in flight on this GPU, HIP events on one bead's stream; a launch here "
+                                           "shares the CUs with other beads' kernels, so its duration is stretched -- not a kernel time"}
+        if in_region.get("dipole_iter") and solver_used != "dense":
+            roof["in_timed_region"]["dipole_iter_frac_if_taken_as_kernel_time"] = flops_jacobi / (in_region["dipole_iter"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
+        other = {}
+        if alone.get("pair") and dom != "pair":
+            other["pair"] = compute_entry("k_pair_fused", alone["pair"], flops_pair, n_local)
+        if alone.get("dipole_iter") and dom == "pair" and solver_used != "dense":
+            other["dipole_iter"] = compute_entry(jac_kernel, alone["dipole_iter"], flops_jacobi, iters * n_local)
+        if split.get("dipole_iter") and split.get("dipole_far"):
+            ms = split["dipole_iter"]
+            other["dipole_iter_stream_only"] = {"bound": "hbm", "kernel": "k_dipole_iter_stream", "achieved": bytes_jacobi / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                                "unit": "GB/s", "frac": bytes_jacobi / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms,
+                                                "algorithmic_bytes_per_launch": bytes_jacobi, "what": "MPMC_JACOBI=split: the stored tile pairs alone"}
+            other["dipole_iter_far_only"] = compute_entry("k_dipole_iter_far", split["dipole_far"], FLOP_PAIR_FAR * n_pairs_far, iters * n_local,
+                                                          {"what": "MPMC_JACOBI=split: the recomputed far-field tile pairs alone"})
+        roof["other_kernels"] = other
+        roof["alone_kernel_ms"] = alone
+        roof["pmc_sources"] = "profiles/r02_pmc_summary.md (SQ_* counters, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes; tools/profile.sh)"
+        roof["note"] = ("fp64 VALU bound: MI355X fp64 vector and matrix peaks are both 78.6 TFLOP/s, the kernel issues v_fma_f64.  One launch per Jacobi "
+                        "iteration over ALL tile pairs: 48 flop per streamed pair (16 B of stored tensor), 64 flop per recomputed far-field pair (FMA = 2).")
+
         out = {
             "metric": "energy-evals/sec (10k-atom LJ+Ewald+polar box); 1/2/4/8-GPU scaling",
             "value": value, "unit": "energy-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{P}-bead path-integral ensemble of the {n}-atom polarizable box (BASELINE configs[3] x configs[4]): "
                                    f"LJ+LRC, Ewald kmax {opts['ewald_kmax']}, Thole exponential damping, {iters} Jacobi iterations, polar_ewald",
                        "natoms": n, "beads": P, "beads_per_gpu": P // world, "polar_solver": solver_used, "combine": args.combine,
-                       "parallelism": f"beads sharded round-robin over {world} GPU(s); one {'all_gather' if args.combine == 'gather' else 'all_reduce'} of 4 fp64 per bead per step"},
+                       "parallelism": f"beads sharded round-robin over {world} GPU(s); one {'all_gather' if args.combine == 'gather' else 'all_reduce'} of 4 fp64 per bead per step",
+                       "dist_backend": (args.dist_backend if world > 1 else "none (one rank)"), "world_size": world, "combine_impl": combine_impl,
+                       "rccl_version": rccl_ver},
             "V_mean_K": v, "obs_rd_es_pol_vdw": [float(x) for x in obs],
-            "kernel_ms": {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in agg.items() if tv["launches"]},
+            "kernel_ms": in_region,
             "device_bytes_per_bead": mem_total,
             "roofline": roof,
         }
+        if pcie is not None:
+            out["pcie_inclusive_value"] = pcie["value"]
+            out["pcie_inclusive"] = pcie
         if args.host_positions:
             out["note_host_positions"] = "positions of every bead re-uploaded from host memory inside every timed step (PCIe-inclusive rate, not the headline)"
+    # which device every rank drove (proof that RCCL saw N ranks on N devices): gathered from all ranks
+    my_info = {"rank": rank, "local_rank": local_rank, "device": dev, "device_name": torch.cuda.get_device_name(local_rank), "pid": os.getpid(),
+               "beads": mine, "comm_n_ranks": (comm.n_ranks if comm is not None else None)}
+    infos = [my_info]
+    if world > 1:
+        infos = [None] * world
+        dist.all_gather_object(infos, my_info)
+    if rank == 0:
+        out["config"]["ranks"] = infos
+        cpu = None
+        if world == 1 and args.cpu_baseline != "none":
+            cpu = cpu_baseline(args.cpu_baseline, {**atoms, "pos": bead_positions(atoms["pos"], 0)}, basis, opts, workdir, gpu_bead0)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
     for s in beads:
         s.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

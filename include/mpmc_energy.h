@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MPMC_ABI_VERSION 2
+#define MPMC_ABI_VERSION 3
 
 /* ---- status codes -------------------------------------------------------------------------------------- */
 #define MPMC_OK 0
@@ -40,6 +40,7 @@ extern "C" {
 #define MPMC_ERR_NO_DEVICE (-1)          /* no HIP device / HIP runtime failure at create                 */
 #define MPMC_ERR_HIP (-2)                /* a HIP call failed (text in mpmc_last_error)                   */
 #define MPMC_ERR_ARG (-3)                /* NULL / out-of-range argument                                  */
+#define MPMC_ERR_COMM (-4)               /* RCCL missing or an RCCL call failed (text in mpmc_comm_last_error) */
 
 /* ---- damping (reference enum constants.h:66-70) -------------------------------------------------------- */
 #define MPMC_DAMPING_OFF 0
@@ -233,6 +234,34 @@ int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sums4[4], mpmc
 int mpmc_last_batch_size(mpmc_ctx *ctx);
 /* obs = sums / P ; returns V = rd + coulombic + vdw + polarization (:786-804) */
 double mpmc_pi_finish(const double sums4_global[4], int P, double obs4[4]);
+
+/* ---- the cross-GPU exchange of PI_calculate_potential on RCCL over xGMI ------------------------------------------
+ * Reference: MPI_Allgather x 4 of one double per rank, then the ordered sum s = 0..P-1 (PathIntegral.cpp:763-766, :786-801).
+ * Here: ONE ncclAllGather of `stride` fp64 per bead, then the same ordered sum on the host (bit-identical on every rank).
+ * Bead s lives on rank s % n_ranks, local slot s / n_ranks.  RCCL is opened with dlopen at first use (librccl.so.1, or
+ * $MPMC_RCCL_LIB); without it these calls fail with MPMC_ERR_COMM and nothing else in the library is affected.
+ *   one process per GPU : rank 0 calls mpmc_comm_unique_id, the host program carries the 128 bytes to the other ranks
+ *                         (MPI_Bcast, a file, the torch.distributed store), every rank calls mpmc_comm_init_rank;
+ *   one process, G GPUs : mpmc_comm_init_all / mpmc_pi_allreduce. */
+typedef struct mpmc_comm mpmc_comm;
+#define MPMC_COMM_ID_BYTES 128
+int mpmc_rccl_version(int *version); /* ncclGetVersion: e.g. 22707 */
+int mpmc_comm_unique_id(char id[MPMC_COMM_ID_BYTES]);
+int mpmc_comm_init_rank(mpmc_comm **out, int n_ranks, int rank, const char id[MPMC_COMM_ID_BYTES], int device);
+int mpmc_comm_init_all(mpmc_comm **out, int n_devices, const int *devices /* NULL: 0..n_devices-1 */);
+int mpmc_comm_destroy(mpmc_comm *comm);
+int mpmc_comm_info(const mpmc_comm *comm, int *n_ranks, int *rank, int *n_local_devices);
+const char *mpmc_comm_last_error(const mpmc_comm *comm); /* comm may be NULL: last error of this thread */
+/* all[r][0..count) = rank r's local[0..count)   (communicators of mpmc_comm_init_rank) */
+int mpmc_comm_allgather_f64(mpmc_comm *comm, const double *local, int64_t count, double *all /*[n_ranks][count]*/);
+/* local[n_local][stride] in local-slot order  ->  all[P][stride] in BEAD order, P = n_local * n_ranks.  stride 4 = the
+ * {rd, coulombic, polarization, vdw} of PI_calculate_potential; 3 * n_molecules = the centres of mass of the kinetic estimator. */
+int mpmc_pi_gather_beads(mpmc_comm *comm, const double *local, int n_local, int stride, double *all);
+/* One process driving several GPUs: beads[b] may live on any device (the usual placement is b mod G).  Evaluates energy() on every
+ * bead -- one host thread per device, all of a device's beads enqueued before the first wait -- gathers the per-bead values over a
+ * process-wide ncclCommInitAll communicator of the devices involved, and returns the UN-normalised ordered sums over beads 0..n-1
+ * (identical on every device: an all-reduce with a fixed summation order).  mpmc_pi_finish divides by P. */
+int mpmc_pi_allreduce(mpmc_ctx **beads, int n_beads, double sums4[4], mpmc_result *per_bead, int *any_iterator_failed);
 
 /* ---- SimulationControl::PI_calculate_kinetic (PathIntegral.cpp:806-824) and its chain measure (:851-965) ----
  * Host-side O(P * n_molecules); no device work.  com: centres of mass [P][n_molecules][3] of the P images of every

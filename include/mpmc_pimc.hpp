@@ -215,7 +215,7 @@ public:
 		std::vector<int> perturbable;
 		const std::vector<Atom> &a = systems[0]->atoms;
 		for (size_t m = 0; m + 1 < mol_first.size(); m++)
-			if (!a[mol_first[m]].frozen) perturbable.push_back((int)m);
+			if (!a[mol_first[m + 1] - 1].frozen) perturbable.push_back((int)m); // Molecule::frozen = flag of the last atom row (src/System.cpp:684)
 		if (perturbable.empty()) throw 3001; // no_molecules_in_system
 		target = perturbable[(int)std::floor(perturbable.size() * dice_roll_for_target)];
 		movetype = (dice_roll_for_move < cfg.bead_perturb_probability) ? MOVETYPE_PERTURB_BEADS : MOVETYPE_DISPLACE;
@@ -340,7 +340,7 @@ public:
 		const int saved = target;
 		const std::vector<Atom> &a = systems[0]->atoms;
 		for (size_t m = 0; m + 1 < mol_first.size(); m++) {
-			if (a[mol_first[m]].frozen) continue;
+			if (a[mol_first[m + 1] - 1].frozen) continue;
 			target = (int)m;
 			PI_perturb_bead_COMs(nSys);
 		}

@@ -111,12 +111,12 @@ public:
 		box_dirty_ = true;
 	}
 	int countNatoms() const { return (int)atoms.size(); }
-	// System::countN, src/System.cpp:909-931: molecules that are not frozen (the flag of a molecule is that of its
-	// first atom, src/System.cpp:684; adiabatic / target molecules are refused by the readers)
+	// System::countN, src/System.cpp:909-931: molecules that are not frozen.  The flag of a molecule is that of its LAST atom row:
+	// the PQR reader overwrites molecule->frozen on every row (src/System.cpp:684); adiabatic / target molecules are refused by the readers
 	unsigned int countN() {
 		unsigned int count = 0;
 		for (size_t i = 0; i < atoms.size(); i++)
-			if ((i == 0 || atoms[i].molecule != atoms[i - 1].molecule) && !atoms[i].frozen) count++;
+			if ((i + 1 == atoms.size() || atoms[i + 1].molecule != atoms[i].molecule) && !atoms[i].frozen) count++;
 		observables->N = count;
 		return count;
 	}
@@ -134,7 +134,7 @@ public:
 			}
 			for (int d = 0; d < 3; d++) com.push_back(c[d] / m);
 			mol_mass.push_back(m);
-			movable.push_back(atoms[a0].frozen ? 0 : 1);
+			movable.push_back(atoms[a1 - 1].frozen ? 0 : 1); // last row decides (src/System.cpp:684)
 			a0 = a1;
 		}
 	}

@@ -147,8 +147,6 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	}
 	if (const char *e = std::getenv("MPMC_ONE_STREAM")) c->two_streams = !(e[0] == '1');
 	if (const char *e = std::getenv("MPMC_JACOBI")) c->jacobi_hybrid = (e[0] != 's');
-	c->jacc = c->use_dpp ? 0 : 1;
-	if (const char *e = std::getenv("MPMC_JACC")) c->jacc = std::atoi(e);
 	if (const char *e = std::getenv("MPMC_NO_UNI")) c->no_uniform = (e[0] == '1');
 	if (const char *e = std::getenv("MPMC_NO_RECIP_TAB")) c->no_recip_tab = (e[0] == '1');
 	const size_t P = (size_t)c->max_pad;
@@ -176,6 +174,9 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	}
 	if (const char *e = std::getenv("MPMC_NO_CLASSES")) c->no_classes = (e[0] == '1');
 	if (const char *e = std::getenv("MPMC_NO_DPP")) if (e[0] == '1') c->use_dpp = false;
+	// the Jacobi kernels rotate their j-side accumulators the way the pair sweep does: decided AFTER the self-test and the override
+	c->jacc = c->use_dpp ? 0 : 1;
+	if (const char *e = std::getenv("MPMC_JACC")) c->jacc = std::atoi(e);
 	*out = c;
 	return MPMC_OK;
 }
@@ -269,7 +270,12 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 		if (o->wolf && !o->rd_only) return fail(c, MPMC_ERR_INCOMPATIBLE, "mpmc_set_options: FH + es_wolf is not implemented"); // System.Energy.cpp:1448-1450
 	}
 	if (c->opts_set && std::memcmp(&c->opts, o, sizeof(mpmc_options)) == 0) return MPMC_OK; // unchanged: keep the accepted configuration's totals
-	if (c->opts_set && (c->opts.polar_gs != 0) != (o->polar_gs != 0)) c->atoms_dirty = true; // Gauss-Seidel sweeps need the reference's atom order
+	{ // Gauss-Seidel sweeps run in the reference's atom order (System.Energy.cpp:3569): whenever "this evaluation sweeps in atom order"
+	  // changes -- through polar_gs, polarization or rd_only, or on the first options after an upload under the defaults -- re-upload
+		auto atom_order = [](const mpmc_options &q) { return q.polar_gs && q.polarization && !q.rd_only; };
+		const bool was = c->opts_set && atom_order(c->opts);
+		if (was != (bool)atom_order(*o)) c->atoms_dirty = true;
+	}
 	c->opts = *o;
 	c->opts_set = true;
 	c->k_dirty = true;
@@ -572,6 +578,9 @@ extern "C" int mpmc_update_positions(mpmc_ctx *c, int first, int count, const do
 extern "C" int mpmc_set_positions_device(mpmc_ctx *c, const double *pos_device) {
 	if (!c || !pos_device) return MPMC_ERR_ARG;
 	if (!c->atoms_set) return fail(c, MPMC_ERR_ARG, "mpmc_set_positions_device: no atoms set");
+	if (c->trial_open) return fail(c, MPMC_ERR_ARG, "mpmc_set_positions_device: a trial move is open (accept or reject it first)");
+	if (c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_set_positions_device: an evaluation is in flight (mpmc_energy_wait first)");
+	c->cache_valid = false; // the accepted totals / structure factors no longer describe the resident configuration
 	HIP_TRY(c, hipSetDevice(c->device));
 	if (c->atoms_dirty) { // need the slot order first
 		int rc = upload_atoms(c);

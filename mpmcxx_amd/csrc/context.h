@@ -92,7 +92,8 @@ struct mpmc_ctx {
 	int *h_flag = nullptr; // pinned
 
 	// reciprocal tables
-	int K = 0, cap_K = 0;
+	int K = 0, cap_K = 0; // cap_K: capacity of the k tables (d_kvec, d_kw, d_lvec, d_w_en)
+	int cap_sf = 0;       // capacity of d_sf, which trades places with d_sf_trial when a trial move is accepted
 	double4 *d_kvec = nullptr, *d_kw = nullptr, *d_sf = nullptr;
 	int4 *d_lvec = nullptr;       // integer l-vectors of the k table
 	double4 *d_sf_part = nullptr; // [n_tiles][K] per-tile structure-factor partials (factorised phases)

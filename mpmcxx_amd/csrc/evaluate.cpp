@@ -34,16 +34,21 @@ static int build_k_tables(mpmc_ctx *c) {
 		dev_free(c, &c->d_kvec, (size_t)c->cap_K);
 		dev_free(c, &c->d_kw, (size_t)c->cap_K);
 		dev_free(c, &c->d_lvec, (size_t)c->cap_K);
-		dev_free(c, &c->d_sf, (size_t)c->cap_K);
 		dev_free(c, &c->d_w_en, (size_t)c->cap_K);
 		c->cap_K = 0;
 		int rc;
 		if ((rc = dev_alloc(c, &c->d_kvec, (size_t)K)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_kw, (size_t)K)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_lvec, (size_t)K)) != MPMC_OK) return rc;
-		if ((rc = dev_alloc(c, &c->d_sf, (size_t)K)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_w_en, (size_t)K)) != MPMC_OK) return rc;
 		c->cap_K = K;
+	}
+	if (K > c->cap_sf) { // the structure factors swap buffers with the trial ones on accept: sized on their own
+		dev_free(c, &c->d_sf, (size_t)c->cap_sf);
+		c->cap_sf = 0;
+		int rc = dev_alloc(c, &c->d_sf, (size_t)K);
+		if (rc != MPMC_OK) return rc;
+		c->cap_sf = K;
 	}
 	if (K > 0) {
 		// on the context's stream (ordered against whatever it still runs), then waited for: the staging vectors die with this scope

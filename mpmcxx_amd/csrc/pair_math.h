@@ -1,9 +1,8 @@
 // pair_math.h -- per-pair arithmetic of the energy hot path, shared by every HIP kernel.
 //
-// These are the ONLY places where the physics formulas live.  They are __host__ __device__ so that the
-// very same code can be swept over all pairs on the host by tests/hostcheck (test infrastructure) and
-// compared with the oracle before it ever runs on a GPU; the product library only instantiates them in
-// device code.
+// These are the ONLY places where the physics formulas live.  They are __host__ __device__ (plain C++ without hipcc) so the same
+// expressions can be compiled for the host by a sanitizer build (tools/host_asan.sh); the product library only instantiates them
+// in device code.
 //
 // Build contract: this translation unit is compiled with -ffp-contract=off.  The minimum-image distance
 // decides pair inclusion and must round exactly like the reference's x86-64 build (no FMA): SURVEY §7

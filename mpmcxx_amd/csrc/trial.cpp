@@ -165,7 +165,7 @@ extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
 		launch_commit_positions(c->stream, c->d_xyzq, c->d_mv_slot, c->d_mv_new, m);
 		HIP_TRY(c, hipGetLastError());
 		std::swap(c->d_sf, c->d_sf_trial); // the trial structure factors become the accepted ones
-		std::swap(c->cap_K, c->cap_sf_trial);
+		std::swap(c->cap_sf, c->cap_sf_trial); // (d_sf has its own capacity: cap_K sizes the k tables, which do not move)
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		for (int t = 0; t < 3 * m; t++) c->h_pos[3 * (size_t)c->trial_first + t] = c->trial_new[t];
 		for (int t = 0; t < m; t++) { // the slot-ordered mirror follows (a later bulk position update uploads it as a whole)

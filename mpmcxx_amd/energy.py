@@ -123,6 +123,17 @@ def lib():
     L.mpmc_trial_energy.argtypes = [vp, C.POINTER(Result)]
     L.mpmc_trial_accept.argtypes = [vp]
     L.mpmc_trial_reject.argtypes = [vp]
+    L.mpmc_rccl_version.argtypes = [C.POINTER(C.c_int)]
+    L.mpmc_comm_unique_id.argtypes = [C.c_char_p]
+    L.mpmc_comm_init_rank.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_int]
+    L.mpmc_comm_init_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
+    L.mpmc_comm_destroy.argtypes = [vp]
+    L.mpmc_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mpmc_comm_last_error.argtypes = [vp]
+    L.mpmc_comm_last_error.restype = C.c_char_p
+    L.mpmc_comm_allgather_f64.argtypes = [vp, dp, C.c_int64, dp]
+    L.mpmc_pi_gather_beads.argtypes = [vp, dp, C.c_int, C.c_int, dp]
+    L.mpmc_pi_allreduce.argtypes = [C.POINTER(vp), C.c_int, dp, C.POINTER(Result), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -372,6 +383,89 @@ def pi_potential_local(beads: Sequence[System]):
     for b, r in zip(beads, per):
         b.observables = r
     return sums, per, bool(failed.value)
+
+
+def pi_allreduce(beads: Sequence[System]):
+    """SimulationControl::PI_calculate_potential for ONE process that drives several GPUs (bead b usually on device b mod G): evaluation with
+    one host thread per device, per-bead values gathered over RCCL (ncclCommInitAll communicator), ordered sum s = 0..P-1.
+    Returns (sums4, per-bead results, failed) like pi_potential_local."""
+    L = lib()
+    n = len(beads)
+    arr = (C.c_void_p * max(n, 1))(*[b.handle for b in beads])
+    sums = np.zeros(4)
+    res = (Result * max(n, 1))()
+    failed = C.c_int(0)
+    rc = L.mpmc_pi_allreduce(arr, n, _dp(sums), res, C.byref(failed))
+    if rc != MPMC_OK:
+        raise MpmcError(rc, ((L.mpmc_last_error(beads[0].handle) if beads else b"") or L.mpmc_comm_last_error(None) or b"").decode())
+    per = [res[i].as_dict() for i in range(n)]
+    for b, r in zip(beads, per):
+        b.observables = r
+    return sums, per, bool(failed.value)
+
+
+def rccl_version() -> int:
+    v = C.c_int(0)
+    rc = lib().mpmc_rccl_version(C.byref(v))
+    if rc != MPMC_OK:
+        raise MpmcError(rc, (lib().mpmc_comm_last_error(None) or b"").decode())
+    return v.value
+
+
+class Comm:
+    """RCCL communicator of the C ABI, one process per GPU: rank 0 makes the id (`Comm.unique_id()`), the launcher's own channel carries
+    the 128 bytes to the other ranks (bench.py: torch.distributed's store), every rank constructs `Comm(n_ranks, rank, id, device)`."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        rc = lib().mpmc_comm_unique_id(buf)
+        if rc != MPMC_OK:
+            raise MpmcError(rc, (lib().mpmc_comm_last_error(None) or b"").decode())
+        return buf.raw
+
+    def __init__(self, n_ranks: int, rank: int, uid: bytes, device: int):
+        self._L = lib()
+        self._h = C.c_void_p()
+        if len(uid) != Comm.ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        rc = self._L.mpmc_comm_init_rank(C.byref(self._h), int(n_ranks), int(rank), uid, int(device))
+        if rc != MPMC_OK:
+            raise MpmcError(rc, (self._L.mpmc_comm_last_error(None) or b"").decode())
+        self.n_ranks, self.rank, self.device = int(n_ranks), int(rank), int(device)
+
+    def _check(self, rc: int):
+        if rc != MPMC_OK:
+            raise MpmcError(rc, (self._L.mpmc_comm_last_error(self._h) or b"").decode())
+
+    def allgather(self, local: np.ndarray) -> np.ndarray:
+        """(count,) fp64 of this rank -> (n_ranks, count) in rank order."""
+        a = np.ascontiguousarray(local, dtype=np.float64).reshape(-1)
+        out = np.zeros((self.n_ranks, a.size))
+        self._check(self._L.mpmc_comm_allgather_f64(self._h, _dp(a), a.size, _dp(out)))
+        return out
+
+    def gather_beads(self, local: np.ndarray) -> np.ndarray:
+        """(n_local, stride) of this rank's beads (local-slot order) -> (P, stride) in bead order; bead s = rank s % n_ranks, slot s // n_ranks."""
+        a = np.ascontiguousarray(local, dtype=np.float64)
+        n_local = a.shape[0]
+        a2 = a.reshape(n_local, -1)
+        out = np.zeros((n_local * self.n_ranks, a2.shape[1]))
+        self._check(self._L.mpmc_pi_gather_beads(self._h, _dp(a2), n_local, a2.shape[1], _dp(out)))
+        return out.reshape((n_local * self.n_ranks,) + a.shape[1:])
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.mpmc_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def pi_finish(sums4_global: np.ndarray, P: int):

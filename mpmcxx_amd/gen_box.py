@@ -286,7 +286,26 @@ def fixture(name: str):
         return lattice_box(10000, 86.0, 13), cubic(86.0), {"ewald_kmax": 7}
     if name == "ion10k_polar":  # BASELINE config 4
         return lattice_box(10000, 86.0, 13), cubic(86.0), dict(POLAR_OPTS)
+    if name.startswith("ion10k_polar_bead"):  # BASELINE config 5: image `b` of the 32-bead ensemble of the config-4 box
+        rows = lattice_box(10000, 86.0, 13)
+        pos = bead_positions([(r.x, r.y, r.z) for r in rows], int(name[len("ion10k_polar_bead"):]))
+        for r, (x, y, z) in zip(rows, pos):
+            r.x, r.y, r.z = float(x), float(y), float(z)
+        return rows, cubic(86.0), dict(POLAR_OPTS)
     raise KeyError(name)
+
+
+def bead_positions(base_pos, bead: int, sigma: float = 0.05):
+    """Image `bead` of a path-integral ensemble: base positions + Gaussian displacement (sigma in A), numpy default_rng([17, bead])
+    (SURVEY §8d config 5), QUANTISED to the 6 decimals of a PQR coordinate column: what bench.py evaluates on the GPU is then, double
+    for double, what the reference reads from `ion10k_polar_beadB.pqr` (tests/golden/ion10k_polar_bead{0,1}.json)."""
+    import numpy as np
+
+    # the PQR text the base positions came from has 6 decimals too: go through the same text -> double conversion
+    base = np.array(np.char.mod("%.6f", np.asarray(base_pos, dtype=np.float64)), dtype=np.float64)
+    rng = np.random.default_rng([17, bead])
+    moved = base + rng.normal(scale=sigma, size=base.shape)
+    return np.array(np.char.mod("%.6f", moved), dtype=np.float64)
 
 
 SMALL_FIXTURES = [
@@ -294,7 +313,7 @@ SMALL_FIXTURES = [
     "ion216_precision", "ion216_gamma", "ion216_alpha", "water64_polar", "lj1000", "ion1000_polar",
     "ion216_wolf", "water64_fh2", "water64_fh4", "ion216_fh4_polar", "ion216_gs", "water64_gs_precision", "ion1000_gs", "ion216_framework",
 ]
-LARGE_FIXTURES = ["ion10k_es", "ion10k_polar"]
+LARGE_FIXTURES = ["ion10k_es", "ion10k_polar", "ion10k_polar_bead0", "ion10k_polar_bead1"]
 
 
 def materialize(name: str, outdir: str):

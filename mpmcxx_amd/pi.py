@@ -28,12 +28,18 @@ def beads_of_rank(P: int, rank: int, world: int) -> List[int]:
 
 
 def combine(per_bead_local: np.ndarray, P: int, rank: int = 0, world: int = 1, group=None, mode: str = "gather",
-            device: Optional[str] = None) -> Tuple[float, np.ndarray]:
+            device: Optional[str] = None, comm=None) -> Tuple[float, np.ndarray]:
     """per_bead_local: (n_local, 4) = {rd, coulombic, polarization, vdw} of this rank's beads, in local-slot order.
-    Returns (V, obs4) exactly as PI_calculate_potential: obs = ordered sum / P, V = rd + coulombic + vdw + polarization."""
+    Returns (V, obs4) exactly as PI_calculate_potential: obs = ordered sum / P, V = rd + coulombic + vdw + polarization.
+    comm: an `energy.Comm` (RCCL communicator of the C ABI): the exchange is then ONE ncclAllGather inside libmpmc_energy.so
+    (mpmc_pi_gather_beads) and torch.distributed is not involved."""
     per_bead_local = np.ascontiguousarray(per_bead_local, dtype=np.float64).reshape(-1, 4)
     n_local = per_bead_local.shape[0]
-    if world == 1:
+    if comm is not None:
+        if comm.n_ranks * n_local != P:
+            raise ValueError("every rank must own P / n_ranks beads")
+        all_beads = comm.gather_beads(per_bead_local)
+    elif world == 1:
         all_beads = per_bead_local
     else:
         import torch
@@ -66,15 +72,16 @@ def combine(per_bead_local: np.ndarray, P: int, rank: int = 0, world: int = 1, g
 
 
 def pi_calculate_potential(local_eval: Callable[[], np.ndarray], P: int, rank: int = 0, world: int = 1, group=None,
-                           mode: str = "gather", device: Optional[str] = None) -> Tuple[float, np.ndarray]:
+                           mode: str = "gather", device: Optional[str] = None, comm=None) -> Tuple[float, np.ndarray]:
     """local_eval() -> (n_local, 4) per-bead energies of this rank (HIP path: energy.pi_potential_local)."""
-    return combine(local_eval(), P, rank, world, group, mode, device)
+    return combine(local_eval(), P, rank, world, group, mode, device, comm)
 
 
 def molecule_coms(pos: np.ndarray, mass: np.ndarray, mol_id: np.ndarray, frozen: np.ndarray):
     """Molecule::update_COM for every molecule of one image (reference src/Molecule.cpp:259-281), accumulated in atom
     order like the reference's list walk.  Returns (com (n_molecules, 3), mol_mass, movable): movable[m] = image 0's
-    molecule m counts in System::countN (src/System.cpp:909-931), i.e. its first atom is not frozen (:684)."""
+    molecule m counts in System::countN (src/System.cpp:909-931), i.e. its LAST atom row is not frozen (the reader overwrites
+    molecule->frozen on every row, :684)."""
     pos = np.asarray(pos, dtype=np.float64).reshape(-1, 3)
     mass = np.asarray(mass, dtype=np.float64)
     mol_id = np.asarray(mol_id)
@@ -86,7 +93,8 @@ def molecule_coms(pos: np.ndarray, mass: np.ndarray, mol_id: np.ndarray, frozen:
     c = np.zeros((nmol, 3))
     np.add.at(m, seg, mass)  # unbuffered, in atom order
     np.add.at(c, seg, mass[:, None] * pos)
-    return c / m[:, None], m, (np.asarray(frozen)[first] == 0).astype(np.int32)
+    last = np.r_[first[1:] - 1, n - 1] if n else np.zeros(0, dtype=int)
+    return c / m[:, None], m, (np.asarray(frozen)[last] == 0).astype(np.int32)
 
 
 def gather_beads(local: np.ndarray, P: int, rank: int = 0, world: int = 1, group=None, device: Optional[str] = None) -> np.ndarray:

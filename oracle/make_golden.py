@@ -8,7 +8,7 @@ For every named fixture in mpmcxx_amd/gen_box.py this script
   3. stores the harness JSON (energies, predicate counts, E0, mu, A-matrix spot blocks at %.17g) as
      tests/golden/NAME.json.
 The 10k-atom boxes are not stored as PQR text (regenerated deterministically by gen_box.fixture); only
-their energies are recorded (tests/golden/NAME.json with "atoms" omitted).
+their energies and the per-atom E0 / mu / E_ind of every 157th atom (64 atoms) are recorded.
 
 Fixtures are DATA (inputs + expected outputs).  No reference source text is written anywhere.
 Usage: python oracle/make_golden.py [--large] [names...]
@@ -60,7 +60,8 @@ def main():
         rows, basis, opts = gen_box.fixture(name)
         n = len(rows)
         spots = [f"0,1", f"1,0", f"0,{n - 1}", f"{n // 2},{n // 3}"] if n > 3 else ["0,1", "1,0"]
-        extra = [] if is_large else ["--dump-atoms"]
+        # small boxes: every atom's E0 / mu / E_ind and the update_com + wrap_all state; 10k boxes: a 64-atom sample (every 157th atom)
+        extra = ["--sample-atoms", "157"] if is_large else ["--dump-atoms", "--dump-com"]
         if opts.get("polarization") == "on" and not is_large:
             extra += ["--amatrix"] + spots
         res = run_harness(inp, extra)

@@ -9,7 +9,10 @@
 // No reference source text lives in this file; it only uses public members
 // declared in the reference headers (System.h, SimulationControl.h).
 //
-// usage: ref_harness INPUT.in [--time K] [--dump-atoms] [--amatrix i,j ...]
+// usage: ref_harness INPUT.in [--time K] [--dump-atoms] [--sample-atoms STRIDE] [--dump-com] [--amatrix i,j ...]
+//   --sample-atoms S : per-atom mu / ef_static / ef_induced of atoms 0, S, 2S, ... only (large boxes)
+//   --dump-com       : what pairs() leaves behind through update_com() + wrap_all() (src/System.cpp:1347-1425):
+//                      Molecule::com, Molecule::wrapped_com, Atom::wrapped_pos
 // Prints one JSON object on the LAST line of stdout (the reference prints its own
 // banner lines before it).
 
@@ -49,13 +52,18 @@ int main(int argc, char **argv) {
 		return 2;
 	}
 	int time_reps = 0;
-	bool dump_atoms = false;
+	bool dump_atoms = false, dump_com = false;
+	int sample_stride = 0;
 	std::vector<std::pair<int, int>> aspots;
 	for (int a = 2; a < argc; a++) {
 		if (!strcmp(argv[a], "--time") && a + 1 < argc)
 			time_reps = atoi(argv[++a]);
 		else if (!strcmp(argv[a], "--dump-atoms"))
 			dump_atoms = true;
+		else if (!strcmp(argv[a], "--dump-com"))
+			dump_com = true;
+		else if (!strcmp(argv[a], "--sample-atoms") && a + 1 < argc)
+			sample_stride = atoi(argv[++a]);
 		else if (!strcmp(argv[a], "--amatrix")) {
 			while (a + 1 < argc && argv[a + 1][0] != '-') {
 				int i = 0, j = 0;
@@ -153,6 +161,34 @@ int main(int argc, char **argv) {
 				printf("%s%.17g, %.17g, %.17g", i ? ", " : "", s.atom_array[i]->ef_induced[0], s.atom_array[i]->ef_induced[1],
 				       s.atom_array[i]->ef_induced[2]);
 			printf("]");
+		}
+
+		if (sample_stride > 0) {
+			printf(",\n \"sample_stride\": %d", sample_stride);
+			const char *names[3] = {"ef_static_sample", "mu_sample", "ef_induced_sample"};
+			for (int w = 0; w < 3; w++) {
+				printf(",\n \"%s\": [", names[w]);
+				for (int i = 0; i < n; i += sample_stride) {
+					const double *v = (w == 0) ? s.atom_array[i]->ef_static : (w == 1) ? s.atom_array[i]->mu : s.atom_array[i]->ef_induced;
+					printf("%s%.17g, %.17g, %.17g", i ? ", " : "", v[0], v[1], v[2]);
+				}
+				printf("]");
+			}
+		}
+
+		if (dump_com) {
+			int nm = 0;
+			printf(",\n \"com\": [");
+			for (Molecule *m = s.molecules; m; m = m->next, nm++) printf("%s%.17g, %.17g, %.17g", nm ? ", " : "", m->com[0], m->com[1], m->com[2]);
+			printf("],\n \"wrapped_com\": [");
+			nm = 0;
+			for (Molecule *m = s.molecules; m; m = m->next, nm++)
+				printf("%s%.17g, %.17g, %.17g", nm ? ", " : "", m->wrapped_com[0], m->wrapped_com[1], m->wrapped_com[2]);
+			printf("],\n \"wrapped_pos\": [");
+			for (int i = 0; i < n; i++)
+				printf("%s%.17g, %.17g, %.17g", i ? ", " : "", s.atom_array[i]->wrapped_pos[0], s.atom_array[i]->wrapped_pos[1],
+				       s.atom_array[i]->wrapped_pos[2]);
+			printf("],\n \"n_molecules\": %d", nm);
 		}
 
 		if (time_reps > 0) {

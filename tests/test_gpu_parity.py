@@ -36,7 +36,7 @@ def test_energy_matches_reference_golden(name):
         mu, E, F = S.dipoles()
         assert util.max_rel(E.reshape(-1), g["ef_static"]) < util.REL_TOL
         assert util.max_rel(mu.reshape(-1), g["mu"]) < util.REL_TOL
-        assert util.max_rel(F.reshape(-1), g["ef_induced"]) < 1e-8
+        assert util.max_rel(F.reshape(-1), g["ef_induced"]) < util.REL_TOL
         assert abs(r["dipole_rrms"] - g["dipole_rrms"]) <= 1e-6 * max(abs(g["dipole_rrms"]), 1e-30) + 1e-15
     S.close()
 
@@ -163,7 +163,7 @@ def test_every_dipole_solver_reproduces_the_reference(name, solver):
     assert r["polar_iterations"] == int(g["polar_iterations"]) and r["iterator_failed"] == g["iterator_failed"]
     mu, E, F = S.dipoles()
     assert util.max_rel(mu.reshape(-1), g["mu"]) < util.REL_TOL
-    assert util.max_rel(F.reshape(-1), g["ef_induced"]) < 1e-8
+    assert util.max_rel(F.reshape(-1), g["ef_induced"]) < util.REL_TOL
     S.close()
 
 
