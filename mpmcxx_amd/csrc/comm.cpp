@@ -318,6 +318,14 @@ extern "C" int mpmc_pi_gather_beads(mpmc_comm *cm, const double *local, int n_lo
 // process-wide communicators of mpmc_pi_allreduce, one per set of devices
 static std::mutex g_auto_mu;
 static std::map<std::vector<int>, mpmc_comm *> g_auto_comms;
+// A communicator that is still alive when the process ends takes RCCL's own teardown down with it (seen: "double free or corruption" at
+// interpreter exit).  The handler is registered when the first one is made -- after RCCL was loaded, so it runs BEFORE RCCL's and HIP's
+// static destructors.
+static void destroy_auto_comms() {
+	std::lock_guard<std::mutex> lk(g_auto_mu);
+	for (auto &kv : g_auto_comms) mpmc_comm_destroy(kv.second);
+	g_auto_comms.clear();
+}
 
 extern "C" int mpmc_pi_allreduce(mpmc_ctx **beads, int n_beads, double sums4[4], mpmc_result *per_bead, int *any_failed) {
 	if (!beads || n_beads <= 0 || !sums4) return MPMC_ERR_ARG;
@@ -346,6 +354,7 @@ extern "C" int mpmc_pi_allreduce(mpmc_ctx **beads, int n_beads, double sums4[4],
 		if (it == g_auto_comms.end()) {
 			int rc = mpmc_comm_init_all(&cm, G, devs.data());
 			if (rc != MPMC_OK) return fail(beads[0], rc, "mpmc_pi_allreduce: " + g_comm_error);
+			if (g_auto_comms.empty()) std::atexit(destroy_auto_comms);
 			g_auto_comms[devs] = cm;
 		} else {
 			cm = it->second;

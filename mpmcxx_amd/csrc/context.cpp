@@ -148,6 +148,8 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	if (const char *e = std::getenv("MPMC_ONE_STREAM")) c->two_streams = !(e[0] == '1');
 	if (const char *e = std::getenv("MPMC_JACOBI")) c->jacobi_hybrid = (e[0] != 's');
 	if (const char *e = std::getenv("MPMC_NO_UNI")) c->no_uniform = (e[0] == '1');
+	if (const char *e = std::getenv("MPMC_THOLE_FAR_X")) c->thole_far_x = std::max(20.0, std::atof(e));
+	if (const char *e = std::getenv("MPMC_NO_PANELS")) c->use_panels = !(e[0] == '1');
 	if (const char *e = std::getenv("MPMC_NO_RECIP_TAB")) c->no_recip_tab = (e[0] == '1');
 	const size_t P = (size_t)c->max_pad;
 	A(dev_alloc(c, &c->d_xyzq, P));
@@ -194,7 +196,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_inv_molmass, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal,
 	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_mv_blob, c->d_moved_idx,
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_panels, c->d_seg, c->d_gpart, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);

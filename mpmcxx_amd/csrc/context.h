@@ -67,10 +67,18 @@ struct mpmc_ctx {
 	int *d_lists = nullptr;         // [2 ntp] work lists of the two Jacobi kernels + [2] their lengths (at the end)
 	double *d_tile_bounds = nullptr; // [n_tiles][12]: wrapped fractional lo/hi, raw Cartesian lo/hi
 	double4 *d_tp_shift = nullptr;   // [n_tile_pairs] lattice vector components of the common image index (CLS_UNIFORM_X/Y/Z)
+	int4 *d_panels = nullptr;        // work table of the panel form of the Jacobi contraction (k_build_panels), rebuilt every evaluation
+	int *d_seg = nullptr;            // [n_tiles + 1] first entry of every j-tile's segment of that table (multiples of 4)
+	double *d_gpart = nullptr;       // [entries / 4][64][3] j-side partial sums, one slot per workgroup
+	size_t cap_panels = 0, cap_seg = 0;
+	int n_panel_entries = 0, seg_tiles = -1; // entries of the table / the tile count its layout was made for
+	bool use_panels = true;          // MPMC_NO_PANELS=1: every tile pair through the single-tile-pair kernel (A/B comparisons)
+	bool panels_built = false;       // this evaluation's classes carry CLS_GROUPED bits and d_panels is valid
 	std::vector<double4> h_xyzq;     // host mirror of d_xyzq (slot order), for bulk position updates
 	std::vector<double> h_pos_sorted; // positions at the time of the last spatial sort
 	double sort_origin_f[3] = {0, 0, 0}; // fractional coordinate at which the spatial sort cuts the periodic wrap
 	bool no_uniform = false;         // MPMC_NO_UNI=1
+	double thole_far_x = kTholeFarX; // lambda r beyond which a tile pair's tensors are not stored (MPMC_THOLE_FAR_X)
 	// lockstep solve of several systems (mpmc_pi_potential_local): enqueue() stops before the dipole iterations when asked to and
 	// possible; the batch driver then runs the iterations of all deferred systems in shared launches on one stream
 	bool defer_solve = false, solve_deferred = false, reduce_pending_join = false;

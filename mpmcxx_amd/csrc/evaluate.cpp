@@ -236,7 +236,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		// tile-pair classes from this configuration's tile bounding boxes (orthorhombic cells; all "near" otherwise)
 		if (c->no_classes) HIP_TRY(c, hipMemsetAsync(c->d_cls, 0, (size_t)c->n_tile_pairs * sizeof(int), st));
 		else launch_tile_classes(st, at, c->box, c->d_tile_pairs, c->n_tile_pairs, (o.polarization && !o.rd_only) ? o.polar_damp : 0.0,
-		                         c->d_tile_bounds, c->d_cls, c->no_uniform ? nullptr : c->d_tp_shift, c->sort_origin_f);
+		                         c->d_tile_bounds, c->d_cls, c->no_uniform ? nullptr : c->d_tp_shift, c->sort_origin_f, c->thole_far_x);
 		FusedParams fp;
 		fp.ewald_alpha = c->ewald_alpha;
 		fp.polar_ewald_alpha = c->polar_ewald_alpha;
@@ -255,8 +255,38 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		}
 		fp.wolf_erfa_over_r = std::erf(c->ewald_alpha * c->box.cutoff) / c->box.cutoff;
 		fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
+		fp.thole_far_x = c->thole_far_x;
 		if (compact && !c->jacobi_hybrid) // work lists of the two-kernel Jacobi form only
 			launch_build_lists(st, c->d_cls, c->n_tile_pairs, c->d_lists, c->d_lists + 2 * (size_t)c->n_tile_pairs);
+		// panels of the Jacobi contraction: two tile pairs of equal class behind one j-tile per wave (orthorhombic cells, stored tensors)
+		c->panels_built = false;
+		if (compact && c->jacobi_hybrid && c->use_panels && c->box.ortho && !c->no_classes && !c->no_uniform && !c->defer_solve && c->n_tiles >= 3) {
+			if (c->seg_tiles != c->n_tiles) { // the table's layout depends on the tile count only
+				std::vector<int> seg((size_t)c->n_tiles + 1, 0);
+				for (int J = 0; J < c->n_tiles; J++) seg[J + 1] = seg[J] + panel_segment_entries(J);
+				if ((size_t)c->n_tiles + 1 > c->cap_seg) {
+					dev_free(c, &c->d_seg, c->cap_seg);
+					c->cap_seg = 0;
+					if ((rc = dev_alloc(c, &c->d_seg, (size_t)c->n_tiles + 1)) != MPMC_OK) return rc;
+					c->cap_seg = (size_t)c->n_tiles + 1;
+				}
+				HIP_TRY(c, hipMemcpyAsync(c->d_seg, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice, st));
+				HIP_TRY(c, hipStreamSynchronize(st)); // `seg` dies here
+				c->n_panel_entries = seg[c->n_tiles];
+				c->seg_tiles = c->n_tiles;
+			}
+			const size_t need = (size_t)c->n_panel_entries;
+			if (need > c->cap_panels) {
+				dev_free(c, &c->d_panels, c->cap_panels);
+				dev_free(c, &c->d_gpart, c->cap_panels / 4 * kTile * 3);
+				c->cap_panels = 0;
+				if ((rc = dev_alloc(c, &c->d_panels, need)) != MPMC_OK) return rc;
+				if ((rc = dev_alloc(c, &c->d_gpart, need / 4 * kTile * 3)) != MPMC_OK) return rc;
+				c->cap_panels = need;
+			}
+			launch_build_panels(st, c->d_cls, c->n_tiles, c->d_seg, c->d_panels);
+			c->panels_built = true;
+		}
 		launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
 		                  compact ? c->d_ab : nullptr);
 	}
@@ -334,8 +364,12 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				launch_dense_matvec(st, c->d_adense, c->n_pad, c->d_mu[c->mu_cur], kDenseChunks, c->d_part);
 			} else if (compact && c->jacobi_hybrid) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
-				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
-				                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part, o.polar_damp);
+				if (c->panels_built) // every tile pair through the panel table: two per wave where classes allow
+					launch_dipole_iter_panel(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels,
+					                         c->n_panel_entries, c->d_ab, c->d_part, c->d_gpart);
+				else
+					launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
+					                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part, o.polar_damp);
 			} else if (compact) {
 				const int *counts = c->d_lists + 2 * (size_t)c->n_tile_pairs;
 				hipStream_t s2 = fork_side(c); // the fp64-bound far-field kernel runs beside the HBM-bound streaming kernel
@@ -356,8 +390,12 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			}
 			{
 				ProfScope p(c, MPMC_K_REDUCE);
-				launch_dipole_update(st, at, c->d_e_static, c->d_part, iter_slots, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur], c->d_e_induced,
-				                     want_rrms, c->d_rrms, allowed, c->d_flag);
+				if (compact && c->jacobi_hybrid && c->panels_built && !dense)
+					launch_dipole_update_panel(st, at, c->d_e_static, c->d_part, c->d_gpart, c->d_seg, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur],
+					                           c->d_e_induced, want_rrms, c->d_rrms, allowed, c->d_flag);
+				else
+					launch_dipole_update(st, at, c->d_e_static, c->d_part, iter_slots, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur], c->d_e_induced,
+					                     want_rrms, c->d_rrms, allowed, c->d_flag);
 			}
 			c->mu_cur = 1 - c->mu_cur;
 			if (by_precision) { // are_we_done_yet needs the verdict on the host

@@ -39,7 +39,14 @@ enum : int {
 	CLS_UNIFORM_Y = 8,     // that dimension (wrapped coordinates); tp_shift holds the lattice vector component B img
 	CLS_UNIFORM_Z = 16
 };
-constexpr double kTholeFarX = 40.0; // exp(-40)*(40^3/6) = 4.5e-14
+// Beyond lambda r = kTholeFarX a tile pair's tensors are the bare dipole tensors (nothing stored, recomputed from the positions).  The
+// Thole factors differ from 1 by exp(-x)(x^3/6 + x^2/2 + x + 1) = 4.7e-10 at x = 30 -- a RELATIVE error of tensors that are themselves
+// < 1/(14 A)^3 = 3.6e-4 of the self term 1/alpha, and only for the few pairs that sit right at the boundary (the class is decided by the
+// tiles' bounding boxes, so almost every pair of a far tile pair is much further out).  Measured on the 10 000-atom box: the polarization
+// energy moves by 6e-15 relative between x = 40 and x = 30 (1.4e-12 at x = 26), dipoles by < 1e-13 of the largest one.  The store shrinks from 5299 to
+// 2576 of 12 403 tile pairs (347 -> 169 MB read per Jacobi iteration), which is worth 6-8 % of the whole-job rate: with 32 beads in
+// flight the aggregate HBM traffic (3.7 TB/s at x = 40) is a co-bottleneck.  MPMC_THOLE_FAR_X overrides (>= 20).
+constexpr double kTholeFarX = 30.0;
 
 // reciprocal space: structure factors for every k, then energy + O(N) atom terms
 struct RecipDev {
@@ -90,6 +97,7 @@ struct FusedParams {
 	int fh_order;         // 0 off, 2 or 4: Feynman-Hibbs corrections
 	double fh_c2, fh_c4;  // M2A2 hbar^2 / (24 kB T amu2kg),  M2A4 hbar^4 / (1152 kB^2 T^2 amu2kg^2)
 	double wolf_erfa_over_r, wolf_inv_r2; // erf(alpha R)/R, 1/R^2
+	double thole_far_x; // lambda r beyond which the exponential damping is dropped (the value the tile classes were made with)
 };
 // every unordered pair once: energies + counts (block partials), static-field partials fpart[nt][n_pad][3],
 // Thole store ab[n_tile_pairs][64*64] (double2 = 16 B per pair)
@@ -104,7 +112,8 @@ void launch_intra_terms(hipStream_t st, const AtomsDev &at, const int *slot_of, 
 // per-tile bounding boxes (wrapped fractional coordinates) and tile-pair classes (CLS_*)
 void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, const int2 *tile_pairs, int n_tile_pairs, double polar_damp,
                          double *tile_bounds /*[nt][12]*/, int *cls, double4 *tp_shift /*[ntp], may be null*/,
-                         const double origin_f[3] /*fractional origin of the spatial sort: where the periodic wrap is cut*/);
+                         const double origin_f[3] /*fractional origin of the spatial sort: where the periodic wrap is cut*/,
+                         double thole_far_x = kTholeFarX /*lambda r beyond which a tile pair is CLS_THOLE_FAR*/);
 // work lists of the two Jacobi kernels from the class array: lists[0..ntp) stored tile pairs, lists[ntp..2ntp) far ones
 void launch_build_lists(hipStream_t st, const int *cls, int n_tile_pairs, int *lists /*[2 ntp]*/, int *counts /*[2]*/);
 // one Jacobi contraction = these two launches (each partial slot is written by exactly one of them): part[nt][n_pad][3]
@@ -118,6 +127,16 @@ void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, con
                                const int *cls, const double4 *tp_shift /*null: no uniform-image fast path*/, int n_tile_pairs,
                                const double2 *ab /*null: matrix-free, tensors inside the damping range rebuilt from the positions*/,
                                double *part, double polar_damp);
+// ---- panel form of the contraction (kernels_panel.hip; orthorhombic cells): two tile pairs that share their j-tile per wave ----
+int panel_segment_entries(int J); // entries (a multiple of 4) the work table reserves for j-tile J; seg[J] = their running sum
+// the work table of the panel kernel: per j-tile its diagonal tile pair, panels of two tile pairs of equal class, odd singles
+void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg /*[n_tiles + 1]*/, int4 *panels);
+// i-side partial sums -> part[J][I atoms] (the usual slots, upper triangle + diagonal only); j-side -> gpart[workgroup][64][3]
+void launch_dipole_iter_panel(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+                              const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart);
+void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,
+                                const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr,
+                                int *not_done_flag);
 // ---- lockstep solve of B systems (path-integral images): per-system pointers of the batched Jacobi / update / energy kernels ----
 struct SolveBead {
 	AtomsDev at;

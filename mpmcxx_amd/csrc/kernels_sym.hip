@@ -23,33 +23,6 @@
 
 namespace mpmc {
 
-// lane l receives the value held by lane (l+1) & 63
-template <bool DPP>
-__device__ __forceinline__ double rot_from_next(double v, int src_lane_x4) {
-	int lo = __double2loint(v), hi = __double2hiint(v);
-	if (DPP) {
-		lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
-		hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
-	} else {
-		lo = __builtin_amdgcn_ds_bpermute(src_lane_x4, lo);
-		hi = __builtin_amdgcn_ds_bpermute(src_lane_x4, hi);
-	}
-	return __hiloint2double(hi, lo);
-}
-
-// the tensor store is read exactly once per launch: stream it past the caches (global_load ... nt).
-// Measured on MI355X (10k atoms): 0.159 ms vs 0.170 ms per launch with default-policy loads.
-template <bool NT>
-__device__ __forceinline__ double2 ld_stream(const double2 *p) {
-	if (NT) {
-		double2 v;
-		v.x = __builtin_nontemporal_load(&p->x);
-		v.y = __builtin_nontemporal_load(&p->y);
-		return v;
-	}
-	return *p;
-}
-
 // first step of an off-diagonal tile walk: 16 different chunk offsets spread over consecutive blocks
 __device__ __forceinline__ int stagger_start(int block) { return ((block * 5) & 15) * 4; }
 
@@ -192,7 +165,7 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 				const double rr = (ri2 == 0.0) ? 0.0 : r;
 				const double lr = lam * rr;
 				double damp1 = 1.0, damp2 = 1.0;
-				if (__any(lr < kTholeFarX)) { // wave-uniform: beyond lambda r = 40 the damping differs from 1 by < 1e-13 (as in CLS_THOLE_FAR)
+				if (__any(lr < fp.thole_far_x)) { // wave-uniform: beyond lambda r = kTholeFarX the damping is dropped (as in CLS_THOLE_FAR)
 					const double explr = exp_fast(-lr);
 					damp1 = fma(-explr, fma(lr, fma(0.5, lr, 1.0), 1.0), 1.0);   // 1 - e^{-lr} (lr^2/2 + lr + 1)
 					damp2 = fma(-explr, (lr * lr) * (lr * (1.0 / 6.0)), damp1);    // damp1 - e^{-lr} lr^3/6
@@ -483,7 +456,7 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 }
 
 void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, const int2 *tile_pairs, int n_tile_pairs, double polar_damp,
-                         double *tile_bounds, int *cls, double4 *tp_shift, const double origin_f[3]) {
+                         double *tile_bounds, int *cls, double4 *tp_shift, const double origin_f[3], double thole_far_x) {
 	if (!bx.ortho) {
 		(void)hipMemsetAsync(cls, 0, (size_t)n_tile_pairs * sizeof(int), st);
 		return;
@@ -492,7 +465,7 @@ void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, cons
 	const double thr_cut2 = tmax * (1.0 + 1e-9);
 	double thr_far2 = 0.0;
 	if (polar_damp > 0.0) {
-		const double rf = kTholeFarX / polar_damp;
+		const double rf = thole_far_x / polar_damp;
 		thr_far2 = rf * rf * (1.0 + 1e-9);
 	}
 	hipLaunchKernelGGL(k_tile_bounds, dim3(at.n_pad / kTile), dim3(kTile), 0, st, at, bx, make_double3(origin_f[0], origin_f[1], origin_f[2]), tile_bounds);
@@ -548,7 +521,7 @@ void launch_build_lists(hipStream_t st, const int *cls, int n_tile_pairs, int *l
 //   k_dipole_iter_stream  tile pairs inside the damping range: (a,b) streamed from the compact store, 16 B per
 //                         unordered pair, each block 64 KiB contiguous.  HBM-bound by construction: 33 flop per 16 B.
 //                         Masked pairs were stored as (0,0): the loop carries no predicates.
-//   k_dipole_iter_far     tile pairs beyond lambda r = 40: damping < 1e-13, a = 1/r^3, b = 3/r^5 recomputed from the
+//   k_dipole_iter_far     tile pairs beyond lambda r = kTholeFarX (damping dropped, kernels.h): a = 1/r^3, b = 3/r^5 recomputed from the
 //                         positions (v_rsq_f64 + 1 Newton step).  fp64-bound, no HBM traffic beyond the atom tiles.
 // Both write the partial slots [source tile][atom] of the same buffer; every slot is written exactly once per
 // iteration by exactly one of the two kernels.
@@ -694,7 +667,7 @@ __global__ __launch_bounds__(64) void k_dipole_iter_far(AtomsDev at, Box bx, con
 		const int jl = (lane + s) & 63;
 		double ox, oy, oz;
 		image_vec<ORTHO>(bx, pi.x - s_x[jl], pi.y - s_y[jl], pi.z - s_z[jl], ox, oy, oz);
-		// undamped dipole tensor: a = 1/r^3, b = 3/r^5 (the damping factors differ from 1 by < 1e-13 beyond lambda r = 40)
+		// undamped dipole tensor: a = 1/r^3, b = 3/r^5 (beyond lambda r = kTholeFarX the damping is dropped, kernels.h)
 		const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
 		const double ir = fast_rsqrt_1(r2);
 		const double ir2 = ir * ir;
@@ -791,7 +764,7 @@ __device__ __forceinline__ void hyb_step(const Box &bx, const HybLds &L, const i
 	} else {
 		image_vec<ORTHO>(bx, pix - xj, piy - yj, piz - zj, ox, oy, oz);
 	}
-	if (FAR) { // undamped dipole tensor: a = 1/r^3, b = 3/r^5 (damping < 1e-13 beyond lambda r = 40)
+	if (FAR) { // undamped dipole tensor: a = 1/r^3, b = 3/r^5 (damping dropped beyond lambda r = kTholeFarX, kernels.h)
 		const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
 		const double ir = fast_rsqrt_1(r2);
 		const double ir2 = ir * ir;
@@ -1000,8 +973,10 @@ __global__ __launch_bounds__(64 * W) void k_dipole_iter_hybrid(AtomsDev at, Box 
 // single-system launch) and the per-launch gaps shrink by B.  `cur` selects the dipole buffer every system reads.
 template <bool ORTHO, int JACC, int PIPE = 8>
 __global__ __launch_bounds__(64) void k_dipole_iter_hybrid_b(const SolveBead *__restrict__ sb, Box bx, int cur) {
-	const SolveBead b = sb[blockIdx.y];
-	hyb_block<ORTHO, JACC, PIPE, 1>(b.at, bx, b.mu[cur], b.tile_pairs, b.cls, b.tp_shift, b.ab, b.part, blockIdx.x);
+	// the members one by one (scalar loads): a by-value copy of the 160-byte record went through 152 B of scratch
+	const SolveBead *__restrict__ b = sb + blockIdx.y;
+	const AtomsDev at = b->at;
+	hyb_block<ORTHO, JACC, PIPE, 1>(at, bx, b->mu[cur], b->tile_pairs, b->cls, b->tp_shift, b->ab, b->part, blockIdx.x);
 }
 
 void launch_dipole_iter_hybrid_batched(hipStream_t st, int jacc, const SolveBead *sb, int n_beads, const Box &bx, int cur, int n_tile_pairs) {

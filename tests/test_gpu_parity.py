@@ -227,8 +227,9 @@ def test_pi_local_loop_matches_per_bead_energies():
 
 @pytest.mark.parametrize("lockstep", ["0", "1"])
 def test_pi_local_loop_polarizable_lockstep_solve(monkeypatch, lockstep):
-    """MPMC_PI_LOCKSTEP=1: the Jacobi iterations of the beads share launches (blockIdx.y = bead); same arithmetic per bead, so the
-    per-bead energies equal stand-alone evaluations bit for bit, with and without it."""
+    """MPMC_PI_LOCKSTEP=1: the Jacobi iterations of the beads share launches (blockIdx.y = bead).  Without it the in-ensemble evaluation IS
+    the stand-alone one (bit for bit); the lockstep launches walk one tile pair per wave where the stand-alone path walks panels of two, so
+    there the per-atom sums differ in their last bits (1e-12)."""
     monkeypatch.setenv("MPMC_PI_LOCKSTEP", lockstep)
     atoms, basis, opts = util.load_fixture("ion1000_polar")
     beads = []
@@ -243,10 +244,16 @@ def test_pi_local_loop_polarizable_lockstep_solve(monkeypatch, lockstep):
     assert beads[0].last_batch_size() == (3 if (lockstep == "1" and plain) else 1)
     mu_batch = [b.dipoles()[0].copy() for b in beads]
     single = [b.energy() for b in beads]
-    assert [p["energy"] for p in per] == single
-    assert [p["polarization_energy"] for p in per] == [b.observables["polarization_energy"] for b in beads]
-    for m, b in zip(mu_batch, beads):
-        assert np.array_equal(m, b.dipoles()[0])
+    if lockstep == "0" or not plain:
+        assert [p["energy"] for p in per] == single
+        assert [p["polarization_energy"] for p in per] == [b.observables["polarization_energy"] for b in beads]
+        for m, b in zip(mu_batch, beads):
+            assert np.array_equal(m, b.dipoles()[0])
+    else:
+        for p, e, b in zip(per, single, beads):
+            assert util.close(p["energy"], e, 1e-13) and util.close(p["polarization_energy"], b.observables["polarization_energy"], 1e-12)
+        for m, b in zip(mu_batch, beads):
+            assert util.max_rel(m, b.dipoles()[0]) < 1e-12
     g = util.golden("ion1000_polar")
     assert all(p["polar_iterations"] == int(g["polar_iterations"]) for p in per)
     for b in beads:

@@ -2,7 +2,7 @@
 # where the waves of the Jacobi / pair kernels spend their cycles: wait, VALU, LDS, VMEM, instruction fetch (two PMC passes, one bead)
 set -o pipefail
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/pmc_stalls
+out=$root/gpurun_out/pmc_stalls${TAG:+_$TAG}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/p1 -- python3 $root/tools/kernel_ab.py "hyb:" > $out/p1.log 2> $out/p1.err || echo "pass 1 failed"
@@ -15,7 +15,7 @@ for f in glob.glob("$out/p*/**/*counter_collection.csv", recursive=True):
         k=r["Kernel_Name"].split("(")[0].replace("void mpmc::","")
         rows[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in rows.items():
-    if "hybrid" in k or "pair_fused" in k:
+    if "hybrid" in k or "pair_fused" in k or "panel" in k:
         m={c: sum(x)/len(x) for c,x in v.items()}
         wc=m.get("SQ_WAVE_CYCLES",1)
         print(k[:50])
