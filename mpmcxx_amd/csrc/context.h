@@ -68,8 +68,8 @@ struct mpmc_ctx {
 	double *d_tile_bounds = nullptr; // [n_tiles][12]: wrapped fractional lo/hi, raw Cartesian lo/hi
 	double4 *d_tp_shift = nullptr;   // [n_tile_pairs] lattice vector components of the common image index (CLS_UNIFORM_X/Y/Z)
 	int4 *d_panels = nullptr;        // work table of the panel form of the Jacobi contraction (k_build_panels), rebuilt every evaluation
-	int *d_seg = nullptr;            // [n_tiles + 1] first entry of every j-tile's segment of that table (multiples of 4)
-	double *d_gpart = nullptr;       // [entries / 4][64][3] j-side partial sums, one slot per workgroup
+	int *d_seg = nullptr;            // [n_tiles + 1] first entry of every j-tile's segment of that table
+	double *d_gpart = nullptr;       // [entries][64][3] j-side partial sums, one slot per entry of the table
 	size_t cap_panels = 0, cap_seg = 0;
 	int n_panel_entries = 0, seg_tiles = -1; // entries of the table / the tile count its layout was made for
 	bool use_panels = true;          // MPMC_NO_PANELS=1: every tile pair through the single-tile-pair kernel (A/B comparisons)

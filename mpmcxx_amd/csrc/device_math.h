@@ -85,7 +85,5 @@ __device__ __forceinline__ double erfc_and_gauss(double x, double &e) {
 	for (int k = MPMC_ERFCX_DEG - 1; k >= 0; --k) p = hstep(p, t, c[k]);
 	return e * (p * (d1 * inv)); // p / (1+2x)
 }
-// out-of-line copy for the rare second evaluation (user-set polar_ewald_alpha != ewald_alpha)
-static __device__ __noinline__ double erfc_and_gauss_cold(double x, double &e) { return erfc_and_gauss(x, e); }
 
 } // namespace mpmc

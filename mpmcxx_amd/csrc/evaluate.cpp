@@ -203,6 +203,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	const bool side_work = need_sf || (mask & RUN_ATOMTERMS) || need_intra;
 	// a fork/join costs ~20 us of dispatch latency: worth it next to reciprocal-space work, not for the O(N) atom terms alone
 	const bool side_fork = c->two_streams && (need_sf || need_intra);
+	bool panel_side = false; // the panel table of the Jacobi contraction is being built on the side stream
 	if (side_work) {
 		hipStream_t s2 = side_fork ? fork_side(c) : st;
 		if (need_intra) {
@@ -278,19 +279,22 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			const size_t need = (size_t)c->n_panel_entries;
 			if (need > c->cap_panels) {
 				dev_free(c, &c->d_panels, c->cap_panels);
-				dev_free(c, &c->d_gpart, c->cap_panels / 4 * kTile * 3);
+				dev_free(c, &c->d_gpart, c->cap_panels * kTile * 3);
 				c->cap_panels = 0;
 				if ((rc = dev_alloc(c, &c->d_panels, need)) != MPMC_OK) return rc;
-				if ((rc = dev_alloc(c, &c->d_gpart, need / 4 * kTile * 3)) != MPMC_OK) return rc;
+				if ((rc = dev_alloc(c, &c->d_gpart, need * kTile * 3)) != MPMC_OK) return rc;
 				c->cap_panels = need;
 			}
-			launch_build_panels(st, c->d_cls, c->n_tiles, c->d_seg, c->d_panels);
+			// the table is needed by the first Jacobi launch only: it is made beside the pair sweep (side stream, joined after the sweep)
+			hipStream_t sp = c->two_streams ? fork_side(c) : st;
+			panel_side = c->two_streams;
+			launch_build_panels(sp, c->d_cls, c->n_tiles, c->d_seg, c->d_panels);
 			c->panels_built = true;
 		}
 		launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
 		                  compact ? c->d_ab : nullptr);
 	}
-	if (side_work && side_fork) join_side(c);
+	if ((side_work && side_fork) || panel_side) join_side(c);
 	bool reduce_forked = false;
 	if (mask & RUN_PAIR) { // the scalar totals of the sweep are only read back at the very end: fold them beside the field / dipole work
 		reduce_forked = c->two_streams && (mask & RUN_FIELD) != 0;

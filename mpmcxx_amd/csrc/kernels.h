@@ -128,10 +128,10 @@ void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, con
                                const double2 *ab /*null: matrix-free, tensors inside the damping range rebuilt from the positions*/,
                                double *part, double polar_damp);
 // ---- panel form of the contraction (kernels_panel.hip; orthorhombic cells): two tile pairs that share their j-tile per wave ----
-int panel_segment_entries(int J); // entries (a multiple of 4) the work table reserves for j-tile J; seg[J] = their running sum
+int panel_segment_entries(int J); // entries the work table reserves for j-tile J; seg[J] = their running sum
 // the work table of the panel kernel: per j-tile its diagonal tile pair, panels of two tile pairs of equal class, odd singles
 void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg /*[n_tiles + 1]*/, int4 *panels);
-// i-side partial sums -> part[J][I atoms] (the usual slots, upper triangle + diagonal only); j-side -> gpart[workgroup][64][3]
+// i-side partial sums -> part[J][I atoms] (the usual slots, upper triangle + diagonal only); j-side -> gpart[entry][64][3]
 void launch_dipole_iter_panel(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                               const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart);
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,

@@ -27,12 +27,13 @@
 
 namespace mpmc {
 
-// Work table: one entry per wave, four entries (= one workgroup of four waves) share their j-tile.  Entries of j-tile J occupy
-// [seg[J], seg[J + 1]) (multiples of 4, host-made): its diagonal tile pair, at most floor(J / 2) panels of two tile pairs and up to two
-// single off-diagonal tile pairs (one per kind); unused entries carry tp = -1.
+// Work table: one entry per workgroup of four waves, which split the entry's walk by steps (short waves: the launch fills and drains
+// the chip in small units).  Entries of j-tile J occupy [seg[J], seg[J + 1]) (host-made): its diagonal tile pair, at most floor(J / 2)
+// panels of two tile pairs and up to two single off-diagonal tile pairs (one per kind); unused entries carry tp = -1.
 //   entry = { tile pair A, tile pair B (-1: single), uniform mask | far << 3 | diagonal << 4, J }
-int panel_segment_entries(int J) { return ((J / 2 + 3) + 3) / 4 * 4; }
+int panel_segment_entries(int J) { return J / 2 + 3; }
 constexpr int kPanFar = 8, kPanDiag = 16;
+constexpr int kPanelWaves = 4; // waves per workgroup: they split the steps of ONE entry's walk
 
 __device__ __forceinline__ int tp_index(int I, int J, int nt) { return I * nt - (I * (I - 1)) / 2 + (J - I); }
 
@@ -142,10 +143,10 @@ __device__ __forceinline__ void pan_walk(const double2 *__restrict__ s_xy, const
                                          const double2 *__restrict__ ab, const size_t (&ab_tile)[NI], const int s_first, const int n_steps,
                                          PanAcc<NI> &A) {
 	int jb = lane + s_first;
-	if (FAR) { // (never a diagonal tile pair: always 64 steps)
+	if (FAR) {
 		const double2 none[NI] = {};
 #define MPMC_FAR_LOOP(P)                                                                                                               \
-	for (int kc = 0; kc < kTile - 4; kc += 4, jb += 4) {                                                                               \
+	for (int kc = 0; kc < n_steps - 4; kc += 4, jb += 4) {                                                                             \
 		_Pragma("unroll") for (int u = 0; u < 4; ++u)                                                                                  \
 		    pan_step<JACC, true, NU, NI, true, P>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, none, A);                      \
 	}                                                                                                                                  \
@@ -197,10 +198,10 @@ __device__ __forceinline__ void pan_walk(const double2 *__restrict__ s_xy, const
 template <int JACC, int PIPE, int NI>
 __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
                                             const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab, double *__restrict__ part,
-                                            const int tpA, const int tpB, const int flags, const int J, double2 *__restrict__ s_xy,
-                                            double2 *__restrict__ s_zm, double2 *__restrict__ s_mm, double *__restrict__ s_valid,
-                                            double (*__restrict__ s_G)[kTile]) {
-	const int lane = threadIdx.x & 63;
+                                            double *__restrict__ gslot, const int tpA, const int tpB, const int flags, const int J,
+                                            double2 *__restrict__ s_xy, double2 *__restrict__ s_zm, double2 *__restrict__ s_mm,
+                                            double *__restrict__ s_valid, double (*__restrict__ s_F)[2][3][kTile], double (*__restrict__ s_G)[3][kTile]) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int src4 = ((lane + 1) & 63) * 4;
 	const int tps[2] = {tpA, tpB};
 	const int um = flags & 7; // dimensions uniform for every member
@@ -223,7 +224,7 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	const double L[3] = {pick(bx.b[0], bx.b[4], bx.b[8], p0), pick(bx.b[0], bx.b[4], bx.b[8], p1), pick(bx.b[0], bx.b[4], bx.b[8], p2)};
 	const double iL[3] = {pick(bx.r[0], bx.r[4], bx.r[8], p0), pick(bx.r[0], bx.r[4], bx.r[8], p1), pick(bx.r[0], bx.r[4], bx.r[8], p2)};
 
-	{ // j-tile into LDS, permuted, every value twice (slot l + s never wraps)
+	if (w == 0) { // j-tile into LDS, permuted, every value twice (slot l + s never wraps)
 		const double4 pj = at.xyzq[j0 + lane];
 		const double mx = mu[3 * (size_t)(j0 + lane)], my = mu[3 * (size_t)(j0 + lane) + 1], mz = mu[3 * (size_t)(j0 + lane) + 2];
 		const double2 xy = make_double2(pick(pj.x, pj.y, pj.z, p0), pick(pj.x, pj.y, pj.z, p1));
@@ -254,10 +255,10 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 		m[k][2] = pick(mx, my, mz, p2);
 		ab_tile[k] = (size_t)tps[k] * (kTile * kTile);
 	}
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the LDS image is this wave's own: no workgroup barrier, program order suffices
-	__builtin_amdgcn_wave_barrier();
+	__syncthreads();
 	const bool pad = (at.n != at.n_pad) && (J == at.n_pad / kTile - 1);
-	const int s_first = diag ? 1 : 0, n_steps = diag ? 32 : 64;
+	// the four waves split the walk: 16 steps each of the 64 of an off-diagonal tile pair (s = 0..63), 8 each of the 32 of a diagonal one (s = 1..32)
+	const int n_steps = (diag ? 32 : 64) / kPanelWaves, s_first = (diag ? 1 : 0) + w * n_steps;
 	PanAcc<NI> A = {};
 #define MPMC_PWALK(F, N) pan_walk<JACC, F, N, NI, PIPE>(s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
 	if (far) {
@@ -276,65 +277,71 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 		}
 	}
 #undef MPMC_PWALK
-	// un-permute and store.  After n_steps - 1 rotations lane l holds the accumulator of j = (l + s_first + n_steps - 1) & 63.
-	const int nt_pad3 = at.n_pad * 3;
-	auto unperm = [&](const double (&v)[3], double *o) { // o[p_d] = v[d] without dynamically indexed registers
-		o[0] = (p0 == 0) ? v[0] : ((p1 == 0) ? v[1] : v[2]);
-		o[1] = (p0 == 1) ? v[0] : ((p1 == 1) ? v[1] : v[2]);
-		o[2] = (p0 == 2) ? v[0] : ((p1 == 2) ? v[1] : v[2]);
-	};
-	// i-side: slot [J][I_k atoms] (the diagonal tile pair: [J][J atoms]).  j-side: parked in LDS at its atom; the workgroup's four
-	// waves share the j-tile, their G meet there and leave as ONE slot (k_dipole_iter_panel).
-#pragma unroll
-	for (int k = 0; k < NI; ++k) {
-		double o[3];
-		unperm(A.f[k], o);
-		double *oi = part + (size_t)J * nt_pad3 + 3 * (size_t)(Is[k] * kTile + lane);
-		oi[0] = o[0];
-		oi[1] = o[1];
-		oi[2] = o[2];
-	}
+	// the waves' partial sums meet in LDS: F of lane l's own atoms, G parked at the atom it belongs to -- after n_steps - 1 rotations
+	// lane l holds the accumulator of j = (l + s_first + n_steps - 1) & 63
 	{
 		const int jl_last = (lane + s_first + n_steps - 1) & 63;
-		double o[3];
-		unperm(A.g, o);
-		s_G[0][jl_last] = o[0];
-		s_G[1][jl_last] = o[1];
-		s_G[2][jl_last] = o[2];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+#pragma unroll
+			for (int k = 0; k < NI; ++k) s_F[w][k][d][lane] = A.f[k][d];
+			s_G[w][d][jl_last] = A.g[d];
+		}
 	}
+	__syncthreads();
+	if (w != 0) return;
+	// wave 0: sums in wave order (fixed => reproducible) and stores; the permutation is undone by the ADDRESS (component d of the
+	// walk is component p_d of the cell).  i-side: slot [J][I_k atoms]; j-side: this entry's slot.
+	const int nt_pad3 = at.n_pad * 3;
+	double g[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) g[d] = ((s_G[0][d][lane] + s_G[1][d][lane]) + s_G[2][d][lane]) + s_G[3][d][lane];
+#pragma unroll
+	for (int k = 0; k < NI; ++k) {
+		double f[3];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) f[d] = ((s_F[0][k][d][lane] + s_F[1][k][d][lane]) + s_F[2][k][d][lane]) + s_F[3][k][d][lane];
+		if (NI == 1 && diag) { // both sides are the same 64 atoms: one slot [J][J atoms] = F + G, nothing on the j-side
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				f[d] += g[d];
+				g[d] = 0.0;
+			}
+		}
+		double *oi = part + (size_t)J * nt_pad3 + 3 * (size_t)(Is[k] * kTile + lane);
+		oi[p0] = f[0];
+		oi[p1] = f[1];
+		oi[p2] = f[2];
+	}
+	gslot[3 * lane + p0] = g[0];
+	gslot[3 * lane + p1] = g[1];
+	gslot[3 * lane + p2] = g[2];
 }
 
-constexpr int kPanelWaves = 4;
 template <int JACC, int PIPE>
 __global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev at, Box bx, const double *__restrict__ mu,
                                                                         const int2 *__restrict__ tile_pairs, const double4 *__restrict__ tp_shift,
                                                                         const int4 *__restrict__ panels, const double2 *__restrict__ ab,
-                                                                        double *__restrict__ part, double *__restrict__ gpart /*[n_wg][64][3]*/) {
-	__shared__ double2 s_xy[kPanelWaves][2 * kTile], s_zm[kPanelWaves][2 * kTile], s_mm[kPanelWaves][2 * kTile];
-	__shared__ double s_valid[kPanelWaves][2 * kTile];
+                                                                        double *__restrict__ part, double *__restrict__ gpart /*[entries][64][3]*/) {
+	__shared__ double2 s_xy[2 * kTile], s_zm[2 * kTile], s_mm[2 * kTile];
+	__shared__ double s_valid[2 * kTile];
+	__shared__ double s_F[kPanelWaves][2][3][kTile];
 	__shared__ double s_G[kPanelWaves][3][kTile];
-	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int4 e = panels[blockIdx.x * kPanelWaves + w];
+	const int4 e = panels[blockIdx.x];
 	// everything that describes the entry is wave-uniform: keep it in scalar registers
 	const int tpA = __builtin_amdgcn_readfirstlane(e.x), tpB = __builtin_amdgcn_readfirstlane(e.y);
 	const int flags = __builtin_amdgcn_readfirstlane(e.z), J = __builtin_amdgcn_readfirstlane(e.w);
-	if (tpA < 0) { // unused entry of this j-tile's segment
-		s_G[w][0][lane] = s_G[w][1][lane] = s_G[w][2][lane] = 0.0;
-	} else if (tpB >= 0) {
-		panel_block<JACC, PIPE, 2>(at, bx, mu, tile_pairs, tp_shift, ab, part, tpA, tpB, flags, J, s_xy[w], s_zm[w], s_mm[w], s_valid[w], s_G[w]);
-	} else {
-		panel_block<JACC, PIPE, 1>(at, bx, mu, tile_pairs, tp_shift, ab, part, tpA, tpB, flags, J, s_xy[w], s_zm[w], s_mm[w], s_valid[w], s_G[w]);
+	double *gslot = gpart + (size_t)blockIdx.x * kTile * 3;
+	if (tpA < 0) { // unused entry of this j-tile's segment: its slot is read by the update kernel all the same
+		if (threadIdx.x < kTile) gslot[3 * threadIdx.x] = gslot[3 * threadIdx.x + 1] = gslot[3 * threadIdx.x + 2] = 0.0;
+		return;
 	}
-	__syncthreads();
-	if (w != 0) return;
-	double *o = gpart + ((size_t)blockIdx.x * kTile + lane) * 3; // wave order: fixed => reproducible
-	o[0] = ((s_G[0][0][lane] + s_G[1][0][lane]) + s_G[2][0][lane]) + s_G[3][0][lane];
-	o[1] = ((s_G[0][1][lane] + s_G[1][1][lane]) + s_G[2][1][lane]) + s_G[3][1][lane];
-	o[2] = ((s_G[0][2][lane] + s_G[1][2][lane]) + s_G[2][2][lane]) + s_G[3][2][lane];
+	if (tpB >= 0) panel_block<JACC, PIPE, 2>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
+	else panel_block<JACC, PIPE, 1>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
 }
 
 // new_mu = alpha (E0 + F), F = sum of the panel kernel's slots of this tile X: part[S][X atoms] for S = X .. nt-1 (i-side, the diagonal
-// included) and gpart[wg][.] for the workgroups of X's segment (j-side).  Same tail as k_dipole_update (contract_dipoles :3586-3593,
+// included) and gpart[e][.] for the entries of X's segment of the work table (j-side).  Same tail as k_dipole_update (contract_dipoles :3586-3593,
 // calc_dipole_rrms :3147-3177, are_we_done_yet :3227-3236).
 constexpr int kUpdGroups = 8;
 __global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDev at, const double *__restrict__ e_static, const double *__restrict__ part,
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDe
 	__shared__ double sh[kUpdGroups][kTile][3];
 	const int a = threadIdx.x & 63, g = threadIdx.x >> 6;
 	const int X = blockIdx.x, i = X * kTile + a;
-	const int nF = nt - X, wg0 = seg[X] / kPanelWaves, nG = seg[X + 1] / kPanelWaves - wg0;
+	const int nF = nt - X, wg0 = seg[X], nG = seg[X + 1] - wg0;
 	double f[3] = {0, 0, 0};
 	for (int t = g; t < nF + nG; t += kUpdGroups) {
 		const double *q = (t < nF) ? part + ((size_t)(X + t) * at.n_pad + i) * 3 : gpart + ((size_t)(wg0 + t - nF) * kTile + a) * 3;
@@ -398,7 +405,7 @@ void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int 
 void launch_dipole_iter_panel(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                               const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart) {
 	if (n_entries <= 0) return;
-	dim3 grid(n_entries / kPanelWaves), block(kTile * kPanelWaves);
+	dim3 grid(n_entries), block(kTile * kPanelWaves);
 	if (jacc == 1)
 		hipLaunchKernelGGL((k_dipole_iter_panel<1, 4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart);
 	else

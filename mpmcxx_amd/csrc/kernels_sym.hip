@@ -45,7 +45,10 @@ void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm) {
 // ------------------------------------------------------------------------------------------------------
 //   EXT   : adjacent physics compiled in (Wolf electrostatics, Feynman-Hibbs corrections); the default instantiations
 //           carry none of that code
-template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP, bool EXT = false>
+//   ALPHA2: polar_ewald_alpha differs from ewald_alpha (both user-set): the field term needs an erfc of its own.  An instantiation,
+//           not a call: an out-of-line second erfc put a function call into the loop, and the SGPRs saved around it (13 spilled
+//           through v_writelane / v_readlane, 16 B of scratch) were paid by every step of the common case.
+template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP, bool EXT = false, bool ALPHA2 = false>
 __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedParams fp, const int2 *__restrict__ tile_pairs,
                                                    const int *__restrict__ cls, double *__restrict__ block_part, int *__restrict__ block_cnt,
                                                    double *__restrict__ fpart /*[nt][n_pad][3]*/, double2 *__restrict__ ab) {
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 	__syncthreads();
 
 	const bool i_real = !(mi.y & AF_PAD);
-	const bool same_alpha = (fp.polar_ewald_alpha == fp.ewald_alpha);
+	constexpr bool same_alpha = !ALPHA2;
 	const double lam = fp.polar_damp;
 	double e_lj = 0, e_re = 0;
 	int n_lj = 0, n_es = 0;
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 					if (FIELD == 1 && fld_pair) { // real_term :2919-2934: erfc form, or erf form (= 1 - erfc) for es_excluded pairs
 						const double ap = fp.polar_ewald_alpha;
 						double ec = erfc_a, ga = gauss_a;
-						if (!same_alpha) ec = erfc_and_gauss_cold(ap * r, ga);
+						if (!same_alpha) ec = erfc_and_gauss(ap * r, ga);
 						const double g = (2.0 * kOneOverSqrtPi * ap) * (ga * r);
 						const double fac = (f.es_excluded ? (g - (1.0 - ec)) : (g + ec)) * (ir * ir * ir);
 						const double fj = fac * qj, fi = fac * pi.w;
@@ -308,6 +311,13 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 template <bool ORTHO, bool ES, int FIELD, bool THOLE>
 static void launch_fused_t(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, const int *cls,
                            int ntp, double *bpart, int *bcnt, double *fpart, double2 *ab) {
+	if (FIELD == 1 && fp.polar_ewald_alpha != fp.ewald_alpha) { // two different Ewald alphas: every extension compiled in, ds_bpermute or DPP
+		if (dpp)
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+		else
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+		return;
+	}
 	if ((ES && fp.wolf) || fp.fh_order) { // extended variant (Wolf / Feynman-Hibbs): DPP rotation only when the self-test allows it
 		if (dpp)
 			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
