@@ -1,10 +1,13 @@
 // examples/energy_cli.cpp -- single-point energy of a reference input file through the C++ facade.
 //   energy_cli INPUT.in            one JSON line: energy components (%.17g), counts, first dipole
+//   energy_cli INPUT.in --time N   N back-to-back energy() calls through the C++ facade: microseconds per call (no Python in the loop)
 //   energy_cli INPUT.in --parse    parse only (no GPU): n, basis, options and per-atom arrays, for checking the readers
 //   energy_cli INPUT.in --write OUT.pqr   re-write the geometry in the reference's PQR row layout
 //   energy_cli INPUT.in --pi B0.pqr B1.pqr ...          path-integral energy estimator over the P bead geometries given
 //   energy_cli INPUT.in --pi-kinetic B0.pqr B1.pqr ...  kinetic part only (host arithmetic, no GPU)
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -61,6 +64,17 @@ int main(int argc, char **argv) {
 				            a.charge, a.polarizability, a.epsilon, a.sigma, a.molecule, a.frozen);
 			}
 			std::printf("]}\n");
+			return 0;
+		}
+		if (argc > 3 && !std::strcmp(argv[2], "--time")) {
+			const int reps = std::atoi(argv[3]);
+			s.eager_dipoles = false; // per-atom vectors are fetched on demand, not after every call
+			double e = s.energy();
+			e = s.energy();
+			const auto t0 = std::chrono::steady_clock::now();
+			for (int k = 0; k < reps; k++) e = s.energy();
+			const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (reps > 0 ? reps : 1);
+			std::printf("{\"natoms\": %d, \"total\": %.17g, \"calls\": %d, \"us_per_call\": %.3f}\n", s.natoms, e, reps, us);
 			return 0;
 		}
 		const double e = s.energy();

@@ -149,6 +149,7 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	if (const char *e = std::getenv("MPMC_JACOBI")) c->jacobi_hybrid = (e[0] != 's');
 	if (const char *e = std::getenv("MPMC_NO_UNI")) c->no_uniform = (e[0] == '1');
 	if (const char *e = std::getenv("MPMC_THOLE_FAR_X")) c->thole_far_x = std::max(20.0, std::atof(e));
+	if (const char *e = std::getenv("MPMC_NO_SINGLE_LAUNCH")) c->single_launch = !(e[0] == '1');
 	if (const char *e = std::getenv("MPMC_NO_PANELS")) c->use_panels = !(e[0] == '1');
 	if (const char *e = std::getenv("MPMC_NO_RECIP_TAB")) c->no_recip_tab = (e[0] == '1');
 	const size_t P = (size_t)c->max_pad;
@@ -163,11 +164,12 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	A(dev_alloc(c, &c->d_perm, P));
 	A(dev_alloc(c, &c->d_scal, (size_t)S_COUNT + (size_t)C_COUNT)); // scalars and counts share one buffer: one clear, one read-back
 	if (rc == MPMC_OK) c->d_cnt = reinterpret_cast<long long *>(c->d_scal + S_COUNT);
-	A(dev_alloc(c, &c->d_flag, (size_t)1));
+	A(dev_alloc(c, &c->d_flag, (size_t)4)); // [0]: Gauss-Seidel's per-sweep flag; [1..3]: iteration control of the precision-terminated Jacobi solve
+	A(dev_alloc(c, &c->d_counter, (size_t)1));
 	static_assert(sizeof(long long) == sizeof(double), "scalars and counts share one buffer");
-	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_scal, (S_COUNT + C_COUNT) * sizeof(double)) != hipSuccess) rc = MPMC_ERR_HIP;
+	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_scal, (S_COUNT + C_COUNT + 1) * sizeof(double)) != hipSuccess) rc = MPMC_ERR_HIP;
 	if (rc == MPMC_OK) c->h_cnt = reinterpret_cast<long long *>(c->h_scal + S_COUNT);
-	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_flag, sizeof(int)) != hipSuccess) rc = MPMC_ERR_HIP;
+	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_flag, 4 * sizeof(int)) != hipSuccess) rc = MPMC_ERR_HIP;
 	if (rc == MPMC_OK) rc = rot_selftest(c);
 	if (rc != MPMC_OK) {
 		g_create_error = "mpmc_ctx_create: device allocation failed: " + c->err;
@@ -195,7 +197,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_inv_molmass, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal,
-	                c->d_flag, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
+	                c->d_flag, c->d_counter, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
 	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_panels, c->d_seg, c->d_gpart, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out};
 	for (void *p : ptrs)
@@ -243,6 +245,7 @@ extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *re
 	std::memcpy(c->box_in, in, sizeof(in)); // (only a call that was accepted is remembered)
 	c->box_in_has_recip = (reciprocal != nullptr);
 	c->k_dirty = true;
+	c->static_dirty = true;
 	c->atoms_dirty = true; // the spatial order depends on the cell
 	c->cache_valid = false;
 	return MPMC_OK;
@@ -281,6 +284,7 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 	c->opts = *o;
 	c->opts_set = true;
 	c->k_dirty = true;
+	c->static_dirty = true;
 	c->cache_valid = false;
 	return MPMC_OK;
 }
@@ -486,6 +490,7 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 
 	int rc = MPMC_OK;
 	c->atoms_dirty = true; // uploaded (in spatial order) by the next evaluation, when the box is known too
+	c->static_dirty = true;
 
 	// upper-triangular tile-pair schedule of the pair kernel
 	const int nt = c->n_tiles;

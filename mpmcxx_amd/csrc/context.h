@@ -91,6 +91,14 @@ struct mpmc_ctx {
 	size_t cap_tile_pairs = 0;
 	long long static_cnt[4] = {0, 0, 0, 0}; // n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent)
 
+	// position-independent scalars (pair LRC, self LRC, Ewald self term): functions of the atom parameters, the cell and the options
+	// only -- computed once (k_atom_terms) whenever one of those changed, kept on the host, added when a result is assembled
+	bool static_dirty = true;
+	double h_static[3] = {0, 0, 0}; // lrc_pair, lrc_self, es_self
+	int *d_counter = nullptr;       // ticket counter of the single-launch small-system kernels (zero between launches)
+	bool single_launch = true;      // MPMC_NO_SINGLE_LAUNCH=1: small systems take the general multi-kernel path
+	bool last_was_single = false;   // the pending evaluation wrote h_scal from the device: nothing to copy back
+	double single_seq = 0;          // launch number the single-launch kernel posts behind its results (host polls h_scal[S_COUNT + C_COUNT])
 	// scalars
 	double *d_scal = nullptr;
 	long long *d_cnt = nullptr;

@@ -1,5 +1,8 @@
 // evaluate.cpp -- one energy evaluation: k tables, work buffers, the enqueue of every kernel of double System::energy(), result assembly, component entry points
 // (part of libmpmc_energy.so; shared state and helpers: context.h.  There is no CPU fallback anywhere in this library.)
+#include <atomic>
+#include <chrono>
+
 #include "context.h"
 
 
@@ -63,6 +66,8 @@ static int build_k_tables(mpmc_ctx *c) {
 }
 
 constexpr int kDenseChunks = 16; // row chunks (= partial slots) of the dense matrix-vector product
+constexpr int kCheckEvery = 4;         // precision-terminated Jacobi solve: host reads the device-side verdict once per this many iterations
+constexpr int kSingleLaunchTiles = 32; // <= 2048 atoms (528 tile pairs): LJ-only evaluations run as ONE launch
 
 static int ensure_polar_buffers(mpmc_ctx *c) {
 	const size_t np = (size_t)c->max_pad;
@@ -147,6 +152,17 @@ int mpmc::prepare(mpmc_ctx *c) {
 		if (rc != MPMC_OK) return rc;
 		c->k_dirty = false;
 	}
+	if (c->static_dirty) { // pair LRC (O(N) moment form), self LRC, Ewald self term: position independent (lj_lrc_corr / lj_lrc_self :1036-1096, coulombic_self :1626-1643)
+		launch_atom_terms(c->stream, atoms_view(c), recip_view(c), c->box, c->ewald_alpha, c->opts.rd_lrc, /*self term*/ 2, c->d_scal);
+		HIP_TRY(c, hipGetLastError());
+		double tmp[S_COUNT];
+		HIP_TRY(c, hipMemcpyAsync(tmp, c->d_scal, sizeof(tmp), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		c->h_static[0] = tmp[S_LRC_PAIR];
+		c->h_static[1] = tmp[S_LRC_SELF];
+		c->h_static[2] = tmp[S_ES_SELF];
+		c->static_dirty = false;
+	}
 	return MPMC_OK;
 }
 
@@ -187,6 +203,20 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	c->iters = 0;
 	c->failed = 0;
 
+	c->last_was_single = false;
+	if (c->single_launch && mask == (RUN_PAIR | RUN_ATOMTERMS) && !o.feynman_hibbs && c->n_tiles <= kSingleLaunchTiles && !c->prof) {
+		// small LJ box (BASELINE configs[1]): the whole evaluation is one launch -- pair sweep without classes, the block that finishes last
+		// folds the partials into the pinned result vector; the LRC terms are the cached position-independent ones
+		FusedParams fp{};
+		fp.rd_lrc = o.rd_lrc;
+		c->single_seq += 1.0;
+		launch_pair_lj_single(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_counter, c->h_scal,
+		                      c->single_seq);
+		HIP_TRY(c, hipGetLastError());
+		c->last_was_single = true;
+		c->pending = true;
+		return MPMC_OK;
+	}
 	HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (S_COUNT + C_COUNT) * sizeof(double), st));
 
 	if (mask & (RUN_FIELD | RUN_SOLVE)) {
@@ -200,7 +230,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	// intramolecular charge-to-screen term of coulombic_real: position dependent but independent of the pair sweep; identically zero
 	// when every molecule is a single atom
 	const bool need_intra = (mask & RUN_PAIR) && (mask & RUN_PAIR_ES) && !(o.wolf && (mask & RUN_WOLF)) && (c->n_molecules != c->n);
-	const bool side_work = need_sf || (mask & RUN_ATOMTERMS) || need_intra;
+	const bool side_work = need_sf || need_intra;
 	// a fork/join costs ~20 us of dispatch latency: worth it next to reciprocal-space work, not for the O(N) atom terms alone
 	const bool side_fork = c->two_streams && (need_sf || need_intra);
 	bool panel_side = false; // the panel table of the Jacobi contraction is being built on the side stream
@@ -222,8 +252,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				}
 				launch_recip_sf(s2, at, c->box, rcp, o.ewald_kmax, c->d_sf_part);
 			}
-			if (mask & (RUN_RECIP | RUN_ATOMTERMS))
-				launch_atom_terms(s2, at, rcp, c->box, c->ewald_alpha, (mask & RUN_ATOMTERMS) ? o.rd_lrc : 0, (mask & RUN_RECIP) ? 1 : 0, c->d_scal);
+			if (mask & RUN_RECIP) launch_recip_energy(s2, rcp, c->box, c->d_scal); // (the LRC and self terms are cached: prepare())
 		}
 		if ((mask & RUN_FIELD) && o.polar_ewald) {
 			ProfScope p(c, MPMC_K_FIELD, s2);
@@ -333,6 +362,19 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			ProfScope p(c, MPMC_K_TENSOR);
 			launch_dense_build(st, at, c->box, o.polar_damp, c->d_adense);
 		}
+		// Precision-terminated Jacobi solves: are_we_done_yet (:3215-3239) runs on the device (ctl = {broke, converged-at, ticket}); the host
+		// enqueues kCheckEvery iterations at a time and reads the verdict once per batch -- the iterations enqueued behind the one that
+		// converged return at once and leave the dipoles alone.  (Gauss-Seidel sweeps and the dense solver still ask after every iteration.)
+		int *ctl = (by_precision && !o.polar_gs) ? c->d_flag + 1 : nullptr;
+		const int *converged = ctl ? ctl + 1 : nullptr;
+		const int check_every = dense ? 1 : kCheckEvery;
+		const int mu_start = c->mu_cur;
+		int done_at = 0;
+		int *host_flag = ctl ? c->h_flag + 2 : nullptr; // pinned {last closed iteration, converged-at} the closing update block posts
+		if (ctl) {
+			HIP_TRY(c, hipMemsetAsync(ctl, 0, 3 * sizeof(int), st));
+			c->h_flag[2] = c->h_flag[3] = 0; // (nothing of an earlier solve can still be in flight: every evaluation is waited for)
+		}
 		int it = 0;
 		bool keep = true;
 		while (keep) {
@@ -342,7 +384,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				c->failed = 1;
 				break;
 			}
-			if (by_precision) HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
+			if (by_precision && o.polar_gs) HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
 			if (o.polar_gs) { // in-place sweep in atom order; old_mu is kept only when rrms / precision need it (:3503-3507)
 				double *mu = c->d_mu[c->mu_cur], *mu_old = c->d_mu[1 - c->mu_cur];
 				if (want_rrms) HIP_TRY(c, hipMemcpyAsync(mu_old, mu, 3 * (size_t)at.n_pad * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -370,10 +412,11 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
 				if (c->panels_built) // every tile pair through the panel table: two per wave where classes allow
 					launch_dipole_iter_panel(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels,
-					                         c->n_panel_entries, c->d_ab, c->d_part, c->d_gpart);
+					                         c->n_panel_entries, c->d_ab, c->d_part, c->d_gpart, converged);
 				else
 					launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
-					                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part, o.polar_damp);
+					                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part, o.polar_damp,
+					                          converged);
 			} else if (compact) {
 				const int *counts = c->d_lists + 2 * (size_t)c->n_tile_pairs;
 				hipStream_t s2 = fork_side(c); // the fp64-bound far-field kernel runs beside the HBM-bound streaming kernel
@@ -390,25 +433,51 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			} else { // matrix-free: the same symmetric tile-pair walk with nothing stored (null store => damped tensors rebuilt)
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
 				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
-				                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, nullptr, c->d_part, o.polar_damp);
+				                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, nullptr, c->d_part, o.polar_damp,
+				                          converged);
 			}
 			{
 				ProfScope p(c, MPMC_K_REDUCE);
 				if (compact && c->jacobi_hybrid && c->panels_built && !dense)
 					launch_dipole_update_panel(st, at, c->d_e_static, c->d_part, c->d_gpart, c->d_seg, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur],
-					                           c->d_e_induced, want_rrms, c->d_rrms, allowed, c->d_flag);
+					                           c->d_e_induced, want_rrms, c->d_rrms, allowed, ctl, host_flag, it);
 				else
 					launch_dipole_update(st, at, c->d_e_static, c->d_part, iter_slots, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur], c->d_e_induced,
-					                     want_rrms, c->d_rrms, allowed, c->d_flag);
+					                     want_rrms, c->d_rrms, allowed, ctl, host_flag, it);
 			}
 			c->mu_cur = 1 - c->mu_cur;
-			if (by_precision) { // are_we_done_yet needs the verdict on the host
-				HIP_TRY(c, hipMemcpyAsync(c->h_flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-				HIP_TRY(c, hipStreamSynchronize(st));
-				keep = (*c->h_flag != 0);
+			if (by_precision) {
+				if (it % check_every == 0 || it + 1 >= kMaxIterationCount) { // the verdict of this batch
+					HIP_TRY(c, hipGetLastError());
+					// spin on the pinned flag until iteration `it` is closed (or an earlier one converged); a stream synchronisation costs
+					// ~15 us, this ~2.  Past a generous budget fall back to the blocking read (correct either way).
+					volatile const int *hf = host_flag;
+					const auto t0 = std::chrono::steady_clock::now();
+					bool seen = false;
+					for (int spins = 0;; ++spins) {
+						if (hf[0] >= it || hf[1] != 0) {
+							std::atomic_thread_fence(std::memory_order_acquire);
+							seen = true;
+							break;
+						}
+						if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+					}
+					if (seen) {
+						done_at = hf[1];
+					} else {
+						HIP_TRY(c, hipMemcpyAsync(c->h_flag, ctl + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+						HIP_TRY(c, hipStreamSynchronize(st));
+						done_at = *c->h_flag;
+					}
+					keep = (done_at == 0);
+				}
 			} else {
 				keep = (it != o.polar_max_iter);
 			}
+		}
+		if (done_at > 0) { // the iterations enqueued behind the converged one did nothing: the result is where iteration done_at left it
+			it = done_at;
+			c->mu_cur = (mu_start + done_at) & 1;
 		}
 		c->iters = it;
 		{
@@ -428,20 +497,36 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 	if (!c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_energy_wait: nothing enqueued");
 	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->sync_stream ? c->sync_stream : c->stream));
+	bool seen = false;
+	if (c->last_was_single) {
+		// the kernel posts its launch number behind the results (system-scope release): a short spin on the pinned slot returns a few
+		// microseconds before the driver's own completion path would; past the budget, or if anything is off, fall back to the sync
+		volatile const double *flag = c->h_scal + S_COUNT + C_COUNT;
+		const auto t0 = std::chrono::steady_clock::now();
+		for (int spins = 0;; ++spins) {
+			if (*flag == c->single_seq) {
+				std::atomic_thread_fence(std::memory_order_acquire);
+				seen = true;
+				break;
+			}
+			if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+		}
+	}
+	if (!seen) HIP_TRY(c, hipStreamSynchronize(c->sync_stream ? c->sync_stream : c->stream));
 	c->sync_stream = nullptr;
 	c->pending = false;
 	prof_harvest(c);
 	if (!out) return MPMC_OK;
 	std::memset(out, 0, sizeof(*out));
 	const double *s = c->h_scal;
+	const bool lrc = (c->run_mask & RUN_ATOMTERMS) && c->opts.rd_lrc;
 	out->lj_pairs = s[S_LJ];
-	out->lrc_pair = s[S_LRC_PAIR];
-	out->lrc_self = s[S_LRC_SELF];
-	out->rd_energy = (s[S_LJ] + s[S_LRC_PAIR]) + s[S_LRC_SELF];
+	out->lrc_pair = lrc ? c->h_static[0] : 0.0;
+	out->lrc_self = lrc ? c->h_static[1] : 0.0;
+	out->rd_energy = (out->lj_pairs + out->lrc_pair) + out->lrc_self;
 	out->es_real = s[S_ES_REAL] - s[S_ES_INTRA];
 	out->es_recip = s[S_ES_RECIP];
-	out->es_self = s[S_ES_SELF];
+	out->es_self = (c->run_mask & RUN_RECIP) ? c->h_static[2] : 0.0;
 	out->coulombic_energy = (out->es_real + out->es_recip) + out->es_self; // coulombic() :1412
 	out->polarization_energy = s[S_POLAR];
 	out->dipole_rrms = s[S_RRMS];

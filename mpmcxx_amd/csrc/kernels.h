@@ -71,10 +71,12 @@ void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const
 void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip,
                            const double *part, int n_split, double gamma, double *e_static, double *mu);
 
-// new_mu = alpha (E0 + F) ; optionally rrms per atom and the "broke tolerance" flag (are_we_done_yet)
+// new_mu = alpha (E0 + F) ; optionally rrms per atom.  Precision-terminated solves pass ctl = { broke, converged-at, ticket } (device
+// ints, zeroed at the start of the solve) and the iteration number: are_we_done_yet runs on the device, the kernels of iterations
+// enqueued after convergence return at once (see iteration_verdict in kernels.hip)
 void launch_dipole_update(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, int n_split,
                           const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom,
-                          double allowed_sqerr, int *not_done_flag);
+                          double allowed_sqerr, int *ctl, int *host_flag /*pinned {closed iteration, converged-at}, may be null*/, int it);
 // iterator failure: mu = alpha * E0
 void launch_dipole_reset(hipStream_t st, const AtomsDev &at, const double *e_static, double *mu);
 void launch_polar_energy(hipStream_t st, const AtomsDev &at, const double *mu, const double *e_static, const double *rrms_atom,
@@ -104,6 +106,13 @@ struct FusedParams {
 void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
                        const int *cls, int n_tile_pairs, double *block_part /*[ntp][2]*/, int *block_cnt /*[ntp][2]*/, double *fpart, double2 *ab);
 void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt);
+// LJ (+ counts) of a small system in ONE launch: no tile classes, the last-arriving block folds the partials and writes the scalar
+// vector [S_COUNT doubles][C_COUNT int64][seq] into pinned host memory (seq last: a host polling that slot finds the results
+// complete); `counter` is a zeroed int the kernel leaves zeroed
+void launch_pair_lj_single(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs, int n_tile_pairs,
+                           double *block_part, int *block_cnt, int *counter, double *out_host, double seq);
+// S_ES_RECIP = (4 pi / V) sum_k w_k |S_k|^2 from the structure factors of this configuration
+void launch_recip_energy(hipStream_t st, const RecipDev &rc, const Box &bx, double *scal);
 // position-independent pair-flag counts (n_intra, n_rd_excluded, n_es_excluded, n_frozen): once per atom upload
 void launch_static_counts(hipStream_t st, const AtomsDev &at, const int2 *tile_pairs, int n_tile_pairs, int *block_cnt /*[ntp][4]*/,
                           long long *cnt4);
@@ -126,17 +135,18 @@ void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const 
 void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                                const int *cls, const double4 *tp_shift /*null: no uniform-image fast path*/, int n_tile_pairs,
                                const double2 *ab /*null: matrix-free, tensors inside the damping range rebuilt from the positions*/,
-                               double *part, double polar_damp);
+                               double *part, double polar_damp, const int *converged = nullptr);
 // ---- panel form of the contraction (kernels_panel.hip; orthorhombic cells): two tile pairs that share their j-tile per wave ----
 int panel_segment_entries(int J); // entries the work table reserves for j-tile J; seg[J] = their running sum
 // the work table of the panel kernel: per j-tile its diagonal tile pair, panels of two tile pairs of equal class, odd singles
 void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg /*[n_tiles + 1]*/, int4 *panels);
 // i-side partial sums -> part[J][I atoms] (the usual slots, upper triangle + diagonal only); j-side -> gpart[entry][64][3]
 void launch_dipole_iter_panel(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                              const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart);
+                              const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart,
+                              const int *converged = nullptr);
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,
                                 const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr,
-                                int *not_done_flag);
+                                int *ctl, int *host_flag, int it);
 // ---- lockstep solve of B systems (path-integral images): per-system pointers of the batched Jacobi / update / energy kernels ----
 struct SolveBead {
 	AtomsDev at;

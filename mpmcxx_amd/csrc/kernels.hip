@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_atom_terms(AtomsDev at, RecipDev rc, Bo
 	double e = 0, self = 0, lrc = 0;
 	double m[13], mf[13], d6 = 0, d12 = 0, df6 = 0, df12 = 0;
 	for (int k = 0; k < 13; ++k) m[k] = mf[k] = 0;
-	if (do_es) {
+	if (do_es == 1) { // (do_es == 2: the self term alone -- the cached position-independent call of prepare())
 		for (int k = threadIdx.x; k < rc.K; k += 256) {
 			const double4 sf = rc.sf[k];
 			e += rc.w_en[k] * (sf.x * sf.x + sf.y * sf.y);
@@ -331,6 +331,21 @@ void launch_atom_terms(hipStream_t st, const AtomsDev &at, const RecipDev &rc, c
 	hipLaunchKernelGGL(k_atom_terms, dim3(1), dim3(256), 0, st, at, rc, bx, ewald_alpha, rd_lrc, do_es, scal);
 }
 
+// the position-dependent part of coulombic_reciprocal alone (:1609-1618): (4 pi / V) sum_k w_k |S_k|^2 -- K terms, one block
+__global__ __launch_bounds__(256) void k_recip_energy(RecipDev rc, Box bx, double *__restrict__ scal) {
+	__shared__ double sh[4];
+	double e = 0;
+	for (int k = threadIdx.x; k < rc.K; k += 256) {
+		const double4 sf = rc.sf[k];
+		e += rc.w_en[k] * (sf.x * sf.x + sf.y * sf.y);
+	}
+	e = block_sum_256(e, sh);
+	if (threadIdx.x == 0) scal[S_ES_RECIP] = e * (4.0 * kPi / bx.volume);
+}
+void launch_recip_energy(hipStream_t st, const RecipDev &rc, const Box &bx, double *scal) {
+	hipLaunchKernelGGL(k_recip_energy, dim3(1), dim3(256), 0, st, rc, bx, scal);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // static field
 // ------------------------------------------------------------------------------------------------------
@@ -463,12 +478,38 @@ void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, in
 	                   gamma, e_static, mu);
 }
 
+// are_we_done_yet (:3215-3239) on the device.  ctl = { "some atom broke the tolerance in this iteration", iteration at which the solve
+// converged (0: still iterating), ticket counter }.  Every update block ORs its verdict into ctl[0] and takes a ticket; the block
+// that comes last closes the iteration: nobody broke => ctl[1] = it.  From then on the contraction and update kernels of the
+// iterations the host had already enqueued return at once (the dipoles stay as they were), so the host looks at ctl[1] only once
+// every few iterations instead of synchronising after each one.  Call from the threads of wave 0 of the block.
+// host_flag (pinned, device-visible, may be null) = { last closed iteration, iteration at which the solve converged }: the host spins on
+// it instead of synchronising the stream.
+__device__ __forceinline__ void iteration_verdict(int *__restrict__ ctl, int *__restrict__ host_flag, int it, bool lane_broke) {
+	const bool wave_broke = __any(lane_broke);
+	if ((threadIdx.x & 63) != 0) return;
+	if (wave_broke) atomicOr(&ctl[0], 1);
+	__threadfence();
+	const int ticket = atomicAdd(&ctl[2], 1);
+	if (ticket != (int)gridDim.x - 1) return;
+	__threadfence();
+	const int broke = atomicOr(&ctl[0], 0);
+	if (!broke) ctl[1] = it;
+	ctl[0] = 0;
+	ctl[2] = 0;
+	if (host_flag) {
+		__hip_atomic_store(host_flag + 1, broke ? 0 : it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(host_flag, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
 // contract_dipoles tail :3586-3593, calc_dipole_rrms :3147-3177, are_we_done_yet :3227-3236
 __device__ __forceinline__ void dipole_update_block(const AtomsDev &at, const double *__restrict__ e_static, const double *__restrict__ part,
                                                     int n_split, const double *__restrict__ mu_old, double *__restrict__ mu_new,
                                                     double *__restrict__ e_induced, int want_rrms, double *__restrict__ rrms_atom,
-                                                    double allowed_sqerr, int *__restrict__ not_done_flag) {
+                                                    double allowed_sqerr, int *__restrict__ ctl, int *__restrict__ host_flag, int it) {
 	__shared__ double sh[kSlotGroups][kTile][3];
+	if (ctl && ctl[1] != 0) return; // converged in an earlier iteration (block-uniform)
 	const int a = threadIdx.x & 63, g = threadIdx.x >> 6;
 	const int i = blockIdx.x * kTile + a;
 	double fsum[3];
@@ -498,17 +539,17 @@ __device__ __forceinline__ void dipole_update_block(const AtomsDev &at, const do
 		if (!isfinite(r)) r = 0.0;
 		rrms_atom[i] = (i < at.n) ? r : 0.0;
 	}
-	if (allowed_sqerr > 0.0 && broke && i < at.n) atomicOr(not_done_flag, 1);
+	if (ctl) iteration_verdict(ctl, host_flag, it, allowed_sqerr > 0.0 && broke && i < at.n);
 }
 __global__ __launch_bounds__(512) void k_dipole_update(AtomsDev at, const double *__restrict__ e_static, const double *__restrict__ part,
                                                        int n_split, const double *__restrict__ mu_old, double *__restrict__ mu_new,
                                                        double *__restrict__ e_induced, int want_rrms, double *__restrict__ rrms_atom,
-                                                       double allowed_sqerr, int *__restrict__ not_done_flag) {
-	dipole_update_block(at, e_static, part, n_split, mu_old, mu_new, e_induced, want_rrms, rrms_atom, allowed_sqerr, not_done_flag);
+                                                       double allowed_sqerr, int *__restrict__ ctl, int *__restrict__ host_flag, int it) {
+	dipole_update_block(at, e_static, part, n_split, mu_old, mu_new, e_induced, want_rrms, rrms_atom, allowed_sqerr, ctl, host_flag, it);
 }
 __global__ __launch_bounds__(512) void k_dipole_update_b(const SolveBead *__restrict__ sb, int n_split, int cur, int want_rrms) {
 	const SolveBead b = sb[blockIdx.y];
-	dipole_update_block(b.at, b.e_static, b.part, n_split, b.mu[cur], b.mu[1 - cur], b.e_induced, want_rrms, b.rrms, 0.0, nullptr);
+	dipole_update_block(b.at, b.e_static, b.part, n_split, b.mu[cur], b.mu[1 - cur], b.e_induced, want_rrms, b.rrms, 0.0, nullptr, nullptr, 0);
 }
 
 __global__ __launch_bounds__(256) void k_dipole_reset(AtomsDev at, const double *__restrict__ e_static, double *__restrict__ mu) {
@@ -547,9 +588,9 @@ __global__ __launch_bounds__(256) void k_polar_energy_b(const SolveBead *__restr
 }
 
 void launch_dipole_update(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, int n_split, const double *mu_old,
-                          double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr, int *not_done_flag) {
+                          double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr, int *ctl, int *host_flag, int it) {
 	hipLaunchKernelGGL(k_dipole_update, dim3(at.n_pad / kTile), dim3(kTile * kSlotGroups), 0, st, at, e_static, part, n_split, mu_old, mu_new,
-	                   e_induced, want_rrms, rrms_atom, allowed_sqerr, not_done_flag);
+	                   e_induced, want_rrms, rrms_atom, allowed_sqerr, ctl, host_flag, it);
 }
 void launch_dipole_update_batched(hipStream_t st, const SolveBead *sb, int n_beads, int n_pad, int n_slots, int cur, int want_rrms) {
 	hipLaunchKernelGGL(k_dipole_update_b, dim3(n_pad / kTile, n_beads), dim3(kTile * kSlotGroups), 0, st, sb, n_slots, cur, want_rrms);

@@ -322,8 +322,10 @@ template <int JACC, int PIPE>
 __global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev at, Box bx, const double *__restrict__ mu,
                                                                         const int2 *__restrict__ tile_pairs, const double4 *__restrict__ tp_shift,
                                                                         const int4 *__restrict__ panels, const double2 *__restrict__ ab,
-                                                                        double *__restrict__ part, double *__restrict__ gpart /*[entries][64][3]*/) {
+                                                                        double *__restrict__ part, double *__restrict__ gpart /*[entries][64][3]*/,
+                                                                        const int *__restrict__ converged /*null, or &ctl[1] of the precision-terminated solve*/) {
 	__shared__ double2 s_xy[2 * kTile], s_zm[2 * kTile], s_mm[2 * kTile];
+	if (converged && *converged != 0) return; // an iteration enqueued ahead of the verdict: nothing to do
 	__shared__ double s_valid[2 * kTile];
 	__shared__ double s_F[kPanelWaves][2][3][kTile];
 	__shared__ double s_G[kPanelWaves][3][kTile];
@@ -348,8 +350,9 @@ __global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDe
                                                                          const double *__restrict__ gpart, const int *__restrict__ seg, int nt,
                                                                          const double *__restrict__ mu_old, double *__restrict__ mu_new,
                                                                          double *__restrict__ e_induced, int want_rrms, double *__restrict__ rrms_atom,
-                                                                         double allowed_sqerr, int *__restrict__ not_done_flag) {
+                                                                         double allowed_sqerr, int *__restrict__ ctl, int *__restrict__ host_flag, int it) {
 	__shared__ double sh[kUpdGroups][kTile][3];
+	if (ctl && ctl[1] != 0) return; // converged in an earlier iteration (block-uniform)
 	const int a = threadIdx.x & 63, g = threadIdx.x >> 6;
 	const int X = blockIdx.x, i = X * kTile + a;
 	const int nF = nt - X, wg0 = seg[X], nG = seg[X + 1] - wg0;
@@ -395,7 +398,23 @@ __global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDe
 		if (!isfinite(r)) r = 0.0;
 		rrms_atom[i] = (i < at.n) ? r : 0.0;
 	}
-	if (allowed_sqerr > 0.0 && broke && i < at.n) atomicOr(not_done_flag, 1);
+	if (ctl) { // are_we_done_yet on the device (iteration_verdict in kernels.hip; repeated here: separate translation unit)
+		const bool wave_broke = __any(allowed_sqerr > 0.0 && broke && i < at.n);
+		if (a != 0) return;
+		if (wave_broke) atomicOr(&ctl[0], 1);
+		__threadfence();
+		const int ticket = atomicAdd(&ctl[2], 1);
+		if (ticket != (int)gridDim.x - 1) return;
+		__threadfence();
+		const int any_broke = atomicOr(&ctl[0], 0);
+		if (!any_broke) ctl[1] = it;
+		ctl[0] = 0;
+		ctl[2] = 0;
+		if (host_flag) { // pinned { last closed iteration, converged-at }: the host spins on it instead of synchronising the stream
+			__hip_atomic_store(host_flag + 1, any_broke ? 0 : it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(host_flag, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
 }
 
 void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg, int4 *panels) {
@@ -403,20 +422,21 @@ void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int 
 }
 
 void launch_dipole_iter_panel(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                              const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart) {
+                              const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart,
+                              const int *converged) {
 	if (n_entries <= 0) return;
 	dim3 grid(n_entries), block(kTile * kPanelWaves);
 	if (jacc == 1)
-		hipLaunchKernelGGL((k_dipole_iter_panel<1, 4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart);
+		hipLaunchKernelGGL((k_dipole_iter_panel<1, 4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged);
 	else
-		hipLaunchKernelGGL((k_dipole_iter_panel<0, 4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart);
+		hipLaunchKernelGGL((k_dipole_iter_panel<0, 4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged);
 }
 
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,
                                 const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr,
-                                int *not_done_flag) {
+                                int *ctl, int *host_flag, int it) {
 	hipLaunchKernelGGL(k_dipole_update_panel, dim3(at.n_pad / kTile), dim3(kTile * kUpdGroups), 0, st, at, e_static, part, gpart, seg, at.n_pad / kTile,
-	                   mu_old, mu_new, e_induced, want_rrms, rrms_atom, allowed_sqerr, not_done_flag);
+	                   mu_old, mu_new, e_induced, want_rrms, rrms_atom, allowed_sqerr, ctl, host_flag, it);
 }
 
 } // namespace mpmc

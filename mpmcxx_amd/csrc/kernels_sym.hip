@@ -48,22 +48,32 @@ void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm) {
 //   ALPHA2: polar_ewald_alpha differs from ewald_alpha (both user-set): the field term needs an erfc of its own.  An instantiation,
 //           not a call: an out-of-line second erfc put a function call into the loop, and the SGPRs saved around it (13 spilled
 //           through v_writelane / v_readlane, 16 B of scratch) were paid by every step of the common case.
-template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP, bool EXT = false, bool ALPHA2 = false>
-__global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedParams fp, const int2 *__restrict__ tile_pairs,
+//   TAIL  : small systems, LJ only: the block that finishes last adds up the block partials (fixed order) and writes the scalar
+//           results straight into the caller's pinned host buffer -- the whole evaluation is ONE launch, no classes, no copy back
+struct PairTail {
+	int *counter;     // zero between launches (the last block resets it)
+	double *out_host; // [S_COUNT + C_COUNT + 1] device-visible pinned host memory (mpmc_ctx::h_scal); the last slot receives `seq`
+	double seq;       // launch number: written AFTER the results (system-scope fence in between), so a host that polls it sees them
+};
+template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP, bool EXT = false, bool ALPHA2 = false, bool TAIL = false>
+__global__ __launch_bounds__(TAIL ? 256 : 64) void k_pair_fused(AtomsDev at, Box bx, FusedParams fp, const int2 *__restrict__ tile_pairs,
                                                    const int *__restrict__ cls, double *__restrict__ block_part, int *__restrict__ block_cnt,
-                                                   double *__restrict__ fpart /*[nt][n_pad][3]*/, double2 *__restrict__ ab) {
+                                                   double *__restrict__ fpart /*[nt][n_pad][3]*/, double2 *__restrict__ ab, PairTail tail = PairTail{}) {
 	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_q[kTile], s_sig[kTile], s_sqe[kTile];
 	__shared__ int s_mol[kTile], s_fl[kTile];
 	__shared__ double s_g[3 * kTile];
 
-	const int lane = threadIdx.x;
+	// TAIL (single-launch form of small systems): four waves share a tile pair, a quarter of the steps each -- a lone wave needs 16 us
+	// for its 64 dependent steps, and with a few hundred tile pairs there are SIMDs to spare
+	constexpr int W = TAIL ? 4 : 1;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int2 IJ = tile_pairs[blockIdx.x];
 	const bool diag = (IJ.x == IJ.y);
 	const int i = IJ.x * kTile + lane;
 	const int j0 = IJ.y * kTile;
 	const int src4 = ((lane + 1) & 63) * 4;
 	// tile-pair class (wave-uniform): whole tile pair beyond the cutoff / beyond the Thole damping range
-	const int cl = cls[blockIdx.x];
+	const int cl = TAIL ? 0 : cls[blockIdx.x]; // (the single-launch form of small systems carries no classes: every tile pair is "near")
 	const bool beyond = (cl & CLS_BEYOND_CUTOFF) != 0;
 	const bool store_thole = THOLE && !(cl & CLS_THOLE_FAR);
 	if (beyond && !store_thole) { // nothing position dependent to do: publish zeros so the fixed-shape reductions stay valid
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 		imm_i = at.inv_molmass[i];
 		s_imm[lane] = at.inv_molmass[j0 + lane];
 	}
-	{
+	if (w == 0) {
 		const double4 pj = at.xyzq[j0 + lane];
 		const double2 lj = at.lj[j0 + lane];
 		const int2 mj = at.mf[j0 + lane];
@@ -126,7 +136,8 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 	constexpr int kSpecial = AF_FROZEN | AF_NULL_RD | AF_HAS_DISP | AF_NEG_SIGMA | AF_ZERO_SIGMA | AF_ZERO_Q | AF_PAD;
 	const bool plain = !__any(((mi.y | s_fl[lane]) & kSpecial) != 0);
 
-	for (int k = 0; k < n_steps; ++k) {
+	const int k_begin = w * (n_steps / W), k_end = k_begin + n_steps / W;
+	for (int k = k_begin; k < k_end; ++k) {
 		const int s = diag ? (s_first + k) : ((s_first + k) & 63);
 		const bool last = (k == n_steps - 1);
 		const int jl = (lane + s) & 63;
@@ -300,11 +311,70 @@ __global__ __launch_bounds__(64) void k_pair_fused(AtomsDev at, Box bx, FusedPar
 	e_re = wave_sum(e_re);
 	n_lj = wave_sum_i(n_lj);
 	n_es = wave_sum_i(n_es);
+	if (W > 1) { // the waves' shares of the tile pair, added in wave order
+		__shared__ double s_pe[W][2];
+		__shared__ int s_pc[W][2];
+		if (lane == 0) {
+			s_pe[w][0] = e_lj;
+			s_pe[w][1] = e_re;
+			s_pc[w][0] = n_lj;
+			s_pc[w][1] = n_es;
+		}
+		__syncthreads();
+		if (w != 0) return;
+		for (int k = 1; k < W; ++k) {
+			e_lj += s_pe[k][0];
+			e_re += s_pe[k][1];
+			n_lj += s_pc[k][0];
+			n_es += s_pc[k][1];
+		}
+	}
 	if (lane == 0) {
 		block_part[2 * (size_t)blockIdx.x] = e_lj;
 		block_part[2 * (size_t)blockIdx.x + 1] = e_re;
 		block_cnt[2 * (size_t)blockIdx.x] = n_lj;
 		block_cnt[2 * (size_t)blockIdx.x + 1] = n_es;
+	}
+	if (TAIL) {
+		// last-arriving block: everybody publishes its partials (release), takes a ticket; the holder of the last ticket sees them all
+		// (acquire) and folds them in block order -- the same order whichever block comes last, so the result is reproducible
+		// (only wave 0 of a block is still here)
+		int is_last = 0;
+		if (lane == 0) {
+			__threadfence();
+			const int ticket = atomicAdd(tail.counter, 1);
+			is_last = (ticket == (int)gridDim.x - 1);
+		}
+		if (!__builtin_amdgcn_readfirstlane(is_last)) return; // lane 0's verdict for the whole wave
+		__threadfence();
+		double s0 = 0, s1 = 0;
+		long long c0 = 0, c1 = 0;
+		for (int b = lane; b < (int)gridDim.x; b += kTile) {
+			s0 += __builtin_nontemporal_load(block_part + 2 * (size_t)b);
+			s1 += __builtin_nontemporal_load(block_part + 2 * (size_t)b + 1);
+			c0 += __builtin_nontemporal_load(block_cnt + 2 * (size_t)b);
+			c1 += __builtin_nontemporal_load(block_cnt + 2 * (size_t)b + 1);
+		}
+		s0 = wave_sum(s0);
+		s1 = wave_sum(s1);
+		for (int off = 32; off > 0; off >>= 1) {
+			c0 += __shfl_down(c0, off, 64);
+			c1 += __shfl_down(c1, off, 64);
+		}
+		if (lane < S_COUNT + C_COUNT) {
+			double v = 0.0;
+			if (lane == S_LJ) v = s0;
+			if (lane == S_ES_REAL) v = s1;
+			tail.out_host[lane] = v;
+		}
+		if (lane == 0) {
+			long long *cnt = reinterpret_cast<long long *>(tail.out_host + S_COUNT);
+			cnt[C_LJ_IN] = c0;
+			cnt[C_ES_IN] = c1;
+			*tail.counter = 0;
+		}
+		__threadfence_system();
+		if (lane == 0) __hip_atomic_store(tail.out_host + S_COUNT + C_COUNT, tail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 
@@ -346,6 +416,23 @@ static void launch_fused_o(hipStream_t st, bool dpp, const AtomsDev &at, const B
 		if (thole) launch_fused_t<ORTHO, true, 2, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
 		else launch_fused_t<ORTHO, true, 2, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
 	}
+}
+
+// small systems, LJ (+ LRC) only: one launch, results land in `out_host` (pinned, device-visible) when the stream has drained
+void launch_pair_lj_single(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs, int n_tile_pairs,
+                           double *block_part, int *block_cnt, int *counter, double *out_host, double seq) {
+	const PairTail tail{counter, out_host, seq};
+	dim3 grid(n_tile_pairs), block(4 * kTile);
+#define MPMC_LJ1(O, D) \
+	hipLaunchKernelGGL((k_pair_fused<O, false, 0, false, D, false, false, true>), grid, block, 0, st, at, bx, fp, tile_pairs, nullptr, block_part, block_cnt, nullptr, nullptr, tail)
+	if (bx.ortho) {
+		if (dpp) MPMC_LJ1(true, true);
+		else MPMC_LJ1(true, false);
+	} else {
+		if (dpp) MPMC_LJ1(false, true);
+		else MPMC_LJ1(false, false);
+	}
+#undef MPMC_LJ1
 }
 
 void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
@@ -974,7 +1061,8 @@ template <bool ORTHO, int JACC, int PIPE = 8, int W = 1>
 __global__ __launch_bounds__(64 * W) void k_dipole_iter_hybrid(AtomsDev at, Box bx, const double *__restrict__ mu,
                                                                 const int2 *__restrict__ tile_pairs, const int *__restrict__ cls,
                                                                 const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab,
-                                                                double *__restrict__ part, double lambda) {
+                                                                double *__restrict__ part, double lambda, const int *__restrict__ converged) {
+	if (converged && *converged != 0) return; // an iteration enqueued ahead of the verdict of a precision-terminated solve
 	hyb_block<ORTHO, JACC, PIPE, W>(at, bx, mu, tile_pairs, cls, tp_shift, ab, part, blockIdx.x, lambda);
 }
 
@@ -1001,10 +1089,11 @@ void launch_dipole_iter_hybrid_batched(hipStream_t st, int jacc, const SolveBead
 }
 
 void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                               const int *cls, const double4 *tp_shift, int n_tile_pairs, const double2 *ab, double *part, double polar_damp) {
+                               const int *cls, const double4 *tp_shift, int n_tile_pairs, const double2 *ab, double *part, double polar_damp,
+                               const int *converged) {
 	dim3 grid(n_tile_pairs);
 #define MPMC_LAUNCH_HYB(O, J, P, W) \
-	hipLaunchKernelGGL((k_dipole_iter_hybrid<O, J, P, W>), grid, dim3(kTile * W), 0, st, at, bx, mu, tile_pairs, cls, tp_shift, ab, part, polar_damp)
+	hipLaunchKernelGGL((k_dipole_iter_hybrid<O, J, P, W>), grid, dim3(kTile * W), 0, st, at, bx, mu, tile_pairs, cls, tp_shift, ab, part, polar_damp, converged)
 	if (bx.ortho) {
 		if (jacc == 1) MPMC_LAUNCH_HYB(true, 1, 8, 1);
 		else MPMC_LAUNCH_HYB(true, 0, 8, 1);
