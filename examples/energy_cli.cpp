@@ -4,6 +4,8 @@
 //   energy_cli INPUT.in --parse    parse only (no GPU): n, basis, options and per-atom arrays, for checking the readers
 //   energy_cli INPUT.in --write OUT.pqr   re-write the geometry in the reference's PQR row layout
 //   energy_cli INPUT.in --pi B0.pqr B1.pqr ...          path-integral energy estimator over the P bead geometries given
+//   energy_cli INPUT.in --pi-rccl B0.pqr B1.pqr ...     the same with the cross-rank exchange on RCCL (a one-rank communicator of
+//                                                      mpmc_comm_init_rank bound to the ensemble: PathIntegralEnsemble::use_comm)
 //   energy_cli INPUT.in --pi-kinetic B0.pqr B1.pqr ...  kinetic part only (host arithmetic, no GPU)
 #include <chrono>
 #include <cstdio>
@@ -34,6 +36,15 @@ int main(int argc, char **argv) {
 			}
 			pi.nSys = (int)beads.size();
 			pi.temperature = beads[0]->temperature;
+			mpmc_comm *comm = nullptr;
+			if (!std::strcmp(argv[2], "--pi-rccl")) {
+				char id[MPMC_COMM_ID_BYTES];
+				if (mpmc_comm_unique_id(id) != MPMC_OK || mpmc_comm_init_rank(&comm, 1, 0, id, 0) != MPMC_OK) {
+					std::printf("{\"error\": \"%s\"}\n", mpmc_comm_last_error(nullptr));
+					return 1;
+				}
+				pi.use_comm(comm);
+			}
 			const mpmc::observables_t &o = pi.sys_observables;
 			if (kinetic_only) {
 				const double k = pi.PI_calculate_kinetic();
@@ -44,6 +55,7 @@ int main(int argc, char **argv) {
 			const double e = pi.PI_calculate_energy();
 			std::printf("{\"P\": %d, \"N\": %.17g, \"energy\": %.17g, \"kinetic\": %.17g, \"rd\": %.17g, \"es\": %.17g, \"polar\": %.17g}\n", pi.nSys,
 			            o.N, e, o.kinetic_energy, o.rd_energy, o.coulombic_energy, o.polarization_energy);
+			if (comm) mpmc_comm_destroy(comm);
 			return 0;
 		}
 		mpmc::System s;

@@ -37,6 +37,8 @@ extern "C" {
 #define MPMC_ERR_UNSUPPORTED 4004        /* unsupported_setting: physics outside the hot path */
 #define MPMC_ERR_INVALID_DATUM 6001      /* invalid_datum (bad atom arrays)                               */
 #define MPMC_ERR_BOX 6004                /* invalid_box_dimensions                                        */
+#define MPMC_ERR_INVALID_MC_MOVE 20000   /* internal_err_invalid_mc_move: the two boxes of a coordinated move disagree (constants.h:147) */
+#define MPMC_ERR_INVALID_MC_MOVE_KIND 102 /* invalid_monte_carlo_move (constants.h:110)                  */
 #define MPMC_ERR_NO_DEVICE (-1)          /* no HIP device / HIP runtime failure at create                 */
 #define MPMC_ERR_HIP (-2)                /* a HIP call failed (text in mpmc_last_error)                   */
 #define MPMC_ERR_ARG (-3)                /* NULL / out-of-range argument                                  */
@@ -262,6 +264,32 @@ int mpmc_pi_gather_beads(mpmc_comm *comm, const double *local, int n_local, int 
  * process-wide ncclCommInitAll communicator of the devices involved, and returns the UN-normalised ordered sums over beads 0..n-1
  * (identical on every device: an all-reduce with a fixed summation order).  mpmc_pi_finish divides by P. */
 int mpmc_pi_allreduce(mpmc_ctx **beads, int n_beads, double sums4[4], mpmc_result *per_bead, int *any_iterator_failed);
+
+/* ---- Gibbs ensemble: the two boxes of SimulationControl::Gibbs_mc -------------------------------------------------------
+ * Reference: final_energy[0] = systems[0]->energy(); final_energy[1] = systems[1]->energy(); (src/SimulationControl.Gibbs.cpp:179-180),
+ * then boltzmann_factor_NVT_Gibbs (:358-522).  The boxes are independent evaluations: box 0 -> device 0, box 1 -> device 1 of the node
+ * (mpmc_ctx_create's device argument); mpmc_gibbs_energy enqueues both before it waits for either. */
+int mpmc_gibbs_energy(mpmc_ctx *box_a, mpmc_ctx *box_b, mpmc_result *out_a, mpmc_result *out_b);
+/* move types as the reference enumerates them (src/constants.h:87-95) */
+#define MPMC_MOVETYPE_INSERT 0
+#define MPMC_MOVETYPE_REMOVE 1
+#define MPMC_MOVETYPE_DISPLACE 2
+#define MPMC_MOVETYPE_ADIABATIC 3
+#define MPMC_MOVETYPE_SPINFLIP 4
+#define MPMC_MOVETYPE_VOLUME 5
+#define MPMC_MOVETYPE_PERTURB_BEADS 6
+typedef struct mpmc_gibbs_move {
+	int32_t movetype[2];       /* sys[i]->checkpoint->movetype                                                  */
+	double temperature;        /* sys[0]->temperature                                                           */
+	double init_energy[2];     /* energies of the accepted configuration                                        */
+	double final_energy[2];    /* systems[i]->energy() after the move (may be non-finite: bad contact)          */
+	double N[2], volume[2];    /* sys[i]->observables->N / ->volume AFTER the move                              */
+	double checkpoint_volume_0; /* sys[0]->checkpoint->observables->volume (the volume the move started from)   */
+} mpmc_gibbs_move;
+/* boltzmann_factor[i] = sys[i]->nodestats->boltzmann_factor; energy[i] (may be NULL) receives MAXVALUE where the reference overwrites
+ * observables->energy on a bad contact.  Entries the reference leaves untouched are left untouched.  Returns MPMC_OK, or the
+ * reference's throw codes 20000 / 102, or MPMC_ERR_UNSUPPORTED for spin-flip moves (quantum rotation is outside the path). */
+int mpmc_gibbs_boltzmann_factor(const mpmc_gibbs_move *move, double boltzmann_factor[2], double energy[2]);
 
 /* ---- SimulationControl::PI_calculate_kinetic (PathIntegral.cpp:806-824) and its chain measure (:851-965) ----
  * Host-side O(P * n_molecules); no device work.  com: centres of mass [P][n_molecules][3] of the P images of every

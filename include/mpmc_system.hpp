@@ -383,6 +383,21 @@ public:
 	observables_t sys_observables; // the aggregate "sys.observables" of the reference
 	std::function<std::vector<double>(const std::vector<double> &)> allgather;
 
+	// one process per GPU: the exchange runs on RCCL inside libmpmc_energy.so (mpmc_pi_gather_beads: ONE ncclAllGather per call, the
+	// reference's 4 x MPI_Allgather, PathIntegral.cpp:763-766).  `comm` comes from mpmc_comm_init_rank; nSys = P over all ranks.
+	void use_comm(mpmc_comm *comm) {
+		allgather = [this, comm](const std::vector<double> &mine) {
+			const int n_local = (int)systems.size();
+			int n_ranks = 1;
+			(void)mpmc_comm_info(comm, &n_ranks, nullptr, nullptr);
+			const int stride = n_local > 0 ? (int)(mine.size() / (size_t)n_local) : 0;
+			std::vector<double> all((size_t)n_ranks * mine.size());
+			const int rc = mpmc_pi_gather_beads(comm, mine.data(), n_local, stride, all.data());
+			if (rc != MPMC_OK) throw rc;
+			return all;
+		};
+	}
+
 	// PI_calculate_potential for a TRIAL configuration in which atoms [first, first+count) of every image sit at new_pos[image]:
 	// per-move delta energies behind the same aggregate (every image enqueued before the first wait); the Systems keep the accepted
 	// configuration until accept_trial() / reject_trial()

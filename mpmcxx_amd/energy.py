@@ -63,6 +63,11 @@ class Result(C.Structure):
         return {f: getattr(self, f) for f, _ in self._fields_}
 
 
+class GibbsMove(C.Structure):
+    _fields_ = [("movetype", C.c_int32 * 2), ("temperature", C.c_double), ("init_energy", C.c_double * 2), ("final_energy", C.c_double * 2),
+                ("N", C.c_double * 2), ("volume", C.c_double * 2), ("checkpoint_volume_0", C.c_double)]
+
+
 class Timings(C.Structure):
     _fields_ = [("ms", C.c_double * 7), ("launches", C.c_int64 * 7)]
 
@@ -123,6 +128,8 @@ def lib():
     L.mpmc_trial_energy.argtypes = [vp, C.POINTER(Result)]
     L.mpmc_trial_accept.argtypes = [vp]
     L.mpmc_trial_reject.argtypes = [vp]
+    L.mpmc_gibbs_energy.argtypes = [vp, vp, C.POINTER(Result), C.POINTER(Result)]
+    L.mpmc_gibbs_boltzmann_factor.argtypes = [C.POINTER(GibbsMove), dp, dp]
     L.mpmc_rccl_version.argtypes = [C.POINTER(C.c_int)]
     L.mpmc_comm_unique_id.argtypes = [C.c_char_p]
     L.mpmc_comm_init_rank.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_int]
@@ -383,6 +390,32 @@ def pi_potential_local(beads: Sequence[System]):
     for b, r in zip(beads, per):
         b.observables = r
     return sums, per, bool(failed.value)
+
+
+def gibbs_energy(box_a: System, box_b: System):
+    """both boxes of a Gibbs ensemble (reference SimulationControl.Gibbs.cpp:179-180): enqueued together, waited for together; the boxes
+    usually live on two devices (System(..., device=0) / System(..., device=1)).  Returns (E_a, E_b)."""
+    ra, rb = Result(), Result()
+    rc = lib().mpmc_gibbs_energy(box_a.handle, box_b.handle, C.byref(ra), C.byref(rb))
+    if rc != MPMC_OK:
+        raise MpmcError(rc, ((lib().mpmc_last_error(box_a.handle) or b"") + b" / " + (lib().mpmc_last_error(box_b.handle) or b"")).decode())
+    box_a.observables, box_b.observables = ra.as_dict(), rb.as_dict()
+    return ra.energy, rb.energy
+
+
+def gibbs_boltzmann_factor(movetype, temperature, init_energy, final_energy, N, volume, checkpoint_volume_0, current=(float("nan"), float("nan"))):
+    """SimulationControl::boltzmann_factor_NVT_Gibbs (reference Gibbs.cpp:358-522).  Returns (status, [bf_a, bf_b], [energy_a, energy_b]);
+    entries the reference leaves untouched come back as `current` / the final energies."""
+    m = GibbsMove()
+    m.movetype[0], m.movetype[1] = int(movetype[0]), int(movetype[1])
+    m.temperature = float(temperature)
+    for k in range(2):
+        m.init_energy[k], m.final_energy[k], m.N[k], m.volume[k] = float(init_energy[k]), float(final_energy[k]), float(N[k]), float(volume[k])
+    m.checkpoint_volume_0 = float(checkpoint_volume_0)
+    bf = np.array(current, dtype=np.float64)
+    en = np.array(final_energy, dtype=np.float64)
+    rc = lib().mpmc_gibbs_boltzmann_factor(C.byref(m), _dp(bf), _dp(en))
+    return rc, bf, en
 
 
 def pi_allreduce(beads: Sequence[System]):
