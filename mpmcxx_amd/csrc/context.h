@@ -157,6 +157,12 @@ struct mpmc_ctx {
 	std::vector<double> trial_new, trial_old;
 	int *d_mv_slot = nullptr, *d_mv_orig = nullptr, *d_moved_idx = nullptr; // d_mv_slot/d_mv_orig/d_mv_new live in ONE allocation (d_mv_blob)
 	double4 *d_mv_new = nullptr, *d_sf_trial = nullptr;
+	// polarizable boxes: the real-space static field of the accepted configuration (k_field_finalize) and of the trial one
+	// (e_real + delta of the pairs with a moved atom); they trade places on accept.  dk_part: scratch of k_delta_field.
+	double *d_e_real = nullptr, *d_e_real_trial = nullptr, *d_dk_part = nullptr;
+	size_t cap_dk_part = 0;
+	bool e_real_valid = false;     // d_e_real describes the accepted configuration
+	bool trial_polar_delta = false; // the open trial took the incremental polarizable path (positions swapped on the device)
 	unsigned char *d_mv_blob = nullptr, *h_mv_blob = nullptr; // device / pinned host staging of a trial's moved-atom list
 	int cap_sf_trial = 0;
 	double *d_delta_out = nullptr, *h_delta_out = nullptr;
@@ -262,7 +268,10 @@ inline void join_side(mpmc_ctx *c) {
 
 
 // ---- shared between the translation units ---------------------------------------------------------------------
-enum : unsigned { RUN_PAIR = 1, RUN_PAIR_ES = 2, RUN_RECIP = 4, RUN_ATOMTERMS = 8, RUN_FIELD = 16, RUN_SOLVE = 32, RUN_WOLF = 64 };
+enum : unsigned {
+	RUN_PAIR = 1, RUN_PAIR_ES = 2, RUN_RECIP = 4, RUN_ATOMTERMS = 8, RUN_FIELD = 16, RUN_SOLVE = 32, RUN_WOLF = 64,
+	RUN_STORE = 128 // tile classes + the Thole tensor store alone (no energies, no field): trial moves of polarizable boxes
+};
 int prepare(mpmc_ctx *c);                        // uploads what is dirty, (re)builds the k tables, resolves the solver (evaluate.cpp)
 int enqueue(mpmc_ctx *c, unsigned mask);         // one evaluation (the pieces in `mask`) on the context's streams (evaluate.cpp)
 int wait_and_fill(mpmc_ctx *c, mpmc_result *out); // waits for it and assembles the result (evaluate.cpp)

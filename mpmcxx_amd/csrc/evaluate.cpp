@@ -79,6 +79,8 @@ static int ensure_polar_buffers(mpmc_ctx *c) {
 		if ((rc = dev_alloc(c, &c->d_e_induced, 3 * np)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_rrms, np)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_e_recip_part, (size_t)kKSplit * 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_e_real, 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_e_real_trial, 3 * np)) != MPMC_OK) return rc;
 		// (dev_alloc zero-fills on the context's stream; nothing in this library touches the null stream, which is unordered against
 		// our non-blocking streams)
 	}
@@ -219,7 +221,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	}
 	HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (S_COUNT + C_COUNT) * sizeof(double), st));
 
-	if (mask & (RUN_FIELD | RUN_SOLVE)) {
+	if (mask & (RUN_FIELD | RUN_SOLVE | RUN_STORE)) {
 		if ((rc = ensure_polar_buffers(c)) != MPMC_OK) return rc;
 		if ((rc = resolve_solver(c)) != MPMC_OK) return rc;
 	}
@@ -261,7 +263,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	}
 
 	// ---- pairwise pass: one symmetric sweep (energies + counts, static-field partials, Thole tensor store) ----------
-	if (mask & (RUN_PAIR | RUN_FIELD)) {
+	if (mask & (RUN_PAIR | RUN_FIELD | RUN_STORE)) {
 		ProfScope p(c, MPMC_K_PAIR);
 		// tile-pair classes from this configuration's tile bounding boxes (orthorhombic cells; all "near" otherwise)
 		if (c->no_classes) HIP_TRY(c, hipMemsetAsync(c->d_cls, 0, (size_t)c->n_tile_pairs * sizeof(int), st));
@@ -286,6 +288,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		fp.wolf_erfa_over_r = std::erf(c->ewald_alpha * c->box.cutoff) / c->box.cutoff;
 		fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
 		fp.thole_far_x = c->thole_far_x;
+		fp.store_only = ((mask & RUN_STORE) && !(mask & (RUN_PAIR | RUN_FIELD))) ? 1 : 0;
 		if (compact && !c->jacobi_hybrid) // work lists of the two-kernel Jacobi form only
 			launch_build_lists(st, c->d_cls, c->n_tile_pairs, c->d_lists, c->d_lists + 2 * (size_t)c->n_tile_pairs);
 		// panels of the Jacobi contraction: two tile pairs of equal class behind one j-tile per wave (orthorhombic cells, stored tensors)
@@ -320,8 +323,9 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			launch_build_panels(sp, c->d_cls, c->n_tiles, c->d_seg, c->d_panels);
 			c->panels_built = true;
 		}
-		launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
-		                  compact ? c->d_ab : nullptr);
+		if (!(fp.store_only && !compact)) // (a store-only pass without a store to fill has nothing to do beyond the classes)
+			launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
+			                  compact ? c->d_ab : nullptr);
 	}
 	if ((side_work && side_fork) || panel_side) join_side(c);
 	bool reduce_forked = false;
@@ -337,7 +341,8 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		ProfScope p(c, MPMC_K_FIELD);
 		c->mu_cur = 0;
 		launch_field_finalize(st, at, c->box, o.polar_ewald, c->d_e_recip_part, c->d_part, c->n_tiles, o.polar_gamma, c->d_e_static,
-		                      c->d_mu[0]);
+		                      c->d_mu[0], c->d_e_real);
+		c->e_real_valid = (mask == full_mask(c)); // (with the accepted positions resident: what trial moves update incrementally)
 	}
 
 	// ---- thole_iterative, reference src/System.Energy.cpp:3450-3543 ------------------------------------------------

@@ -69,7 +69,8 @@ void launch_atom_terms(hipStream_t st, const AtomsDev &at, const RecipDev &rc, c
 void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double *e_recip /*[kKSplit][n_pad][3]*/);
 // E0 = recip*(8 pi/V) + sum_s part ; mu0 = gamma * alpha * E0
 void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip,
-                           const double *part, int n_split, double gamma, double *e_static, double *mu);
+                           const double *part, int n_split, double gamma, double *e_static, double *mu,
+                           double *e_real_out = nullptr /*the real-space part alone (sum of the slots): what a trial move updates incrementally*/);
 
 // new_mu = alpha (E0 + F) ; optionally rrms per atom.  Precision-terminated solves pass ctl = { broke, converged-at, ticket } (device
 // ints, zeroed at the start of the solve) and the iteration number: are_we_done_yet runs on the device, the kernels of iterations
@@ -100,6 +101,7 @@ struct FusedParams {
 	double fh_c2, fh_c4;  // M2A2 hbar^2 / (24 kB T amu2kg),  M2A4 hbar^4 / (1152 kB^2 T^2 amu2kg^2)
 	double wolf_erfa_over_r, wolf_inv_r2; // erf(alpha R)/R, 1/R^2
 	double thole_far_x; // lambda r beyond which the exponential damping is dropped (the value the tile classes were made with)
+	int store_only;     // nothing but the Thole tensor store (trial moves of polarizable boxes: energies and field come from the delta kernels)
 };
 // every unordered pair once: energies + counts (block partials), static-field partials fpart[nt][n_pad][3],
 // Thole store ab[n_tile_pairs][64*64] (double2 = 16 B per pair)
@@ -188,6 +190,12 @@ void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const 
                   const int *mv_slot, const int *orig_of_mv, const double4 *mv_new, int m, int *moved_idx, double4 *sf_trial,
                   double *block_part, int *block_cnt, double *out4, long long *dcnt2);
 void launch_commit_positions(hipStream_t st, double4 *xyzq, const int *mv_slot, const double4 *mv_new, int m);
+// polarizable boxes: e_real_trial = e_real + (real-space static field of the pairs with a moved atom, new minus old geometry);
+// dk_part: scratch [n_tiles][m][3]
+void launch_delta_field(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_ewald_alpha, int polar_ewald, const int *mv_slot,
+                        const double4 *mv_new, int m, int *moved_idx, const double *e_real, double *e_real_trial, double *dk_part);
+// resident positions of the moved atoms <-> mv_new (call again to undo)
+void launch_swap_positions(hipStream_t st, double4 *xyzq, const int *mv_slot, double4 *mv_new, int m);
 
 // device-resident positions [n][3] in original atom order -> xyzq[slot].xyz (perm[slot] = original index)
 void launch_set_positions(hipStream_t st, const double *pos_dev, const int *perm, double4 *xyzq, int n);

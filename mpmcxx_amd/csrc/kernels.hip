@@ -401,13 +401,15 @@ __device__ __forceinline__ void slot_sum_64(const double *__restrict__ part, int
 
 __global__ __launch_bounds__(512) void k_field_finalize(AtomsDev at, Box bx, int polar_ewald, const double *__restrict__ e_recip_part,
                                                         const double *__restrict__ part, int n_split, double gamma,
-                                                        double *__restrict__ e_static, double *__restrict__ mu) {
+                                                        double *__restrict__ e_static, double *__restrict__ mu, double *__restrict__ e_real_out) {
 	__shared__ double sh[kSlotGroups][kTile][3];
 	const int a = threadIdx.x & 63, g = threadIdx.x >> 6;
 	const int i = blockIdx.x * kTile + a;
 	double real[3];
 	slot_sum_64(part, n_split, at.n_pad, i, a, g, sh, real);
 	if (g != 0) return;
+	if (e_real_out)
+		for (int p = 0; p < 3; ++p) e_real_out[3 * (size_t)i + p] = real[p];
 	double e[3] = {0, 0, 0};
 	if (polar_ewald) {
 		for (int s = 0; s < kKSplit; ++s)
@@ -473,9 +475,9 @@ void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const
 }
 
 void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip_part, const double *part,
-                           int n_split, double gamma, double *e_static, double *mu) {
+                           int n_split, double gamma, double *e_static, double *mu, double *e_real_out) {
 	hipLaunchKernelGGL(k_field_finalize, dim3(at.n_pad / kTile), dim3(kTile * kSlotGroups), 0, st, at, bx, polar_ewald, e_recip_part, part, n_split,
-	                   gamma, e_static, mu);
+	                   gamma, e_static, mu, e_real_out);
 }
 
 // are_we_done_yet (:3215-3239) on the device.  ctl = { "some atom broke the tolerance in this iteration", iteration at which the solve

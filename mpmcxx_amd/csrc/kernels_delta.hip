@@ -1,4 +1,4 @@
-// kernels_delta.hip -- trial-move ("delta") energies for non-polarizable boxes.
+// kernels_delta.hip -- trial-move ("delta") energies: pair energies, structure factors and (polarizable boxes) the real-space static field.
 //
 // The reference avoids recomputing unchanged pairs through its per-pair cache (`recalculate_energy`, set by
 // minimum_image when a pair's raw displacement changed, System.cpp:1211-1224; lj() :925 and coulombic_real() :1484 then
@@ -201,17 +201,139 @@ __global__ __launch_bounds__(256) void k_delta_finish(const double *__restrict__
 	}
 }
 
-// accept: write the trial positions into the resident arrays
-__global__ void k_commit_positions(double4 *__restrict__ xyzq, const int *__restrict__ mv_slot, const double4 *__restrict__ mv_new, int m) {
-	const int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k < m) xyzq[mv_slot[k]] = mv_new[k];
-}
 // set / clear the moved-atom index map
 __global__ void k_mark_moved(int *__restrict__ moved_idx, const int *__restrict__ mv_slot, int m, int set) {
 	const int k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k < m) moved_idx[mv_slot[k]] = set ? k : -1;
 }
 
+// ---- polarizable boxes: change of the REAL-SPACE static field ---------------------------------------------------------------------
+// thole_field's real part (real_term :2900-2940 with polar_ewald, thole_field_nopbc :3300-3333 without) is a pair sum: a trial move of
+// m atoms changes, for every atom j, only the terms with a moved partner.  Thread = atom j, loop over the moved atoms k, each pair in
+// its new and in its old geometry with the arithmetic of k_pair_fused:
+//   E_j += q_k [F(r_j - r_k')  - F(r_j - r_k)],      E_k += q_j [F(r_k' - r_j) - F(r_k - r_j)]   (F odd: the pair is evaluated once)
+// FIELD 1: F(d) = fac(|d|) d with fac = (2 a/sqrt(pi) e^{-a^2 r^2} r +- erfc/erf(a r)) / r^3 inside the cutoff (es_excluded pairs take
+// the erf form); FIELD 2: fac = 1/r^3 for inter-molecular pairs inside the cutoff.  The moved atoms' own changes are reduced per wave and
+// land in dk_part[tile][k][3]; k_delta_field_finish adds them up over the tiles.
+template <bool ORTHO, int FIELD>
+__device__ __forceinline__ void field_pair(const Box &bx, double ap, const double4 &pi, const double4 &pj, const PairFlags &f, double sg,
+                                           double (&ei)[3], double (&ej)[3]) {
+	double ox, oy, oz;
+	const double ri2 = min_image_sq<ORTHO>(bx, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, ox, oy, oz);
+	if (ri2 == 0.0) return;
+	double fac;
+	if (FIELD == 1) {
+		if (!(ri2 <= bx.t_es) || (pi.w == 0.0 && pj.w == 0.0)) return; // real_term :2916-2917
+		const double ir = fast_rsqrt_1(ri2), r = ri2 * ir;
+		double ga;
+		const double ec = erfc_and_gauss(ap * r, ga);
+		const double g = (2.0 * kOneOverSqrtPi * ap) * (ga * r);
+		fac = (f.es_excluded ? (g - (1.0 - ec)) : (g + ec)) * (ir * ir * ir);
+	} else {
+		if (f.intra || !(ri2 <= bx.t_lj)) return; // thole_field_nopbc :3311-3326
+		const double ir = fast_rsqrt_1(ri2);
+		fac = ir * ir * ir;
+	}
+	const double fj = sg * fac * pj.w, fi = sg * fac * pi.w;
+	ei[0] = fma(fj, ox, ei[0]);
+	ei[1] = fma(fj, oy, ei[1]);
+	ei[2] = fma(fj, oz, ei[2]);
+	ej[0] = fma(-fi, ox, ej[0]);
+	ej[1] = fma(-fi, oy, ej[1]);
+	ej[2] = fma(-fi, oz, ej[2]);
+}
+
+template <bool ORTHO, int FIELD>
+__global__ __launch_bounds__(64) void k_delta_field(AtomsDev at, Box bx, double ap, const int *__restrict__ mv_slot, const double4 *__restrict__ mv_new,
+                                                    int m, const int *__restrict__ moved_idx, const double *__restrict__ e_real,
+                                                    double *__restrict__ e_real_trial, double *__restrict__ dk_part /*[n_tiles][m][3]*/) {
+	const int j = blockIdx.x * kTile + threadIdx.x;
+	const double4 pj_old = at.xyzq[j];
+	const int2 mj = at.mf[j];
+	int kj = -1;
+	if (moved_idx) kj = moved_idx[j];
+	else
+		for (int k = 0; k < m; ++k)
+			if (mv_slot[k] == j) kj = k;
+	const double4 pj_new = (kj >= 0) ? mv_new[kj] : pj_old;
+	const bool j_real = !(mj.y & AF_PAD);
+	double ej[3] = {0, 0, 0};
+	for (int k = 0; k < m; ++k) {
+		double ek[3] = {0, 0, 0};
+		if (j_real && !(kj >= 0 && kj <= k)) { // moved-moved pairs once (from the higher list index), never an atom with itself
+			const int si = mv_slot[k];
+			const int2 mi = at.mf[si];
+			const PairFlags f = pair_flags(mi.x, mi.y, mj.x, mj.y);
+			if (!f.frozen) {
+				field_pair<ORTHO, FIELD>(bx, ap, mv_new[k], pj_new, f, 1.0, ek, ej);
+				field_pair<ORTHO, FIELD>(bx, ap, at.xyzq[si], pj_old, f, -1.0, ek, ej);
+			}
+		}
+		for (int d = 0; d < 3; ++d) ek[d] = wave_sum(ek[d]);
+		if (threadIdx.x == 0) {
+			double *o = dk_part + ((size_t)blockIdx.x * m + k) * 3;
+			o[0] = ek[0];
+			o[1] = ek[1];
+			o[2] = ek[2];
+		}
+	}
+	for (int d = 0; d < 3; ++d) e_real_trial[3 * (size_t)j + d] = e_real[3 * (size_t)j + d] + ej[d];
+}
+// the moved atoms' own share: e_real_trial[slot_k] += sum over tiles of dk_part[tile][k]  (one thread per moved atom, tiles in order)
+__global__ __launch_bounds__(64) void k_delta_field_finish(const int *__restrict__ mv_slot, int m, int n_tiles, const double *__restrict__ dk_part,
+                                                           double *__restrict__ e_real_trial) {
+	const int k = blockIdx.x * 64 + threadIdx.x;
+	if (k >= m) return;
+	double s[3] = {0, 0, 0};
+	for (int t = 0; t < n_tiles; ++t) {
+		const double *q = dk_part + ((size_t)t * m + k) * 3;
+		s[0] += q[0];
+		s[1] += q[1];
+		s[2] += q[2];
+	}
+	double *o = e_real_trial + 3 * (size_t)mv_slot[k];
+	o[0] += s[0];
+	o[1] += s[1];
+	o[2] += s[2];
+}
+
+void launch_delta_field(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_ewald_alpha, int polar_ewald, const int *mv_slot,
+                        const double4 *mv_new, int m, int *moved_idx, const double *e_real, double *e_real_trial, double *dk_part) {
+	const int nt = at.n_pad / kTile;
+	const bool use_map = (m > 8);
+	if (use_map) hipLaunchKernelGGL(k_mark_moved, dim3((m + 63) / 64), dim3(64), 0, st, moved_idx, mv_slot, m, 1);
+	else moved_idx = nullptr;
+#define MPMC_DF(O, F) hipLaunchKernelGGL((k_delta_field<O, F>), dim3(nt), dim3(kTile), 0, st, at, bx, polar_ewald_alpha, mv_slot, mv_new, m, moved_idx, e_real, e_real_trial, dk_part)
+	if (bx.ortho) {
+		if (polar_ewald) MPMC_DF(true, 1);
+		else MPMC_DF(true, 2);
+	} else {
+		if (polar_ewald) MPMC_DF(false, 1);
+		else MPMC_DF(false, 2);
+	}
+#undef MPMC_DF
+	hipLaunchKernelGGL(k_delta_field_finish, dim3((m + 63) / 64), dim3(64), 0, st, mv_slot, m, nt, dk_part, e_real_trial);
+	if (use_map) hipLaunchKernelGGL(k_mark_moved, dim3((m + 63) / 64), dim3(64), 0, st, moved_idx, mv_slot, m, 0);
+}
+
+// swap: the resident positions of the moved atoms become the trial ones, the old ones are kept in mv_new's place (a second call undoes it)
+__global__ void k_swap_positions(double4 *__restrict__ xyzq, const int *__restrict__ mv_slot, double4 *__restrict__ mv_new, int m) {
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < m) {
+		const double4 old = xyzq[mv_slot[k]];
+		xyzq[mv_slot[k]] = mv_new[k];
+		mv_new[k] = old;
+	}
+}
+void launch_swap_positions(hipStream_t st, double4 *xyzq, const int *mv_slot, double4 *mv_new, int m) {
+	hipLaunchKernelGGL(k_swap_positions, dim3((m + 63) / 64), dim3(64), 0, st, xyzq, mv_slot, mv_new, m);
+}
+
+// accept: write the trial positions into the resident arrays
+__global__ void k_commit_positions(double4 *__restrict__ xyzq, const int *__restrict__ mv_slot, const double4 *__restrict__ mv_new, int m) {
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < m) xyzq[mv_slot[k]] = mv_new[k];
+}
 void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc, double alpha, int do_es,
                   const int *mv_slot, const int *orig_of_mv, const double4 *mv_new, int m, int *moved_idx, double4 *sf_trial,
                   double *block_part, int *block_cnt, double *out4, long long *dcnt2) {

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(TAIL ? 256 : 64) void k_pair_fused(AtomsDev at, Box
 				tb = 3.0 * damp2 * ir5;
 			}
 
-			if (!f.frozen && !beyond) {
+			if (!f.frozen && !beyond && !fp.store_only) {
 				double sig, eps;
 				if (plain) {
 					sig = 0.5 * (li.x + s_sig[jl]);
@@ -405,7 +405,9 @@ template <bool ORTHO>
 static void launch_fused_o(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, const int *cls,
                            int ntp, double *bpart, int *bcnt, double *fpart, double2 *ab) {
 	const bool thole = fp.do_thole && ab;
-	if (!fp.do_es)
+	if (!fp.do_es && thole) // (store-only sweeps of polarizable trial moves)
+		launch_fused_t<ORTHO, false, 0, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
+	else if (!fp.do_es)
 		launch_fused_t<ORTHO, false, 0, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
 	else if (fp.do_field == 0)
 		launch_fused_t<ORTHO, true, 0, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);

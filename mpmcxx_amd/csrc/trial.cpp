@@ -65,7 +65,10 @@ extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
 	const mpmc_options &o = c->opts;
 	const bool polar = o.polarization && !o.rd_only;
 	const int m = c->trial_count;
-	if (polar || m > MPMC_TRIAL_MAX_ATOMS || o.wolf || o.feynman_hibbs) { // (the delta kernels carry the base LJ + Ewald terms only)
+	c->trial_polar_delta = false;
+	static const bool no_polar_delta = [] { const char *e = std::getenv("MPMC_NO_POLAR_DELTA"); return e && e[0] == '1'; }();
+	const bool polar_delta = polar && c->e_real_valid && !no_polar_delta && m <= MPMC_TRIAL_MAX_ATOMS && !o.wolf && !o.feynman_hibbs;
+	if ((polar && !polar_delta) || m > MPMC_TRIAL_MAX_ATOMS || o.wolf || o.feynman_hibbs) { // (the delta kernels carry the base LJ + Ewald terms only)
 		// the dipole solve couples every atom: evaluate the trial configuration in full (still on the device)
 		c->trial_keep = c->last_full;
 		int rc = mpmc_update_positions(c, c->trial_first, m, c->trial_new.data());
@@ -100,6 +103,38 @@ extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipMemcpyAsync(c->h_delta_out, c->d_delta_out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
 	c->trial_was_full = false;
+	if (polar_delta) {
+		// Polarizable box: the pair energies and structure factors above are O(m N); the static field follows the same way -- real part:
+		// delta of the pairs with a moved atom; reciprocal part: recomputed from the trial structure factors (O(K N), 30 us at 10 000
+		// atoms) -- then the tensor store is rebuilt for the trial geometry (store-only sweep of the near tile pairs) and the dipoles are
+		// solved from alpha E0 exactly as in a full evaluation (thole_iterative restarts every call, :3547-3560).  What is saved: the
+		// energy / erfc / field arithmetic of the N^2/2 pair sweep and the O(K N) structure factors.
+		const size_t need = (size_t)c->n_tiles * (size_t)m * 3;
+		if (need > c->cap_dk_part) {
+			dev_free(c, &c->d_dk_part, c->cap_dk_part);
+			c->cap_dk_part = 0;
+			if ((rc = dev_alloc(c, &c->d_dk_part, (size_t)c->n_tiles * MPMC_TRIAL_MAX_ATOMS * 3)) != MPMC_OK) return rc;
+			c->cap_dk_part = (size_t)c->n_tiles * MPMC_TRIAL_MAX_ATOMS * 3;
+		}
+		const AtomsDev at = atoms_view(c);
+		{
+			ProfScope p(c, MPMC_K_FIELD);
+			launch_delta_field(st, at, c->box, c->polar_ewald_alpha, o.polar_ewald, c->d_mv_slot, c->d_mv_new, m, c->d_moved_idx, c->d_e_real,
+			                   c->d_e_real_trial, c->d_dk_part);
+			// from here on the resident positions are the TRIAL ones (the old ones wait in d_mv_new: reject swaps them back)
+			launch_swap_positions(st, c->d_xyzq, c->d_mv_slot, c->d_mv_new, m);
+			if (o.polar_ewald) {
+				RecipDev rt = recip_view(c);
+				rt.sf = c->d_sf_trial;
+				launch_field_recip(st, at, c->box, rt, o.ewald_kmax, c->d_e_recip_part);
+			}
+			c->mu_cur = 0;
+			launch_field_finalize(st, at, c->box, o.polar_ewald, c->d_e_recip_part, c->d_e_real_trial, 1, o.polar_gamma, c->d_e_static, c->d_mu[0]);
+		}
+		HIP_TRY(c, hipGetLastError());
+		c->trial_polar_delta = true;
+		if ((rc = enqueue(c, RUN_STORE | RUN_SOLVE)) != MPMC_OK) return rc; // classes + store of the trial geometry, the iterations, -1/2 mu.E0
+	}
 	c->trial_enqueued = true;
 	return MPMC_OK;
 }
@@ -123,8 +158,16 @@ extern "C" int mpmc_trial_energy_wait(mpmc_ctx *c, mpmc_result *out) {
 		return MPMC_OK;
 	}
 	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	prof_harvest(c);
+	mpmc_result solved{};
+	if (c->trial_polar_delta) { // the solve half went through enqueue(): its scalars (polarization energy, rrms, iterations) arrive the usual way
+		const mpmc_result keep = c->last_full;
+		int rc = wait_and_fill(c, &solved);
+		c->last_full = keep;
+		if (rc != MPMC_OK) return rc;
+	} else {
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		prof_harvest(c);
+	}
 	const int do_es = c->opts.rd_only ? 0 : 1;
 	const mpmc_result &a = c->last_full;
 	mpmc_result r = a;
@@ -136,6 +179,12 @@ extern "C" int mpmc_trial_energy_wait(mpmc_ctx *c, mpmc_result *out) {
 		r.es_recip = c->h_delta_out[3];
 		r.coulombic_energy = (r.es_real + r.es_recip) + r.es_self;
 		r.n_es_in_cutoff = a.n_es_in_cutoff + c->h_delta_cnt[1];
+	}
+	if (c->trial_polar_delta) {
+		r.polarization_energy = solved.polarization_energy;
+		r.dipole_rrms = solved.dipole_rrms;
+		r.polar_iterations = solved.polar_iterations;
+		r.iterator_failed = solved.iterator_failed;
 	}
 	r.energy = r.rd_energy + r.coulombic_energy + r.polarization_energy + r.vdw_energy + r.three_body_energy;
 	r.NU = r.N * r.energy;
@@ -162,7 +211,11 @@ extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
 		return MPMC_OK;
 	}
 	if (!c->trial_was_full) {
-		launch_commit_positions(c->stream, c->d_xyzq, c->d_mv_slot, c->d_mv_new, m);
+		if (c->trial_polar_delta) { // the trial positions are already resident; the trial real-space field becomes the accepted one
+			std::swap(c->d_e_real, c->d_e_real_trial);
+		} else {
+			launch_commit_positions(c->stream, c->d_xyzq, c->d_mv_slot, c->d_mv_new, m);
+		}
 		HIP_TRY(c, hipGetLastError());
 		std::swap(c->d_sf, c->d_sf_trial); // the trial structure factors become the accepted ones
 		std::swap(c->cap_sf, c->cap_sf_trial); // (d_sf has its own capacity: cap_K sizes the k tables, which do not move)
@@ -176,6 +229,7 @@ extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
 	c->last_full = c->trial_res;
 	c->cache_valid = true;
 	c->trial_open = false;
+	c->trial_polar_delta = false;
 	return MPMC_OK;
 }
 
@@ -188,12 +242,21 @@ extern "C" int mpmc_trial_reject(mpmc_ctx *c) {
 		if (rc != MPMC_OK) return rc;
 	}
 	c->trial_open = false;
+	if (c->trial_polar_delta) { // (enqueued or evaluated) the device holds the trial positions: swap the accepted ones back
+		HIP_TRY(c, hipSetDevice(c->device));
+		launch_swap_positions(c->stream, c->d_xyzq, c->d_mv_slot, c->d_mv_new, c->trial_count);
+		HIP_TRY(c, hipGetLastError());
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		c->trial_polar_delta = false;
+		return MPMC_OK; // (the store, classes and dipoles describe the rejected geometry; the next trial or energy() rebuilds them)
+	}
 	if (c->trial_evaluated && c->trial_was_full) { // the resident configuration is the trial one: put the old positions back
 		const mpmc_result keep = c->last_full;
 		int rc = mpmc_update_positions(c, c->trial_first, c->trial_count, c->trial_old.data());
 		if (rc != MPMC_OK) return rc;
 		c->last_full = keep;
 		c->cache_valid = true;
+		c->e_real_valid = false; // (the real-space field on the device is the rejected configuration's: the next polarizable trial evaluates in full)
 		const bool polar = c->opts.polarization && !c->opts.rd_only;
 		if (!polar && !c->opts.wolf) { // the resident structure factors are the trial ones: re-base on the restored configuration
 			mpmc_result tmp;

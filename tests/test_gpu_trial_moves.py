@@ -25,7 +25,9 @@ def nonpolar(opts):
 
 
 @pytest.mark.parametrize("name,polar", [("lj64", False), ("ion64_es", False), ("water64_polar", False), ("ion216_triclinic", False),
-                                        ("ion216_frozen", False), ("water64_polar", True), ("ion216_wolf", False), ("water64_fh2", False)])
+                                        ("ion216_frozen", False), ("water64_polar", True), ("ion216_wolf", False), ("water64_fh2", False),
+                                        ("ion216_polar", True), ("ion216_polar_nopbc", True), ("ion216_triclinic", True), ("ion216_framework", True),
+                                        ("ion1000_polar", True), ("ion216_precision", True)])
 def test_trial_moves_track_full_evaluations(name, polar):
     from oracle import OracleSystem
 
@@ -56,6 +58,13 @@ def test_trial_moves_track_full_evaluations(name, polar):
         assert S.trial_observables["n_es_in_cutoff"] == T.observables["n_es_in_cutoff"]
         assert util.close(e_trial, e_full, 1e-11)
         T.close()
+        # ... and the ORACLE on the same trial configuration, every step (1e-9, counts bit-exact)
+        ref_t = OracleSystem(at2, basis, opts).energy(want_atoms=False)
+        for k in ("energy", "rd_energy", "coulombic_energy", "polarization_energy"):
+            assert abs(S.trial_observables[k] - ref_t[k]) <= 1e-9 * max(abs(ref_t[k]), 1e-3 * abs(ref_t["energy"])), (name, step, k)
+        assert S.trial_observables["n_lj_in_cutoff"] == ref_t["n_lj_in_cutoff"]
+        if polar:
+            assert S.trial_observables["polar_iterations"] == ref_t["polar_iterations"]
         if rng.random() < 0.5:
             S.accept()
             pos = full_pos
