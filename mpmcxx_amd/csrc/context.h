@@ -163,6 +163,10 @@ struct mpmc_ctx {
 	size_t cap_dk_part = 0;
 	bool e_real_valid = false;     // d_e_real describes the accepted configuration
 	bool trial_polar_delta = false; // the open trial took the incremental polarizable path (positions swapped on the device)
+	// the tensor store between trial moves: a trial rebuilds only the tile pairs of the tiles its moved atoms live in; after a REJECTED
+	// trial those tiles hold the rejected geometry's tensors and are rebuilt by the next trial (or by any full evaluation)
+	std::vector<int> store_dirty_tiles, trial_tiles;
+	int touch_n = -1, touch[8] = {0}; // what enqueue(RUN_STORE) passes to the store-only sweep (-1: all tile pairs)
 	unsigned char *d_mv_blob = nullptr, *h_mv_blob = nullptr; // device / pinned host staging of a trial's moved-atom list
 	int cap_sf_trial = 0;
 	double *d_delta_out = nullptr, *h_delta_out = nullptr;

@@ -289,6 +289,9 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
 		fp.thole_far_x = c->thole_far_x;
 		fp.store_only = ((mask & RUN_STORE) && !(mask & (RUN_PAIR | RUN_FIELD))) ? 1 : 0;
+		fp.touch_n = fp.store_only ? c->touch_n : -1;
+		for (int k = 0; k < 8; k++) fp.touch[k] = c->touch[k];
+		if (!fp.store_only && compact) c->store_dirty_tiles.clear(); // a full sweep rebuilds every stored tile pair
 		if (compact && !c->jacobi_hybrid) // work lists of the two-kernel Jacobi form only
 			launch_build_lists(st, c->d_cls, c->n_tile_pairs, c->d_lists, c->d_lists + 2 * (size_t)c->n_tile_pairs);
 		// panels of the Jacobi contraction: two tile pairs of equal class behind one j-tile per wave (orthorhombic cells, stored tensors)

@@ -102,6 +102,8 @@ struct FusedParams {
 	double wolf_erfa_over_r, wolf_inv_r2; // erf(alpha R)/R, 1/R^2
 	double thole_far_x; // lambda r beyond which the exponential damping is dropped (the value the tile classes were made with)
 	int store_only;     // nothing but the Thole tensor store (trial moves of polarizable boxes: energies and field come from the delta kernels)
+	int touch_n;        // store-only passes: >= 0 restricts the pass to the tile pairs that contain one of touch[0 .. touch_n) (the tiles of
+	int touch[8];       // the moved atoms: every other tile pair keeps the tensors it has); < 0: all tile pairs
 };
 // every unordered pair once: energies + counts (block partials), static-field partials fpart[nt][n_pad][3],
 // Thole store ab[n_tile_pairs][64*64] (double2 = 16 B per pair)

@@ -68,6 +68,11 @@ __global__ __launch_bounds__(TAIL ? 256 : 64) void k_pair_fused(AtomsDev at, Box
 	constexpr int W = TAIL ? 4 : 1;
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int2 IJ = tile_pairs[blockIdx.x];
+	if (THOLE && fp.store_only && fp.touch_n >= 0) { // (block-uniform) a trial move: only the tile pairs of the moved atoms' tiles are rebuilt
+		bool hit = false;
+		for (int k = 0; k < fp.touch_n; ++k) hit = hit || (IJ.x == fp.touch[k]) || (IJ.y == fp.touch[k]);
+		if (!hit) return;
+	}
 	const bool diag = (IJ.x == IJ.y);
 	const int i = IJ.x * kTile + lane;
 	const int j0 = IJ.y * kTile;

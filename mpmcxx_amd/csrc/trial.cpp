@@ -133,7 +133,22 @@ extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
 		}
 		HIP_TRY(c, hipGetLastError());
 		c->trial_polar_delta = true;
-		if ((rc = enqueue(c, RUN_STORE | RUN_SOLVE)) != MPMC_OK) return rc; // classes + store of the trial geometry, the iterations, -1/2 mu.E0
+		// the store-only sweep rebuilds the tile pairs of the tiles the moved atoms live in, and of the tiles a rejected trial left behind:
+		// no other tile pair's geometry (or class) changed
+		c->trial_tiles.clear();
+		for (int t = 0; t < m; t++) {
+			const int tile = c->slot_of[c->trial_first + t] / kTile;
+			if (std::find(c->trial_tiles.begin(), c->trial_tiles.end(), tile) == c->trial_tiles.end()) c->trial_tiles.push_back(tile);
+		}
+		std::vector<int> touch = c->trial_tiles;
+		for (int tile : c->store_dirty_tiles)
+			if (std::find(touch.begin(), touch.end(), tile) == touch.end()) touch.push_back(tile);
+		c->touch_n = (touch.size() <= 8) ? (int)touch.size() : -1;
+		for (int k = 0; k < c->touch_n; k++) c->touch[k] = touch[k];
+		rc = enqueue(c, RUN_STORE | RUN_SOLVE); // classes + store of the trial geometry, the iterations, -1/2 mu.E0
+		c->touch_n = -1;
+		if (rc != MPMC_OK) return rc;
+		c->store_dirty_tiles = c->trial_tiles; // until accepted: these tiles hold the TRIAL geometry's tensors
 	}
 	c->trial_enqueued = true;
 	return MPMC_OK;
@@ -213,6 +228,7 @@ extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
 	if (!c->trial_was_full) {
 		if (c->trial_polar_delta) { // the trial positions are already resident; the trial real-space field becomes the accepted one
 			std::swap(c->d_e_real, c->d_e_real_trial);
+			c->store_dirty_tiles.clear(); // ... and so is the store
 		} else {
 			launch_commit_positions(c->stream, c->d_xyzq, c->d_mv_slot, c->d_mv_new, m);
 		}
