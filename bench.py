@@ -400,7 +400,7 @@ def main():
         src = alone if alone else in_region
         share = {"dipole_iter": (src.get("dipole_iter") or 0.0) * iters, "pair": src.get("pair") or 0.0}
         dom = max(share, key=share.get) if any(share.values()) else "dipole_iter"
-        jac_kernel = "k_dense_matvec" if solver_used == "dense" else "k_dipole_iter_hybrid"
+        jac_kernel = "k_dense_matvec" if solver_used == "dense" else ("k_dipole_iter_panel" if not os.environ.get("MPMC_NO_PANELS") else "k_dipole_iter_hybrid")
         if solver_used == "dense":  # the reference's 3N x 3N layout, contraction on v_mfma_f64_16x16x4_f64: HBM-bound
             n3 = 3 * ((n + 63) // 64 * 64)
             ms = src.get("dipole_iter") or 1e30
@@ -415,7 +415,7 @@ def main():
         else:
             ms = src.get("dipole_iter") or 1e30
             roof = compute_entry(jac_kernel, ms, flops_jacobi, iters * n_local)
-            tr = pmc_traffic.get("k_dipole_iter_hybrid")
+            tr = pmc_traffic.get(jac_kernel)
             if tr and tr.get("natoms") == n:
                 roof["traffic"] = tr["hbm_bytes_per_launch"]
                 roof["traffic_source"] = tr["source"]
@@ -454,7 +454,8 @@ def main():
         roof["alone_kernel_ms"] = alone
         roof["pmc_sources"] = "profiles/r02_pmc_summary.md (SQ_* counters, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes; tools/profile.sh)"
         roof["note"] = ("fp64 VALU bound: MI355X fp64 vector and matrix peaks are both 78.6 TFLOP/s, the kernel issues v_fma_f64.  One launch per Jacobi "
-                        "iteration over ALL tile pairs: 48 flop per streamed pair (16 B of stored tensor), 64 flop per recomputed far-field pair (FMA = 2).")
+                        "iteration over ALL tile pairs (panels of two tile pairs per workgroup of four waves): 48 flop per streamed pair (16 B of stored "
+                        "tensor), 64 flop per recomputed far-field pair (FMA = 2).  Tensors are stored for the tile pairs within lambda r = 30 only.")
 
         out = {
             "metric": "energy-evals/sec (10k-atom LJ+Ewald+polar box); 1/2/4/8-GPU scaling",

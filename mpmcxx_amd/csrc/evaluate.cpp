@@ -264,11 +264,13 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 
 	// ---- pairwise pass: one symmetric sweep (energies + counts, static-field partials, Thole tensor store) ----------
 	if (mask & (RUN_PAIR | RUN_FIELD | RUN_STORE)) {
-		ProfScope p(c, MPMC_K_PAIR);
 		// tile-pair classes from this configuration's tile bounding boxes (orthorhombic cells; all "near" otherwise)
-		if (c->no_classes) HIP_TRY(c, hipMemsetAsync(c->d_cls, 0, (size_t)c->n_tile_pairs * sizeof(int), st));
-		else launch_tile_classes(st, at, c->box, c->d_tile_pairs, c->n_tile_pairs, (o.polarization && !o.rd_only) ? o.polar_damp : 0.0,
-		                         c->d_tile_bounds, c->d_cls, c->no_uniform ? nullptr : c->d_tp_shift, c->sort_origin_f, c->thole_far_x);
+		{
+			ProfScope pc(c, MPMC_K_CLASSES);
+			if (c->no_classes) HIP_TRY(c, hipMemsetAsync(c->d_cls, 0, (size_t)c->n_tile_pairs * sizeof(int), st));
+			else launch_tile_classes(st, at, c->box, c->d_tile_pairs, c->n_tile_pairs, (o.polarization && !o.rd_only) ? o.polar_damp : 0.0,
+			                         c->d_tile_bounds, c->d_cls, c->no_uniform ? nullptr : c->d_tp_shift, c->sort_origin_f, c->thole_far_x);
+		}
 		FusedParams fp;
 		fp.ewald_alpha = c->ewald_alpha;
 		fp.polar_ewald_alpha = c->polar_ewald_alpha;
@@ -323,9 +325,13 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			// the table is needed by the first Jacobi launch only: it is made beside the pair sweep (side stream, joined after the sweep)
 			hipStream_t sp = c->two_streams ? fork_side(c) : st;
 			panel_side = c->two_streams;
-			launch_build_panels(sp, c->d_cls, c->n_tiles, c->d_seg, c->d_panels);
+			{
+				ProfScope pc(c, MPMC_K_CLASSES, sp);
+				launch_build_panels(sp, c->d_cls, c->n_tiles, c->d_seg, c->d_panels);
+			}
 			c->panels_built = true;
 		}
+		ProfScope p(c, MPMC_K_PAIR);
 		if (!(fp.store_only && !compact)) // (a store-only pass without a store to fill has nothing to do beyond the classes)
 			launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
 			                  compact ? c->d_ab : nullptr);

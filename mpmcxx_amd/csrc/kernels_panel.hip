@@ -37,52 +37,76 @@ constexpr int kPanelWaves = 4; // waves per workgroup: they split the steps of O
 
 __device__ __forceinline__ int tp_index(int I, int J, int nt) { return I * nt - (I * (I - 1)) / 2 + (J - I); }
 
-// one thread per j-tile; pending members per class live in LDS (16 classes: far << 3 | uniform mask).  The classes are read in
-// batches of 8 independent loads (a dependent load per tile pair made this kernel latency-bound: 96 us at 157 tiles).
+// One WAVE per j-tile J.  Its off-diagonal tile pairs (I < J, J) are taken 64 at a time: lane = one tile pair, key = its class
+// (far << 3 | uniform mask).  Within a class the members pair up by rank (ballot + popcount): ranks (0,1), (2,3), ...; an odd one out
+// is carried to the next chunk of 64 as that class's pending member.  At the end the pending members of equal kind (stored / far)
+// pair up across classes -- the panel then keeps only the dimensions uniform for BOTH -- and what is still single becomes a
+// one-member entry.  Every step is wave-uniform or a fixed function of the lane: the table is the same whatever the timing.
 __global__ __launch_bounds__(64) void k_build_panels(const int *__restrict__ cls, int nt, const int *__restrict__ seg, int4 *__restrict__ panels) {
-	__shared__ int s_pend[16][64];
-	const int J = blockIdx.x * 64 + threadIdx.x;
+	__shared__ int s_odd[16][33]; // the odd-rank member of every pair of one chunk, by class and pair index
+	const int J = blockIdx.x, lane = threadIdx.x;
 	if (J >= nt) return;
-	const int t = threadIdx.x;
-	for (int k = 0; k < 16; ++k) s_pend[k][t] = -1;
 	int4 *out = panels + seg[J];
 	const int cap = seg[J + 1] - seg[J];
-	int n = 0;
-	out[n++] = make_int4(tp_index(J, J, nt), -1, ((cls[tp_index(J, J, nt)] / CLS_UNIFORM_X) & 7) | kPanDiag, J);
-	for (int I0 = 0; I0 < J; I0 += 8) {
-		int c[8];
+	int n = 0; // entries written so far (wave-uniform)
+	if (lane == 0) out[0] = make_int4(tp_index(J, J, nt), -1, ((cls[tp_index(J, J, nt)] / CLS_UNIFORM_X) & 7) | kPanDiag, J);
+	n = 1;
+	int pend[16]; // pending member of every class (wave-uniform values, kept in every lane)
 #pragma unroll
-		for (int u = 0; u < 8; ++u) c[u] = (I0 + u < J) ? cls[tp_index(I0 + u, J, nt)] : -1;
+	for (int k = 0; k < 16; ++k) pend[k] = -1;
+	const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane)); // lanes below this one
+	for (int I0 = 0; I0 < J; I0 += 64) {
+		const int I = I0 + lane;
+		const bool live = I < J;
+		const int tp = live ? tp_index(I, J, nt) : -1;
+		const int c = live ? cls[tp] : 0;
+		const int key = ((c & CLS_THOLE_FAR) ? 8 : 0) | ((c / CLS_UNIFORM_X) & 7);
 #pragma unroll
-		for (int u = 0; u < 8; ++u) {
-			if (I0 + u >= J) break;
-			const int tp = tp_index(I0 + u, J, nt);
-			const int key = ((c[u] & CLS_THOLE_FAR) ? 8 : 0) | ((c[u] / CLS_UNIFORM_X) & 7);
-			const int p = s_pend[key][t];
-			if (p >= 0) {
-				out[n++] = make_int4(p, tp, key, J);
-				s_pend[key][t] = -1;
-			} else {
-				s_pend[key][t] = tp;
+		for (int k = 0; k < 16; ++k) {
+			const unsigned long long mask = __ballot(live && key == k);
+			if (mask == 0ull) continue; // wave-uniform
+			const int cnt = __popcll(mask);
+			const bool mine = live && key == k;
+			// with a pending member from an earlier chunk the ranks shift by one: pending = rank 0
+			const int shift = (pend[k] >= 0) ? 1 : 0;
+			const int rank = __popcll(mask & lt) + shift;
+			const int total = cnt + shift;
+			if (mine && (rank & 1)) s_odd[k][rank >> 1] = tp;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			if (mine && !(rank & 1) && rank + 1 < total) out[n + (rank >> 1)] = make_int4(tp, s_odd[k][rank >> 1], k, J);
+			if (shift && lane == 0) out[n] = make_int4(pend[k], s_odd[k][0], k, J); // the pending member is rank 0: its partner is rank 1
+			// the new pending member: the last one when the total is odd
+			int np = -1;
+			if (total & 1) {
+				// (total odd) the member of rank total - 1: the pending one itself when nobody joined (cannot happen: cnt >= 1), else the top lane of the class
+				const int top = 63 - __clzll(mask);
+				np = __shfl(tp, top, 64);
 			}
+			n += total >> 1;
+			pend[k] = np;
+			__builtin_amdgcn_wave_barrier();
 		}
 	}
-	for (int far = 0; far < 2; ++far) { // leftovers of one kind: pair them in class order, the panel keeps the dimensions uniform for BOTH members
-		int prev = -1, prev_um = 0;
-		for (int um = 7; um >= 0; --um) {
-			const int p = s_pend[far * 8 + um][t];
-			if (p < 0) continue;
-			if (prev >= 0) {
-				out[n++] = make_int4(prev, p, (prev_um & um) | (far ? kPanFar : 0), J);
-				prev = -1;
-			} else {
-				prev = p;
-				prev_um = um;
+	if (lane == 0) {
+		for (int far = 0; far < 2; ++far) { // leftovers of one kind pair up in class order
+			int prev = -1, prev_um = 0;
+#pragma unroll
+			for (int um = 7; um >= 0; --um) {
+				const int p = pend[far * 8 + um];
+				if (p < 0) continue;
+				if (prev >= 0) {
+					out[n++] = make_int4(prev, p, (prev_um & um) | (far ? kPanFar : 0), J);
+					prev = -1;
+				} else {
+					prev = p;
+					prev_um = um;
+				}
 			}
+			if (prev >= 0) out[n++] = make_int4(prev, -1, prev_um | (far ? kPanFar : 0), J); // odd one out: a single
 		}
-		if (prev >= 0) out[n++] = make_int4(prev, -1, prev_um | (far ? kPanFar : 0), J); // odd one out: a single
+		for (; n < cap; ++n) out[n] = make_int4(-1, -1, 0, J);
 	}
-	for (; n < cap; ++n) out[n] = make_int4(-1, -1, 0, J);
 }
 
 template <int NI>
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDe
 }
 
 void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg, int4 *panels) {
-	hipLaunchKernelGGL(k_build_panels, dim3((n_tiles + 63) / 64), dim3(64), 0, st, cls, n_tiles, seg, panels);
+	hipLaunchKernelGGL(k_build_panels, dim3(n_tiles), dim3(64), 0, st, cls, n_tiles, seg, panels);
 }
 
 void launch_dipole_iter_panel(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,

@@ -27,7 +27,7 @@ ERR_INVALID_SETTING = 4000
 ERR_NO_DEVICE = -1
 DAMPING = {"off": 0, "linear": 1, "exponential": 2, None: 2}
 SOLVER = {"auto": 0, "matrix_free": 1, "compact": 2, "dense": 3}
-K_NAMES = ["pair", "recip", "field", "tensor", "dipole_iter", "reduce", "dipole_far"]
+K_NAMES = ["pair", "recip", "field", "tensor", "dipole_iter", "reduce", "dipole_far", "classes"]
 
 
 class MpmcError(RuntimeError):
@@ -69,7 +69,7 @@ class GibbsMove(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_int64 * 7)]
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_int64 * 8)]
 
 
 _lib = None
@@ -350,7 +350,7 @@ class System:
     def timings(self, reset: bool = False) -> Dict[str, Dict[str, float]]:
         t = Timings()
         self._check(self._L.mpmc_get_timings(self._h, C.byref(t), 1 if reset else 0))
-        return {K_NAMES[i]: {"ms": t.ms[i], "launches": int(t.launches[i])} for i in range(7)}
+        return {K_NAMES[i]: {"ms": t.ms[i], "launches": int(t.launches[i])} for i in range(len(K_NAMES))}
 
     def synchronize(self):
         self._check(self._L.mpmc_synchronize(self._h))
