@@ -41,6 +41,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(energy.Options) == 12 * 4 + 5 * 8 + 8 + 2 * 4 + 8
     assert ctypes.sizeof(energy.Result) == 16 * 8 + 7 * 8 + 2 * 4
     assert ctypes.sizeof(energy.Timings) == 8 * 8 + 8 * 8
+    assert ctypes.sizeof(energy.GibbsMove) == 2 * 4 + 10 * 8
 
 
 def test_pbc_compute_matches_reference_values():
