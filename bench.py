@@ -306,7 +306,7 @@ def main():
 
     # ---- PCIe-inclusive rate: the same step with every bead's positions handed over in host memory (short extra pass, all ranks) ----
     pcie = None
-    if not args.no_extra_passes and not args.host_positions:
+    if not args.no_extra_passes and not args.host_positions and world == 1:  # (multi-rank runs report the headline only: no extra collectives)
         state["host_positions"] = True
         step()
         k_pcie = max(2, min(args.steps, 5))
@@ -318,7 +318,7 @@ def main():
 
     # ---- the kernels with NOTHING else on the GPU: untimed passes, one bead at a time on one stream (HIP events again) ----------
     iso = iso_split = None
-    if rank == 0 and not args.no_extra_passes:
+    if rank == 0 and not args.no_extra_passes and world == 1:  # (with several ranks nobody is kept waiting in a barrier: in-region durations only)
         def fresh(env, count):
             old = {k: os.environ.get(k) for k in env}
             os.environ.update(env)
