@@ -59,5 +59,60 @@ def main():
     print(len(cases), "cases")
 
 
+def trajectories():
+    """tests/golden/gibbs_*/: two-box inputs in the reference's own formats + the trajectory oracle/_ref/ref_gibbs_traj made for them
+    (the reference's own pick_Gibbs_move / make_move_Gibbs / energy / boltzmann_factor_NVT_Gibbs / restore, driven step by step)."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from mpmcxx_amd import gen_box
+
+    traj = os.path.join(HERE, "_ref", "ref_gibbs_traj")
+    cases = {
+        # name: (molecules A, molecules B, L, extra options, steps)
+        "gibbs_water": (24, 10, 16.0, {"ewald_kmax": 5}, 200),
+        "gibbs_water_polar": (20, 8, 16.0, dict(gen_box.POLAR_OPTS, ewald_kmax=5), 80),
+        "gibbs_lj": (0, 0, 18.0, {"rd_only": "on"}, 150),
+    }
+    for name, (na, nb, L, extra, steps) in cases.items():
+        d = os.path.join(ROOT, "tests", "golden", name)
+        os.makedirs(d, exist_ok=True)
+        if name == "gibbs_lj":  # single-site atoms: 40 in the dense box, 12 in the dilute one
+            A = gen_box.lattice_box(40, L, 21, charged=False, alpha=0.0)
+            B = gen_box.lattice_box(12, L, 22, charged=False, alpha=0.0)
+        else:
+            A = gen_box.molecular_box(na, L, 5, extra_neutral=False)
+            B = gen_box.molecular_box(nb, L, 9, extra_neutral=False)
+        gen_box.write_pqr(os.path.join(d, "boxA.pqr"), A)
+        gen_box.write_pqr(os.path.join(d, "boxB.pqr"), B)
+        opts = {"job_name": name, "ensemble": "nvt_gibbs", "temperature": 300.0, "numsteps": steps, "corrtime": 10, "seed": 7, "move_factor": 0.05,
+                "rot_factor": 0.05, "transfer_probability": 0.3, "volume_probability": 0.1, "volume_change_factor": 0.25}
+        opts.update(extra)
+        lines = [f"{k} {gen_box._fmt(v)}" for k, v in opts.items()]
+        lines += [f"basis1 {L!r} 0.0 0.0", f"basis2 0.0 {L!r} 0.0", f"basis3 0.0 0.0 {L!r}", "pqr_input boxA.pqr", "pqr_input_B boxB.pqr"]
+        lines += [f"{k} off" for k in ("pop_histogram", "traj_output", "energy_output", "dipole_output", "field_output")]
+        with open(os.path.join(d, "input.in"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+        p = subprocess.run([traj, "input.in", str(steps)], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        txt = p.stdout
+        res = json.loads(txt[txt.rfind("\n{\"initial") + 1:])
+        res["generator"] = "oracle/make_gibbs_golden.py + oracle/_ref/ref_gibbs_traj (the reference's own move / energy / acceptance functions)"
+        with open(os.path.join(d, "trajectory.json"), "w") as f:
+            json.dump(res, f, indent=0, separators=(",", ":"))
+            f.write("\n")
+        for junk in os.listdir(d):
+            if junk not in ("input.in", "boxA.pqr", "boxB.pqr", "trajectory.json"):
+                os.remove(os.path.join(d, junk))
+        import collections
+
+        print(name, len(res["steps"]), "steps", dict(collections.Counter(tuple(s["movetype"]) for s in res["steps"])), "accepted", sum(s["accepted"][0] for s in res["steps"]))
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+
+    if len(sys.argv) > 1 and sys.argv[1] == "trajectories":
+        trajectories()
+    else:
+        main()
+        trajectories()
