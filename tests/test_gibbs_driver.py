@@ -117,3 +117,23 @@ def test_driver_on_the_hip_path_reproduces_the_reference_made_trajectory(gibbs_n
     out = subprocess.run([gibbs_nvt, os.path.join(util.GOLDEN, name, "input.in")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-500:] + out.stderr[-500:]
     compare(parse(out.stdout), ref, 1e-9, 1e-9)
+
+
+def test_driver_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The Gibbs driver inserts and erases molecules in the middle of the atom list: run it, with the oracle as evaluator, under
+    -fsanitize=address,undefined (any report aborts the run)."""
+    from mpmcxx_amd import build as mbuild
+
+    mbuild.build_library()
+    subprocess.check_call(["make", "-s", "-C", ORACLE, "oracle"])
+    exe = str(tmp_path / "gibbs_san")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-Wall", "-Wextra",
+                           "-Werror", "-I", os.path.join(util.ROOT, "include"), os.path.join(util.ROOT, "tests", "cpp", "gibbs_check.cpp"),
+                           "-L", LIBDIR, "-lmpmc_energy", "-L", ORACLE, "-lmpmc_oracle", f"-Wl,-rpath,{LIBDIR}", f"-Wl,-rpath,{ORACLE}",
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1")
+    for name, steps in (("gibbs_water", 120), ("gibbs_water_polar", 40)):
+        out = subprocess.run([exe, os.path.join(util.GOLDEN, name, "input.in"), str(steps)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        ours, ref = parse(out.stdout), golden(name)
+        assert [s["accepted"] for s in ours["steps"]] == [s["accepted"] for s in ref["steps"][:steps]]
