@@ -198,14 +198,21 @@ def main():
     except energy.MpmcError:
         pass
     if world > 1 and args.combine_impl == "cabi" and args.dist_backend == "nccl" and args.combine == "gather":
-        # rank 0 makes the RCCL unique id, the launcher's channel (torch.distributed) carries its 128 bytes, every rank joins
+        # rank 0 makes the RCCL unique id, the launcher's channel (torch.distributed) carries its 128 bytes, every rank joins.
+        # ncclCommInitRank blocks until ALL ranks have called it, so first make sure every rank can open RCCL below Python at all.
         ok = 1
-        try:
-            uid = [energy.Comm.unique_id() if rank == 0 else None]
-        except energy.MpmcError:
-            uid, ok = [None], 0
-        dist.broadcast_object_list(uid, src=0)
-        if uid[0] is not None:
+        ready = torch.tensor([1 if rccl_ver else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+        uid = [None]
+        if int(ready.item()) == 1:
+            try:
+                uid = [energy.Comm.unique_id() if rank == 0 else None]
+            except energy.MpmcError:
+                uid = [None]
+            dist.broadcast_object_list(uid, src=0)
+        if uid[0] is None:
+            ok = 0
+        else:
             try:
                 comm = energy.Comm(world, rank, uid[0], local_rank)
             except energy.MpmcError as e:
