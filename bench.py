@@ -459,7 +459,7 @@ def main():
                                                           {"what": "MPMC_JACOBI=split: the recomputed far-field tile pairs alone"})
         roof["other_kernels"] = other
         roof["alone_kernel_ms"] = alone
-        roof["pmc_sources"] = "profiles/r02_pmc_summary.md (SQ_* counters, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes; tools/profile.sh)"
+        roof["pmc_sources"] = "profiles/r02_final_pmc_serial_summary.md (SQ_* counters, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes; tools/profile.sh)"
         roof["note"] = ("fp64 VALU bound: MI355X fp64 vector and matrix peaks are both 78.6 TFLOP/s, the kernel issues v_fma_f64.  One launch per Jacobi "
                         "iteration over ALL tile pairs (panels of two tile pairs per workgroup of four waves): 48 flop per streamed pair (16 B of stored "
                         "tensor), 64 flop per recomputed far-field pair (FMA = 2).  Tensors are stored for the tile pairs within lambda r = 30 only.")

@@ -198,7 +198,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_inv_molmass, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal,
 	                c->d_flag, c->d_counter, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_panels, c->d_seg, c->d_gpart, c->d_mv_blob, c->d_moved_idx,
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_panels, c->d_seg, c->d_gpart, c->d_trace, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out, c->d_e_real, c->d_e_real_trial, c->d_dk_part};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -643,6 +643,17 @@ extern "C" int mpmc_get_tile_stats(mpmc_ctx *c, int64_t out4[4]) {
 		if (v & CLS_BEYOND_CUTOFF) out4[3]++;
 	}
 	return MPMC_OK;
+}
+
+// measurement only: per-workgroup time stamps of the last panel launch (tools/panel_trace.py); 0 entries unless MPMC_TRACE_PANEL=1
+extern "C" int mpmc_debug_panel_trace(mpmc_ctx *c, long long *out4, int max_entries) {
+	if (!c || !out4) return -1;
+	if (!c->d_trace) return 0;
+	const int n = std::min(max_entries, c->n_panel_entries);
+	if (hipSetDevice(c->device) != hipSuccess) return -1;
+	if (hipMemcpyAsync(out4, c->d_trace, (size_t)n * 4 * sizeof(long long), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+	if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+	return n;
 }
 
 extern "C" int mpmc_memory_usage(mpmc_ctx *c, int64_t *total, int64_t *tensor) {

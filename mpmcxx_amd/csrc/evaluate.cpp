@@ -321,6 +321,12 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				if ((rc = dev_alloc(c, &c->d_panels, need)) != MPMC_OK) return rc;
 				if ((rc = dev_alloc(c, &c->d_gpart, need * kTile * 3)) != MPMC_OK) return rc;
 				c->cap_panels = need;
+				static const bool want_trace = [] { const char *e = std::getenv("MPMC_TRACE_PANEL"); return e && e[0] == '1'; }();
+				if (want_trace) {
+					if (c->d_trace) (void)hipFree(c->d_trace);
+					c->d_trace = nullptr;
+					if ((rc = dev_alloc(c, &c->d_trace, need * 4)) != MPMC_OK) return rc;
+				}
 			}
 			// the table is needed by the first Jacobi launch only: it is made beside the pair sweep (side stream, joined after the sweep)
 			hipStream_t sp = c->two_streams ? fork_side(c) : st;
@@ -426,7 +432,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
 				if (c->panels_built) // every tile pair through the panel table: two per wave where classes allow
 					launch_dipole_iter_panel(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels,
-					                         c->n_panel_entries, c->d_ab, c->d_part, c->d_gpart, converged);
+					                         c->n_panel_entries, c->d_ab, c->d_part, c->d_gpart, converged, c->d_trace);
 				else
 					launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
 					                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part, o.polar_damp,

@@ -347,7 +347,10 @@ __global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev
                                                                         const int2 *__restrict__ tile_pairs, const double4 *__restrict__ tp_shift,
                                                                         const int4 *__restrict__ panels, const double2 *__restrict__ ab,
                                                                         double *__restrict__ part, double *__restrict__ gpart /*[entries][64][3]*/,
-                                                                        const int *__restrict__ converged /*null, or &ctl[1] of the precision-terminated solve*/) {
+                                                                        const int *__restrict__ converged /*null, or &ctl[1] of the precision-terminated solve*/,
+                                                                        long long *__restrict__ trace /*null; measurement only: [entries][4] = start, end (100 MHz ticks), HW_ID, XCC_ID*/) {
+	long long t_start = 0;
+	if (trace) t_start = wall_clock64();
 	__shared__ double2 s_xy[2 * kTile], s_zm[2 * kTile], s_mm[2 * kTile];
 	if (converged && *converged != 0) return; // an iteration enqueued ahead of the verdict: nothing to do
 	__shared__ double s_valid[2 * kTile];
@@ -360,16 +363,24 @@ __global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev
 	double *gslot = gpart + (size_t)blockIdx.x * kTile * 3;
 	if (tpA < 0) { // unused entry of this j-tile's segment: its slot is read by the update kernel all the same
 		if (threadIdx.x < kTile) gslot[3 * threadIdx.x] = gslot[3 * threadIdx.x + 1] = gslot[3 * threadIdx.x + 2] = 0.0;
+		if (trace && threadIdx.x == 0) trace[4 * (size_t)blockIdx.x + 1] = 0; // no work: the reader drops entries whose end stamp is 0
 		return;
 	}
 	if (tpB >= 0) panel_block<JACC, PIPE, 2>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
 	else panel_block<JACC, PIPE, 1>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
+	if (trace && threadIdx.x == 0) { // (wave 0 is the last one to leave a workgroup: it folds the partial sums)
+		long long *o = trace + 4 * (size_t)blockIdx.x;
+		o[0] = t_start;
+		o[1] = wall_clock64();
+		o[2] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+		o[3] = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (3 << 11));
+	}
 }
 
 // new_mu = alpha (E0 + F), F = sum of the panel kernel's slots of this tile X: part[S][X atoms] for S = X .. nt-1 (i-side, the diagonal
 // included) and gpart[e][.] for the entries of X's segment of the work table (j-side).  Same tail as k_dipole_update (contract_dipoles :3586-3593,
 // calc_dipole_rrms :3147-3177, are_we_done_yet :3227-3236).
-constexpr int kUpdGroups = 8;
+constexpr int kUpdGroups = 16;
 __global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDev at, const double *__restrict__ e_static, const double *__restrict__ part,
                                                                          const double *__restrict__ gpart, const int *__restrict__ seg, int nt,
                                                                          const double *__restrict__ mu_old, double *__restrict__ mu_new,
@@ -380,9 +391,22 @@ __global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDe
 	const int a = threadIdx.x & 63, g = threadIdx.x >> 6;
 	const int X = blockIdx.x, i = X * kTile + a;
 	const int nF = nt - X, wg0 = seg[X], nG = seg[X + 1] - wg0;
+	// two plain strided walks (i-side slots, then j-side slots) so that the loads of an unrolled group are independent and in flight
+	// together: the kernel is a latency chain otherwise (fewer workgroups than CUs).  The order of the sums is fixed by (g, t) alone.
 	double f[3] = {0, 0, 0};
-	for (int t = g; t < nF + nG; t += kUpdGroups) {
-		const double *q = (t < nF) ? part + ((size_t)(X + t) * at.n_pad + i) * 3 : gpart + ((size_t)(wg0 + t - nF) * kTile + a) * 3;
+	const double *pf = part + ((size_t)X * at.n_pad + i) * 3;
+	const size_t sf = (size_t)at.n_pad * 3;
+#pragma unroll 4
+	for (int t = g; t < nF; t += kUpdGroups) {
+		const double *q = pf + (size_t)t * sf;
+		f[0] += q[0];
+		f[1] += q[1];
+		f[2] += q[2];
+	}
+	const double *pg = gpart + ((size_t)wg0 * kTile + a) * 3;
+#pragma unroll 4
+	for (int t = g; t < nG; t += kUpdGroups) {
+		const double *q = pg + (size_t)t * (kTile * 3);
 		f[0] += q[0];
 		f[1] += q[1];
 		f[2] += q[2];
@@ -447,13 +471,13 @@ void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int 
 
 void launch_dipole_iter_panel(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                               const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart,
-                              const int *converged) {
+                              const int *converged, long long *trace) {
 	if (n_entries <= 0) return;
 	dim3 grid(n_entries), block(kTile * kPanelWaves);
 	if (jacc == 1)
-		hipLaunchKernelGGL((k_dipole_iter_panel<1, 4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged);
+		hipLaunchKernelGGL((k_dipole_iter_panel<1, 4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace);
 	else
-		hipLaunchKernelGGL((k_dipole_iter_panel<0, 4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged);
+		hipLaunchKernelGGL((k_dipole_iter_panel<0, 4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace);
 }
 
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,
