@@ -151,6 +151,7 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	if (const char *e = std::getenv("MPMC_THOLE_FAR_X")) c->thole_far_x = std::max(20.0, std::atof(e));
 	if (const char *e = std::getenv("MPMC_NO_SINGLE_LAUNCH")) c->single_launch = !(e[0] == '1');
 	if (const char *e = std::getenv("MPMC_NO_PANELS")) c->use_panels = !(e[0] == '1');
+	if (const char *e = std::getenv("MPMC_PAIR_WAVES")) c->pair_waves = (std::atoi(e) == 4) ? 4 : (std::atoi(e) == 1 ? 1 : 0);
 	if (const char *e = std::getenv("MPMC_NO_RECIP_TAB")) c->no_recip_tab = (e[0] == '1');
 	const size_t P = (size_t)c->max_pad;
 	A(dev_alloc(c, &c->d_xyzq, P));

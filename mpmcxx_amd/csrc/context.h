@@ -71,6 +71,7 @@ struct mpmc_ctx {
 	int *d_seg = nullptr;            // [n_tiles + 1] first entry of every j-tile's segment of that table
 	double *d_gpart = nullptr;       // [entries][64][3] j-side partial sums, one slot per entry of the table
 	size_t cap_panels = 0, cap_seg = 0;
+	int pair_waves = 0;              // 0: by table size (kPairSplitMax); MPMC_PAIR_WAVES=1|4 forces (measurement)
 	long long *d_trace = nullptr;    // measurement only (MPMC_TRACE_PANEL=1): [entries][4] start / end ticks, HW_ID, XCC_ID of every workgroup of the LAST panel launch
 	int n_panel_entries = 0, seg_tiles = -1; // entries of the table / the tile count its layout was made for
 	bool use_panels = true;          // MPMC_NO_PANELS=1: every tile pair through the single-tile-pair kernel (A/B comparisons)

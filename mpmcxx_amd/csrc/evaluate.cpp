@@ -78,7 +78,7 @@ static int ensure_polar_buffers(mpmc_ctx *c) {
 		if ((rc = dev_alloc(c, &c->d_mu[1], 3 * np)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_e_induced, 3 * np)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_rrms, np)) != MPMC_OK) return rc;
-		if ((rc = dev_alloc(c, &c->d_e_recip_part, (size_t)kKSplit * 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_e_recip_part, recip_slices_capacity(np))) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_e_real, 3 * np)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_e_real_trial, 3 * np)) != MPMC_OK) return rc;
 		// (dev_alloc zero-fills on the context's stream; nothing in this library touches the null stream, which is unordered against
@@ -290,6 +290,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		fp.wolf_erfa_over_r = std::erf(c->ewald_alpha * c->box.cutoff) / c->box.cutoff;
 		fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
 		fp.thole_far_x = c->thole_far_x;
+		fp.pair_waves = c->pair_waves ? c->pair_waves : (c->n_tile_pairs <= kPairSplitMax ? 4 : 1);
 		fp.store_only = ((mask & RUN_STORE) && !(mask & (RUN_PAIR | RUN_FIELD))) ? 1 : 0;
 		fp.touch_n = fp.store_only ? c->touch_n : -1;
 		for (int k = 0; k < 8; k++) fp.touch[k] = c->touch[k];

@@ -4,12 +4,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "pair_math.h"
 
 namespace mpmc {
 
 constexpr int kTile = 64; // one wavefront owns 64 i-atoms; j-atoms are staged in LDS 64 at a time
-constexpr int kKSplit = 8; // k-vector range split of the reciprocal field kernel
+constexpr int kKSplit = 8; // k-vector range split of the reciprocal field kernel: at least this many slices, ...
+constexpr int kKSplitMax = 64, kKSplitWaves = 1024;
+// ... and more when there are few tiles: one wave walks its slice of the k-vectors serially (26 us for the whole range over 8 slices,
+// whatever the number of atoms), so a small system cuts the range until about kKSplitWaves waves share it.  A function of n_pad alone:
+// the launcher of the field kernel and the kernel that adds the slices up both call it.
+inline int recip_ksplit(int n_pad) {
+	const int nt = n_pad / kTile;
+	int ks = kKSplit;
+	while (ks < kKSplitMax && nt * ks < kKSplitWaves) ks *= 2;
+	return ks;
+}
+// doubles in the slice buffer [recip_ksplit(n_pad)][n_pad][3] for any n_pad <= max_pad
+inline size_t recip_slices_capacity(size_t max_pad) { return std::max((size_t)kKSplit * 3 * max_pad, (size_t)2 * kKSplitWaves * kTile * 3); }
 
 // device view of one System's atoms (struct-of-arrays, padded to a multiple of kTile)
 struct AtomsDev {
@@ -66,7 +80,7 @@ void launch_atom_terms(hipStream_t st, const AtomsDev &at, const RecipDev &rc, c
                        int do_es, double *scal);
 
 // static field
-void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double *e_recip /*[kKSplit][n_pad][3]*/);
+void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double *e_recip /*[recip_ksplit(n_pad)][n_pad][3]*/);
 // E0 = recip*(8 pi/V) + sum_s part ; mu0 = gamma * alpha * E0
 void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip,
                            const double *part, int n_split, double gamma, double *e_static, double *mu,
@@ -104,7 +118,13 @@ struct FusedParams {
 	int store_only;     // nothing but the Thole tensor store (trial moves of polarizable boxes: energies and field come from the delta kernels)
 	int touch_n;        // store-only passes: >= 0 restricts the pass to the tile pairs that contain one of touch[0 .. touch_n) (the tiles of
 	int touch[8];       // the moved atoms: every other tile pair keeps the tensors it has); < 0: all tile pairs
+	int pair_waves;     // waves per tile pair of the sweep: 4 for small tables (n_tile_pairs <= kPairSplitMax), else 1
 };
+// Tables up to this many tile pairs run the pair sweep with four waves per tile pair.  Measured (profiles/r02_pair_waves.txt): one
+// evaluation at a time four waves win at every size (-12 % at 216 atoms, -11 % at 3000, -7 % at 5000, -3 % at 7000, -1 % at 10 000);
+// with 32 beads in flight they are level at 3000 atoms, +3..7 % at 5000, +1.4 % at 7000 (6105 tile pairs) and level (-0.3 %) at
+// 10 000 (12 403) -- so the switch sits between the last size with a gain in both regimes and the first without one.
+constexpr int kPairSplitMax = 8192;
 // every unordered pair once: energies + counts (block partials), static-field partials fpart[nt][n_pad][3],
 // Thole store ab[n_tile_pairs][64*64] (double2 = 16 B per pair)
 void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,

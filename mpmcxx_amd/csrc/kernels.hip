@@ -350,9 +350,9 @@ void launch_recip_energy(hipStream_t st, const RecipDev &rc, const Box &bx, doub
 // static field
 // ------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(64) void k_field_recip(AtomsDev at, RecipDev rc, double *__restrict__ e_part /*[kKSplit][n_pad][3]*/) {
+__global__ __launch_bounds__(64) void k_field_recip(AtomsDev at, RecipDev rc, double *__restrict__ e_part /*[gridDim.y][n_pad][3]*/) {
 	const int i = blockIdx.x * kTile + threadIdx.x;
-	const int per = (rc.K + kKSplit - 1) / kKSplit;
+	const int per = (rc.K + (int)gridDim.y - 1) / (int)gridDim.y; // gridDim.y = recip_ksplit(n_pad) slices
 	const int k0 = blockIdx.y * per, k1 = min(rc.K, k0 + per);
 	const double4 p = at.xyzq[i];
 	double ex = 0, ey = 0, ez = 0;
@@ -380,7 +380,8 @@ constexpr int kSlotGroups = 8;
 __device__ __forceinline__ void slot_sum_64(const double *__restrict__ part, int n_slots, int n_pad, int i, int a, int g,
                                             double (*sh)[kTile][3], double out[3]) {
 	double f[3] = {0, 0, 0};
-	for (int t = g; t < n_slots; t += kSlotGroups) {
+#pragma unroll 4
+	for (int t = g; t < n_slots; t += kSlotGroups) { // (unrolled: the loads of a group of four are in flight together; same order of sums)
 		const double *q = part + ((size_t)t * n_pad + i) * 3;
 		f[0] += q[0];
 		f[1] += q[1];
@@ -401,19 +402,21 @@ __device__ __forceinline__ void slot_sum_64(const double *__restrict__ part, int
 
 __global__ __launch_bounds__(512) void k_field_finalize(AtomsDev at, Box bx, int polar_ewald, const double *__restrict__ e_recip_part,
                                                         const double *__restrict__ part, int n_split, double gamma,
-                                                        double *__restrict__ e_static, double *__restrict__ mu, double *__restrict__ e_real_out) {
+                                                        double *__restrict__ e_static, double *__restrict__ mu, double *__restrict__ e_real_out, int n_kslices) {
 	__shared__ double sh[kSlotGroups][kTile][3];
+	__shared__ double shk[kSlotGroups][kTile][3];
 	const int a = threadIdx.x & 63, g = threadIdx.x >> 6;
 	const int i = blockIdx.x * kTile + a;
 	double real[3];
+	double e[3] = {0, 0, 0};
+	// the k-slices of the reciprocal field are added the way the real-space slots are: the eight groups stride over them, fixed-order
+	// fold (a small system has up to kKSplitMax slices; a serial walk by one thread was a 19 us chain)
+	if (polar_ewald) slot_sum_64(e_recip_part, n_kslices, at.n_pad, i, a, g, shk, e); // (block-uniform branch)
 	slot_sum_64(part, n_split, at.n_pad, i, a, g, sh, real);
 	if (g != 0) return;
 	if (e_real_out)
 		for (int p = 0; p < 3; ++p) e_real_out[3 * (size_t)i + p] = real[p];
-	double e[3] = {0, 0, 0};
 	if (polar_ewald) {
-		for (int s = 0; s < kKSplit; ++s)
-			for (int p = 0; p < 3; ++p) e[p] += e_recip_part[((size_t)s * at.n_pad + i) * 3 + p];
 		const double sc = 8.0 * kPi / bx.volume; // :2890
 		for (int p = 0; p < 3; ++p) e[p] *= sc;
 	}
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(64) void k_field_recip_tab(AtomsDev at, Box bx, Rec
 			tab[(size_t)(q * KM1 + m) * kTile + lane] = v;
 		}
 	}
-	const int per = (rc.K + kKSplit - 1) / kKSplit;
+	const int per = (rc.K + (int)gridDim.y - 1) / (int)gridDim.y; // gridDim.y = recip_ksplit(n_pad) slices
 	const int k0 = blockIdx.y * per, k1 = min(rc.K, k0 + per);
 	double ex = 0, ey = 0, ez = 0;
 	for (int k = k0; k < k1; ++k) {
@@ -468,16 +471,16 @@ __global__ __launch_bounds__(64) void k_field_recip_tab(AtomsDev at, Box bx, Rec
 void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double *e_recip_part) {
 	if (rc.lvec && kmax <= kRecipTabMaxK) {
 		const size_t lds = (size_t)3 * kTile * (kmax + 1) * sizeof(double2);
-		hipLaunchKernelGGL(k_field_recip_tab, dim3(at.n_pad / kTile, kKSplit), dim3(kTile), lds, st, at, bx, rc, kmax, e_recip_part);
+		hipLaunchKernelGGL(k_field_recip_tab, dim3(at.n_pad / kTile, recip_ksplit(at.n_pad)), dim3(kTile), lds, st, at, bx, rc, kmax, e_recip_part);
 		return;
 	}
-	hipLaunchKernelGGL(k_field_recip, dim3(at.n_pad / kTile, kKSplit), dim3(kTile), 0, st, at, rc, e_recip_part);
+	hipLaunchKernelGGL(k_field_recip, dim3(at.n_pad / kTile, recip_ksplit(at.n_pad)), dim3(kTile), 0, st, at, rc, e_recip_part);
 }
 
 void launch_field_finalize(hipStream_t st, const AtomsDev &at, const Box &bx, int polar_ewald, const double *e_recip_part, const double *part,
                            int n_split, double gamma, double *e_static, double *mu, double *e_real_out) {
 	hipLaunchKernelGGL(k_field_finalize, dim3(at.n_pad / kTile), dim3(kTile * kSlotGroups), 0, st, at, bx, polar_ewald, e_recip_part, part, n_split,
-	                   gamma, e_static, mu, e_real_out);
+	                   gamma, e_static, mu, e_real_out, recip_ksplit(at.n_pad));
 }
 
 // are_we_done_yet (:3215-3239) on the device.  ctl = { "some atom broke the tolerance in this iteration", iteration at which the solve

@@ -55,18 +55,21 @@ struct PairTail {
 	double *out_host; // [S_COUNT + C_COUNT + 1] device-visible pinned host memory (mpmc_ctx::h_scal); the last slot receives `seq`
 	double seq;       // launch number: written AFTER the results (system-scope fence in between), so a host that polls it sees them
 };
-template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP, bool EXT = false, bool ALPHA2 = false, bool TAIL = false>
-__global__ __launch_bounds__(TAIL ? 256 : 64) void k_pair_fused(AtomsDev at, Box bx, FusedParams fp, const int2 *__restrict__ tile_pairs,
+//   WAVES : waves per tile pair (1 or 4).  A lone wave's 64 dependent steps take 16 us with LJ alone and 65 us with Ewald + field +
+//           Thole store; a table of a few hundred tile pairs leaves most SIMDs empty, so small systems split the steps over four
+//           waves whose sums meet in LDS in wave order (reproducible).  Large tables keep one wave per tile pair (one prologue).
+template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP, bool EXT = false, bool ALPHA2 = false, bool TAIL = false, int WAVES = (TAIL ? 4 : 1)>
+__global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, FusedParams fp, const int2 *__restrict__ tile_pairs,
                                                    const int *__restrict__ cls, double *__restrict__ block_part, int *__restrict__ block_cnt,
                                                    double *__restrict__ fpart /*[nt][n_pad][3]*/, double2 *__restrict__ ab, PairTail tail = PairTail{}) {
 	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_q[kTile], s_sig[kTile], s_sqe[kTile];
 	__shared__ int s_mol[kTile], s_fl[kTile];
 	__shared__ double s_g[3 * kTile];
 
-	// TAIL (single-launch form of small systems): four waves share a tile pair, a quarter of the steps each -- a lone wave needs 16 us
-	// for its 64 dependent steps, and with a few hundred tile pairs there are SIMDs to spare
-	constexpr int W = TAIL ? 4 : 1;
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	static_assert(WAVES == 1 || WAVES == 4, "one wave per tile pair, or four");
+	static_assert(!TAIL || WAVES == 4, "the single-launch form is the four-wave form");
+	constexpr int W = WAVES;
+	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int2 IJ = tile_pairs[blockIdx.x];
 	if (THOLE && fp.store_only && fp.touch_n >= 0) { // (block-uniform) a trial move: only the tile pairs of the moved atoms' tiles are rebuilt
 		bool hit = false;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(TAIL ? 256 : 64) void k_pair_fused(AtomsDev at, Box
 	const int k_begin = w * (n_steps / W), k_end = k_begin + n_steps / W;
 	for (int k = k_begin; k < k_end; ++k) {
 		const int s = diag ? (s_first + k) : ((s_first + k) & 63);
-		const bool last = (k == n_steps - 1);
+		const bool last = (k == k_end - 1); // this wave's last step: its j-side accumulators stay where they are
 		const int jl = (lane + s) & 63;
 		const int molj = s_mol[jl];
 		bool act;
@@ -289,26 +292,57 @@ __global__ __launch_bounds__(TAIL ? 256 : 64) void k_pair_fused(AtomsDev at, Box
 	}
 
 	if (FIELD != 0) {
-		const int jl_last = (lane + s_first + n_steps - 1) & 63; // the j-atom whose accumulator this lane ended up holding
+		int jown = (lane + s_first + k_end - 1) & 63; // the j-atom whose accumulator this lane ended up holding
 		const int nt_pad3 = at.n_pad * 3;
-		if (diag) { // both sides belong to the same 64 atoms: fold through LDS, one slot [I][I-atoms]
-			s_g[3 * jl_last + 0] = gx;
-			s_g[3 * jl_last + 1] = gy;
-			s_g[3 * jl_last + 2] = gz;
+		bool writer = true;
+		if (W > 1) { // the waves' shares meet in LDS, parked at the atom they belong to, and are added in wave order by wave 0
+			__shared__ double s_fw[W][6][kTile];
+			s_fw[w][0][lane] = eix;
+			s_fw[w][1][lane] = eiy;
+			s_fw[w][2][lane] = eiz;
+			s_fw[w][3][jown] = gx;
+			s_fw[w][4][jown] = gy;
+			s_fw[w][5][jown] = gz;
 			__syncthreads();
-			double *o = fpart + (size_t)IJ.x * nt_pad3 + 3 * (size_t)i;
-			o[0] = eix + s_g[3 * lane + 0];
-			o[1] = eiy + s_g[3 * lane + 1];
-			o[2] = eiz + s_g[3 * lane + 2];
-		} else {
-			double *oi = fpart + (size_t)IJ.y * nt_pad3 + 3 * (size_t)i; // i-atoms, contribution of tile J
-			oi[0] = eix;
-			oi[1] = eiy;
-			oi[2] = eiz;
-			double *oj = fpart + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + jl_last); // j-atoms, contribution of tile I
-			oj[0] = gx;
-			oj[1] = gy;
-			oj[2] = gz;
+			writer = (w == 0);
+			if (writer) {
+				double v[6];
+#pragma unroll
+				for (int d = 0; d < 6; ++d) {
+					v[d] = s_fw[0][d][lane];
+#pragma unroll
+					for (int k = 1; k < W; ++k) v[d] += s_fw[k][d][lane];
+				}
+				eix = v[0], eiy = v[1], eiz = v[2];
+				gx = v[3], gy = v[4], gz = v[5];
+				jown = lane;
+			}
+		}
+		if (writer) {
+			if (diag) { // both sides belong to the same 64 atoms: one slot [I][I-atoms]
+				if (W == 1) { // fold through LDS
+					s_g[3 * jown + 0] = gx;
+					s_g[3 * jown + 1] = gy;
+					s_g[3 * jown + 2] = gz;
+					__syncthreads();
+					gx = s_g[3 * lane + 0];
+					gy = s_g[3 * lane + 1];
+					gz = s_g[3 * lane + 2];
+				}
+				double *o = fpart + (size_t)IJ.x * nt_pad3 + 3 * (size_t)i;
+				o[0] = eix + gx;
+				o[1] = eiy + gy;
+				o[2] = eiz + gz;
+			} else {
+				double *oi = fpart + (size_t)IJ.y * nt_pad3 + 3 * (size_t)i; // i-atoms, contribution of tile J
+				oi[0] = eix;
+				oi[1] = eiy;
+				oi[2] = eiz;
+				double *oj = fpart + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + jown); // j-atoms, contribution of tile I
+				oj[0] = gx;
+				oj[1] = gy;
+				oj[2] = gz;
+			}
 		}
 	}
 
@@ -398,6 +432,13 @@ static void launch_fused_t(hipStream_t st, bool dpp, const AtomsDev &at, const B
 			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
 		else
 			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+		return;
+	}
+	if (fp.pair_waves == 4) { // small table: four waves per tile pair
+		if (dpp)
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, false, false, false, 4>), dim3(ntp), dim3(4 * kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+		else
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, false, false, false, 4>), dim3(ntp), dim3(4 * kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
 		return;
 	}
 	if (dpp)

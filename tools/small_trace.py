@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Launch list of ONE steady-state evaluation of a small polarizable fixture (default ion216_polar), for rocprofv3 --kernel-trace:
+   cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/small_trace.py [fixture] [evals]
+then  python3 tools/small_trace.py --report $OUT   prints, for the last evaluation, every kernel with its duration and the gap before it."""
+import csv
+import glob
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+if len(sys.argv) > 2 and sys.argv[1] == "--report":
+    f = glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True)[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    # evaluations are separated by the pair sweep
+    starts = [i for i, r in enumerate(rows) if "k_pair_fused" in r["Kernel_Name"] or "k_tile_bounds" in r["Kernel_Name"]]
+    firsts = [i for k, i in enumerate(starts) if k == 0 or rows[starts[k - 1]]["Kernel_Name"] == rows[i]["Kernel_Name"] or True]
+    tb = [i for i, r in enumerate(rows) if "k_tile_bounds" in r["Kernel_Name"]] or [i for i, r in enumerate(rows) if "k_pair_fused" in r["Kernel_Name"]]
+    a, b = tb[-2], tb[-1]
+    ev = rows[a:b]
+    t0 = int(ev[0]["Start_Timestamp"])
+    busy = 0
+    prev_end = t0
+    print(f"{len(ev)} launches in the evaluation before the last one; span {(int(rows[b]['Start_Timestamp']) - t0) / 1e3:.1f} us")
+    for r in ev:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        busy += e - s
+        name = r["Kernel_Name"].replace("mpmc::", "").split("(")[0][:58]
+        print(f"  +{(s - t0) / 1e3:7.1f} us  gap {(s - prev_end) / 1e3:6.1f}  run {(e - s) / 1e3:6.1f}  {name}")
+        prev_end = e
+    print(f"kernel time {busy / 1e3:.1f} us")
+    sys.exit(0)
+
+import time  # noqa: E402
+
+import util  # noqa: E402
+from mpmcxx_amd import energy  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "ion216_polar"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+atoms, basis, opts = util.load_fixture(name)
+S = energy.System(atoms, basis, opts)
+for _ in range(20):
+    S.energy()
+t = time.perf_counter()
+for _ in range(n):
+    S.energy()
+dt = (time.perf_counter() - t) / n
+print(f"{name}: {len(atoms['pos'])} atoms, {dt * 1e6:.1f} us per evaluation (python loop), iterations {S.observables['polar_iterations']}")
+S.close()
