@@ -145,7 +145,8 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 		delete c;
 		return fail(nullptr, MPMC_ERR_HIP, "mpmc_ctx_create: hipStreamCreate failed");
 	}
-	if (const char *e = std::getenv("MPMC_ONE_STREAM")) c->two_streams = !(e[0] == '1');
+	if (const char *e = std::getenv("MPMC_ONE_STREAM")) c->stream_mode = (e[0] == '1') ? 0 : 1;
+	c->two_streams = (c->stream_mode != 0);
 	if (const char *e = std::getenv("MPMC_JACOBI")) c->jacobi_hybrid = (e[0] != 's');
 	if (const char *e = std::getenv("MPMC_NO_UNI")) c->no_uniform = (e[0] == '1');
 	if (const char *e = std::getenv("MPMC_THOLE_FAR_X")) c->thole_far_x = std::max(20.0, std::atof(e));

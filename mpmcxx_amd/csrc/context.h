@@ -33,7 +33,8 @@ struct mpmc_ctx {
 	// pair sweep; the far-field Jacobi kernel next to the streaming one); always joined back before results are used
 	hipStream_t stream2 = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-	bool two_streams = true; // MPMC_ONE_STREAM=1 disables the fork/join
+	bool two_streams = true; // the side stream is forked in THIS evaluation (set per evaluation from stream_mode and the table size)
+	int stream_mode = -1;    // -1: by table size (kOneStreamMaxPairs); MPMC_ONE_STREAM=1 -> 0 never fork, =0 -> 1 always fork
 	int jacc = 0; // hybrid Jacobi kernel variant (MPMC_JACC): 0 DPP lane rotation, 1 ds_bpermute (when the DPP self-test fails)
 	bool jacobi_hybrid = true; // one launch per Jacobi iteration over all tile pairs; MPMC_JACOBI=split: two kernels (stream / far)
 	int max_atoms = 0, max_pad = 0;

@@ -233,7 +233,9 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	// when every molecule is a single atom
 	const bool need_intra = (mask & RUN_PAIR) && (mask & RUN_PAIR_ES) && !(o.wolf && (mask & RUN_WOLF)) && (c->n_molecules != c->n);
 	const bool side_work = need_sf || need_intra;
-	// a fork/join costs ~20 us of dispatch latency: worth it next to reciprocal-space work, not for the O(N) atom terms alone
+	// a fork/join costs ~20 us of dispatch latency: worth it next to reciprocal-space work, not for the O(N) atom terms alone -- and not
+	// for small tables at all (kOneStreamMaxPairs).  Decided here, once per evaluation: nothing is forked at this point.
+	c->two_streams = (c->stream_mode == 1) || (c->stream_mode < 0 && c->n_tile_pairs > kOneStreamMaxPairs);
 	const bool side_fork = c->two_streams && (need_sf || need_intra);
 	bool panel_side = false; // the panel table of the Jacobi contraction is being built on the side stream
 	if (side_work) {

@@ -120,6 +120,11 @@ struct FusedParams {
 	int touch[8];       // the moved atoms: every other tile pair keeps the tensors it has); < 0: all tile pairs
 	int pair_waves;     // waves per tile pair of the sweep: 4 for small tables (n_tile_pairs <= kPairSplitMax), else 1
 };
+// Tables up to this many tile pairs run everything on ONE stream: forking the side stream (reciprocal space, panel table) and joining it
+// costs two cross-stream waits, more than the 20-odd us of work they overlap.  Measured (profiles/r02_one_stream.txt), one evaluation at
+// a time: -11 % at 216 atoms, -7 % at 1000, -5 % at 2000, -2 % at 3000 (1128 tile pairs), level at 4000 (2016), +3 % at 5000, +2 % at
+// 10 000; with 32 beads in flight: +7 % evaluations/s at 3000 atoms on one stream, level at 5000 and 7000, -2.6 % at 10 000.
+constexpr int kOneStreamMaxPairs = 1536;
 // Tables up to this many tile pairs run the pair sweep with four waves per tile pair.  Measured (profiles/r02_pair_waves.txt): one
 // evaluation at a time four waves win at every size (-12 % at 216 atoms, -11 % at 3000, -7 % at 5000, -3 % at 7000, -1 % at 10 000);
 // with 32 beads in flight they are level at 3000 atoms, +3..7 % at 5000, +1.4 % at 7000 (6105 tile pairs) and level (-0.3 %) at

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Where four waves per tile pair stop paying in the pair sweep: full evaluations of the polarizable ion box of bench.py at several sizes with
-MPMC_PAIR_WAVES=1 and =4 (the switch is read when a context is created), same process, same box; energies of the two forms compared."""
+"""Two settings of a switch that is read when a context is created, over system sizes: full evaluations of the polarizable ion box of
+bench.py, one at a time, same process, same box, the settings interleaved (three rounds); energies of the two forms compared.
+   python tools/pair_waves_sweep.py [--env NAME=a,b] [sizes...]      default: MPMC_PAIR_WAVES=1,4 (one against four waves per tile pair
+   in the pair sweep); MPMC_ONE_STREAM=0,1 places the size below which the side stream is not forked."""
 import os
 import sys
 import tempfile
@@ -11,22 +13,32 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from mpmcxx_amd import energy  # noqa: E402
 
-sizes = [int(x) for x in sys.argv[1:]] or [216, 512, 1000, 2000, 3000, 4000, 5000, 7000, 10000]
+args = sys.argv[1:]
+name, values = "MPMC_PAIR_WAVES", ["1", "4"]
+if args and args[0] == "--env":
+    name, v = args[1].split("=")
+    values = v.split(",")
+    args = args[2:]
+sizes = [int(x) for x in args] or [216, 512, 1000, 2000, 3000, 4000, 5000, 7000, 10000]
 tmp = tempfile.mkdtemp()
-print("atoms  tile_pairs   W=1 us/eval   W=4 us/eval   rel.diff of the energies")
+print(f"atoms  tile_pairs   {name}={values[0]} us/eval (3 rounds)      {name}={values[1]} us/eval (3 rounds)      rel.diff of the energies")
 for n in sizes:
     atoms, basis, opts = bench.build_case(n, tmp)
-    res = {}
-    for w in (1, 4):
-        os.environ["MPMC_PAIR_WAVES"] = str(w)
-        S = energy.System(atoms, basis, opts)
-        for _ in range(5):
-            e = S.energy()
-        reps = 40 if n <= 4000 else 15
-        t = time.perf_counter()
-        for _ in range(reps):
-            S.energy()
-        res[w] = ((time.perf_counter() - t) / reps * 1e6, e)
-        S.close()
+    res = {v: [] for v in values}
+    en = {}
+    for rnd in range(3):
+        for v in values:
+            os.environ[name] = v
+            S = energy.System(atoms, basis, opts)
+            for _ in range(5):
+                en[v] = S.energy()
+            reps = 200 if n <= 1000 else (60 if n <= 4000 else 20)
+            t = time.perf_counter()
+            for _ in range(reps):
+                S.energy()
+            res[v].append((time.perf_counter() - t) / reps * 1e6)
+            S.close()
     nt = (len(atoms["pos"]) + 63) // 64
-    print(f"{len(atoms['pos']):5d}  {nt * (nt + 1) // 2:9d}   {res[1][0]:10.1f}   {res[4][0]:10.1f}   {abs(res[1][1] - res[4][1]) / abs(res[1][1]):.2e}", flush=True)
+    a, b = values
+    print(f"{len(atoms['pos']):5d}  {nt * (nt + 1) // 2:9d}   " + " / ".join(f"{x:7.1f}" for x in res[a]) + "      " + " / ".join(f"{x:7.1f}" for x in res[b])
+          + f"      {abs(en[a] - en[b]) / abs(en[a]):.2e}", flush=True)
