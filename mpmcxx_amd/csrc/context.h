@@ -100,6 +100,8 @@ struct mpmc_ctx {
 	double h_static[3] = {0, 0, 0}; // lrc_pair, lrc_self, es_self
 	int *d_counter = nullptr;       // ticket counter of the single-launch small-system kernels (zero between launches)
 	bool single_launch = true;      // MPMC_NO_SINGLE_LAUNCH=1: small systems take the general multi-kernel path
+	bool scal_clean = false;        // d_scal is all zeros (the post kernel of the last evaluation left it so): no clear needed in front of this one
+	bool spin_on_post = false;      // the pending evaluation ends in k_post_results and is short: wait_and_fill polls the launch number first
 	bool last_was_single = false;   // the pending evaluation wrote h_scal from the device: nothing to copy back
 	double single_seq = 0;          // launch number the single-launch kernel posts behind its results (host polls h_scal[S_COUNT + C_COUNT])
 	// scalars

@@ -155,6 +155,9 @@ int mpmc::prepare(mpmc_ctx *c) {
 		c->k_dirty = false;
 	}
 	if (c->static_dirty) { // pair LRC (O(N) moment form), self LRC, Ewald self term: position independent (lj_lrc_corr / lj_lrc_self :1036-1096, coulombic_self :1626-1643)
+		// (the kernel ADDS into its three slots: they start from zero here whatever came before, and the block counts as used afterwards)
+		HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (S_COUNT + C_COUNT) * sizeof(double), c->stream));
+		c->scal_clean = false;
 		launch_atom_terms(c->stream, atoms_view(c), recip_view(c), c->box, c->ewald_alpha, c->opts.rd_lrc, /*self term*/ 2, c->d_scal);
 		HIP_TRY(c, hipGetLastError());
 		double tmp[S_COUNT];
@@ -206,6 +209,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	c->failed = 0;
 
 	c->last_was_single = false;
+	c->spin_on_post = false;
 	if (c->single_launch && mask == (RUN_PAIR | RUN_ATOMTERMS) && !o.feynman_hibbs && c->n_tiles <= kSingleLaunchTiles && !c->prof) {
 		// small LJ box (BASELINE configs[1]): the whole evaluation is one launch -- pair sweep without classes, the block that finishes last
 		// folds the partials into the pinned result vector; the LRC terms are the cached position-independent ones
@@ -219,7 +223,10 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		c->pending = true;
 		return MPMC_OK;
 	}
-	HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (S_COUNT + C_COUNT) * sizeof(double), st));
+	// the scalar block: zeroed by the post kernel of the evaluation before this one; cleared here only when something else used it since
+	// (the static-terms pass, the lockstep path of pi.cpp, an evaluation that failed half way)
+	if (!c->scal_clean) HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (S_COUNT + C_COUNT) * sizeof(double), st));
+	c->scal_clean = false;
 
 	if (mask & (RUN_FIELD | RUN_SOLVE | RUN_STORE)) {
 		if ((rc = ensure_polar_buffers(c)) != MPMC_OK) return rc;
@@ -511,7 +518,15 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	}
 	if (reduce_forked) join_side(c);
 	HIP_TRY(c, hipGetLastError());
-	HIP_TRY(c, hipMemcpyAsync(c->h_scal, c->d_scal, (S_COUNT + C_COUNT) * sizeof(double), hipMemcpyDeviceToHost, st));
+	// results to the pinned block by a kernel of ours (a blit and a stream synchronisation cost more than the whole reciprocal space of a
+	// small box): copy, zero the device block for the next evaluation, launch number last
+	c->single_seq += 1.0;
+	launch_post_results(st, c->d_scal, c->h_scal, c->single_seq);
+	HIP_TRY(c, hipGetLastError());
+	c->scal_clean = true;
+	// short evaluations are polled for (a few us against ~10-15 for the synchronisation); long ones, and profiled ones (the event
+	// harvest needs an idle stream), are waited for the ordinary way
+	c->spin_on_post = (c->n_tile_pairs <= kOneStreamMaxPairs) && c->ev_used.empty();
 	c->pending = true;
 	return MPMC_OK;
 }
@@ -521,10 +536,11 @@ int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 	if (!c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_energy_wait: nothing enqueued");
 	HIP_TRY(c, hipSetDevice(c->device));
 	bool seen = false;
-	if (c->last_was_single) {
+	if (c->last_was_single || c->spin_on_post) {
 		// the kernel posts its launch number behind the results (system-scope release): a short spin on the pinned slot returns a few
 		// microseconds before the driver's own completion path would; past the budget, or if anything is off, fall back to the sync
 		volatile const double *flag = c->h_scal + S_COUNT + C_COUNT;
+		const auto budget = std::chrono::microseconds(c->last_was_single ? 200 : 1000);
 		const auto t0 = std::chrono::steady_clock::now();
 		for (int spins = 0;; ++spins) {
 			if (*flag == c->single_seq) {
@@ -532,7 +548,7 @@ int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 				seen = true;
 				break;
 			}
-			if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+			if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) break;
 		}
 	}
 	if (!seen) HIP_TRY(c, hipStreamSynchronize(c->sync_stream ? c->sync_stream : c->stream));

@@ -94,6 +94,9 @@ void launch_dipole_update(hipStream_t st, const AtomsDev &at, const double *e_st
                           double allowed_sqerr, int *ctl, int *host_flag /*pinned {closed iteration, converged-at}, may be null*/, int it);
 // iterator failure: mu = alpha * E0
 void launch_dipole_reset(hipStream_t st, const AtomsDev &at, const double *e_static, double *mu);
+// end of an evaluation: the scalar block [S_COUNT doubles][C_COUNT int64] goes to pinned host memory, the launch number behind it (a host
+// that polls that slot finds the results complete), and the device block is left zeroed for the next evaluation
+void launch_post_results(hipStream_t st, double *scal, double *out_host, double seq);
 void launch_polar_energy(hipStream_t st, const AtomsDev &at, const double *mu, const double *e_static, const double *rrms_atom,
                          double *scal);
 

@@ -468,6 +468,21 @@ __global__ __launch_bounds__(64) void k_field_recip_tab(AtomsDev at, Box bx, Rec
 	o[2] = ez;
 }
 
+__global__ __launch_bounds__(64) void k_post_results(double *__restrict__ scal, double *__restrict__ out_host, double seq) {
+	static_assert(S_COUNT + C_COUNT <= 64, "one wave posts the scalar block");
+	const int t = threadIdx.x;
+	if (t < S_COUNT + C_COUNT) { // (the counts travel as bit patterns: loads and stores only)
+		const double v = scal[t];
+		out_host[t] = v;
+		scal[t] = 0.0;
+	}
+	__threadfence_system();
+	if (t == 0) __hip_atomic_store(out_host + S_COUNT + C_COUNT, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_post_results(hipStream_t st, double *scal, double *out_host, double seq) {
+	hipLaunchKernelGGL(k_post_results, dim3(1), dim3(64), 0, st, scal, out_host, seq);
+}
+
 void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double *e_recip_part) {
 	if (rc.lvec && kmax <= kRecipTabMaxK) {
 		const size_t lds = (size_t)3 * kTile * (kmax + 1) * sizeof(double2);
