@@ -218,7 +218,8 @@ void launch_gs_finish(hipStream_t st, const AtomsDev &at, const double *mu_old, 
 // out4 = { d lj_pairs, d es_real(erfc part), d intramolecular term, E_recip of the trial structure factors }, dcnt2 = { d n_lj, d n_es }
 void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc, double alpha, int do_es,
                   const int *mv_slot, const int *orig_of_mv, const double4 *mv_new, int m, int *moved_idx, double4 *sf_trial,
-                  double *block_part, int *block_cnt, double *out4, long long *dcnt2);
+                  double *block_part, int *block_cnt, double *out4, long long *dcnt2,
+                  double *host_out /*pinned [9]: the result and, last, the launch number `seq`*/, double seq);
 void launch_commit_positions(hipStream_t st, double4 *xyzq, const int *mv_slot, const double4 *mv_new, int m);
 // polarizable boxes: e_real_trial = e_real + (real-space static field of the pairs with a moved atom, new minus old geometry);
 // dk_part: scratch [n_tiles][m][3]

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(64) void k_delta_recip(AtomsDev at, RecipDev rc, co
 __global__ __launch_bounds__(256) void k_delta_finish(const double *__restrict__ block_part, const int *__restrict__ block_cnt, int nb,
                                                       RecipDev rc, const double4 *__restrict__ sf_trial, Box bx, int do_es,
                                                       double *__restrict__ out /* dlj, des_real, (dintra at [2]), e_recip_trial at [3] */,
-                                                      long long *__restrict__ dcnt) {
+                                                      long long *__restrict__ dcnt,
+                                                      double *__restrict__ host_out /* pinned [9]: the same 5 doubles + 2 counts, spare, launch number */,
+                                                      double seq) {
 	__shared__ double sh[4];
 	__shared__ long long shc[256];
 	double s0 = 0, s1 = 0, e = 0;
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void k_delta_finish(const double *__restrict__
 		out[3] = e * (4.0 * kPi / bx.volume);
 		out[4] = (double)0;
 	}
+	long long tot[2] = {0, 0};
 	for (int k = 0; k < 2; ++k) {
 		__syncthreads();
 		shc[threadIdx.x] = k ? c1 : c0;
@@ -197,7 +200,21 @@ __global__ __launch_bounds__(256) void k_delta_finish(const double *__restrict__
 			if (threadIdx.x < off) shc[threadIdx.x] += shc[threadIdx.x + off];
 			__syncthreads();
 		}
-		if (threadIdx.x == 0) dcnt[k] = shc[0];
+		if (threadIdx.x == 0) dcnt[k] = tot[k] = shc[0];
+	}
+	// the result goes to the caller's pinned block from here (no copy-back command, no stream synchronisation: the host polls the launch
+	// number, which is stored last, behind a system-scope fence)
+	if (host_out && threadIdx.x == 0) {
+		host_out[0] = s0;
+		host_out[1] = s1;
+		host_out[2] = do_es ? out[2] : 0.0;
+		host_out[3] = e * (4.0 * kPi / bx.volume);
+		host_out[4] = 0.0;
+		long long *hc = reinterpret_cast<long long *>(host_out + 5);
+		hc[0] = tot[0];
+		hc[1] = tot[1];
+		__threadfence_system();
+		__hip_atomic_store(host_out + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 
@@ -336,7 +353,7 @@ __global__ void k_commit_positions(double4 *__restrict__ xyzq, const int *__rest
 }
 void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc, double alpha, int do_es,
                   const int *mv_slot, const int *orig_of_mv, const double4 *mv_new, int m, int *moved_idx, double4 *sf_trial,
-                  double *block_part, int *block_cnt, double *out4, long long *dcnt2) {
+                  double *block_part, int *block_cnt, double *out4, long long *dcnt2, double *host_out, double seq) {
 	const int nt = at.n_pad / kTile;
 	const bool use_map = (m > 8); // short lists are scanned in the kernels; long ones go through the slot -> list-index map
 	if (use_map) hipLaunchKernelGGL(k_mark_moved, dim3((m + 63) / 64), dim3(64), 0, st, moved_idx, mv_slot, m, 1);
@@ -349,7 +366,7 @@ void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const 
 		hipLaunchKernelGGL(k_delta_intra, dim3(1), dim3(64), 0, st, at, slot_of, alpha, orig_of_mv, mv_new, m, moved_idx, out4 + 2);
 		if (rc.K > 0) hipLaunchKernelGGL(k_delta_recip, dim3(rc.K), dim3(64), 0, st, at, rc, mv_slot, mv_new, m, sf_trial);
 	}
-	hipLaunchKernelGGL(k_delta_finish, dim3(1), dim3(256), 0, st, block_part, block_cnt, nt, rc, sf_trial, bx, do_es, out4, dcnt2);
+	hipLaunchKernelGGL(k_delta_finish, dim3(1), dim3(256), 0, st, block_part, block_cnt, nt, rc, sf_trial, bx, do_es, out4, dcnt2, host_out, seq);
 	if (use_map) hipLaunchKernelGGL(k_mark_moved, dim3((m + 63) / 64), dim3(64), 0, st, moved_idx, mv_slot, m, 0);
 }
 

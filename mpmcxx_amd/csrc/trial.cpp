@@ -1,5 +1,8 @@
 // trial.cpp -- per-move delta energies (mpmc_trial_*): the device-side counterpart of the reference's per-pair cache
 // (part of libmpmc_energy.so; shared state and helpers: context.h.  There is no CPU fallback anywhere in this library.)
+#include <atomic>
+#include <chrono>
+
 #include "context.h"
 
 
@@ -18,7 +21,8 @@ static int ensure_trial_buffers(mpmc_ctx *c) {
 		if ((rc = dev_alloc(c, &c->d_delta_out, (size_t)8)) != MPMC_OK) return rc; // 5 doubles + 2 int64 counts
 		c->d_delta_cnt = reinterpret_cast<long long *>(c->d_delta_out + 5);
 		HIP_TRY(c, hipMemsetAsync(c->d_moved_idx, 0xff, (size_t)c->max_pad * sizeof(int), c->stream)); // all -1; on our stream (ordered before the first delta kernel)
-		HIP_TRY(c, hipHostMalloc((void **)&c->h_delta_out, 8 * sizeof(double)));
+		HIP_TRY(c, hipHostMalloc((void **)&c->h_delta_out, 9 * sizeof(double)));
+		c->h_delta_out[8] = 0.0;
 		c->h_delta_cnt = reinterpret_cast<long long *>(c->h_delta_out + 5);
 		HIP_TRY(c, hipHostMalloc((void **)&c->h_mv_blob, kMvBlobBytes));
 	}
@@ -98,10 +102,10 @@ extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
 	{
 		ProfScope p(c, MPMC_K_PAIR);
 		launch_delta(st, atoms_view(c), c->d_slot_of, c->box, recip_view(c), c->ewald_alpha, do_es, c->d_mv_slot, c->d_mv_orig, c->d_mv_new, m,
-		             c->d_moved_idx, c->d_sf_trial, c->d_block_part, c->d_block_cnt, c->d_delta_out, c->d_delta_cnt);
+		             c->d_moved_idx, c->d_sf_trial, c->d_block_part, c->d_block_cnt, c->d_delta_out, c->d_delta_cnt, c->h_delta_out,
+		             (c->trial_seq += 1.0));
 	}
-	HIP_TRY(c, hipGetLastError());
-	HIP_TRY(c, hipMemcpyAsync(c->h_delta_out, c->d_delta_out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipGetLastError()); // (k_delta_finish posts the result into h_delta_out itself)
 	c->trial_was_full = false;
 	if (polar_delta) {
 		// Polarizable box: the pair energies and structure factors above are O(m N); the static field follows the same way -- real part:
@@ -180,7 +184,22 @@ extern "C" int mpmc_trial_energy_wait(mpmc_ctx *c, mpmc_result *out) {
 		c->last_full = keep;
 		if (rc != MPMC_OK) return rc;
 	} else {
-		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		// the finish kernel posts its launch number behind the result: poll for it (a trial is a few tens of microseconds; the stream
+		// synchronisation alone costs 10-15); with profiling events outstanding, or past the budget, wait the ordinary way
+		bool seen = false;
+		if (c->ev_used.empty()) {
+			volatile const double *flag = c->h_delta_out + 8;
+			const auto t0 = std::chrono::steady_clock::now();
+			for (int spins = 0;; ++spins) {
+				if (*flag == c->trial_seq) {
+					std::atomic_thread_fence(std::memory_order_acquire);
+					seen = true;
+					break;
+				}
+				if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) break;
+			}
+		}
+		if (!seen) HIP_TRY(c, hipStreamSynchronize(c->stream));
 		prof_harvest(c);
 	}
 	const int do_es = c->opts.rd_only ? 0 : 1;
@@ -235,7 +254,8 @@ extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
 		HIP_TRY(c, hipGetLastError());
 		std::swap(c->d_sf, c->d_sf_trial); // the trial structure factors become the accepted ones
 		std::swap(c->cap_sf, c->cap_sf_trial); // (d_sf has its own capacity: cap_K sizes the k tables, which do not move)
-		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		// (no wait: whatever comes next on this context is enqueued behind the commit on the same stream, and the host mirrors below are
+		// the host's own -- the stream synchronisation that stood here cost 13 us of a 41 us accepted move)
 		for (int t = 0; t < 3 * m; t++) c->h_pos[3 * (size_t)c->trial_first + t] = c->trial_new[t];
 		for (int t = 0; t < m; t++) { // the slot-ordered mirror follows (a later bulk position update uploads it as a whole)
 			double4 &v = c->h_xyzq[c->slot_of[c->trial_first + t]];
@@ -261,8 +281,7 @@ extern "C" int mpmc_trial_reject(mpmc_ctx *c) {
 	if (c->trial_polar_delta) { // (enqueued or evaluated) the device holds the trial positions: swap the accepted ones back
 		HIP_TRY(c, hipSetDevice(c->device));
 		launch_swap_positions(c->stream, c->d_xyzq, c->d_mv_slot, c->d_mv_new, c->trial_count);
-		HIP_TRY(c, hipGetLastError());
-		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		HIP_TRY(c, hipGetLastError()); // (stream-ordered in front of whatever comes next: nothing to wait for)
 		c->trial_polar_delta = false;
 		return MPMC_OK; // (the store, classes and dipoles describe the rejected geometry; the next trial or energy() rebuilds them)
 	}

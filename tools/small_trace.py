@@ -42,6 +42,34 @@ name = sys.argv[1] if len(sys.argv) > 1 else "ion216_polar"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 atoms, basis, opts = util.load_fixture(name)
 S = energy.System(atoms, basis, opts)
+if len(sys.argv) > 3 and sys.argv[3] == "trial":  # us per trial move: trial_energy + reject, and trial_energy + accept
+    import numpy as np
+
+    rng = np.random.default_rng(1)
+    ids = atoms["mol_id"]
+    starts = [0] + [i for i in range(1, len(ids)) if ids[i] != ids[i - 1]] + [len(ids)]
+    pos = atoms["pos"].copy()
+    S.energy()
+    out = []
+    for accept in (False, True):
+        moves = []
+        for _ in range(n + 20):
+            k = int(rng.integers(len(starts) - 1))
+            moves.append((starts[k], starts[k + 1], rng.normal(scale=0.05, size=(starts[k + 1] - starts[k], 3))))
+        t = 0.0
+        for it, (a, b, d) in enumerate(moves):
+            if it == 20:
+                t = time.perf_counter()
+            S.trial_energy(a, pos[a:b] + d)
+            if accept:
+                S.accept()
+                pos[a:b] += d
+            else:
+                S.reject()
+        out.append((time.perf_counter() - t) / n * 1e6)
+    print(f"{name}: {len(pos)} atoms, trial + reject {out[0]:.1f} us, trial + accept {out[1]:.1f} us (python loop)")
+    S.close()
+    sys.exit(0)
 for _ in range(20):
     S.energy()
 t = time.perf_counter()
