@@ -175,6 +175,8 @@ struct mpmc_ctx {
 	unsigned char *d_mv_blob = nullptr, *h_mv_blob = nullptr; // device / pinned host staging of a trial's moved-atom list
 	int cap_sf_trial = 0;
 	double *d_delta_out = nullptr, *h_delta_out = nullptr; // h: pinned [9] = 5 doubles, 2 int64 counts, spare, launch number (k_delta_finish posts it)
+	MvInline mv_inline{};          // the pending trial's move when it travelled in the kernel arguments (trial_inline)
+	bool trial_inline = false;
 	double trial_seq = 0;          // launch number of the pending trial's k_delta_finish
 	long long *d_delta_cnt = nullptr, *h_delta_cnt = nullptr;
 

@@ -216,10 +216,18 @@ void launch_gs_finish(hipStream_t st, const AtomsDev &at, const double *mu_old, 
 
 // ---- trial moves (kernels_delta.hip) ----------------------------------------------------------------------
 // out4 = { d lj_pairs, d es_real(erfc part), d intramolecular term, E_recip of the trial structure factors }, dcnt2 = { d n_lj, d n_es }
+// a trial move short enough to travel in the kernel arguments (no staging copy): trial positions + charge, slot and original index
+constexpr int kMvInline = 8;
+struct MvInline {
+	double nw[kMvInline][4];
+	int slot[kMvInline], orig[kMvInline];
+};
+void launch_commit_positions_inline(hipStream_t st, double4 *xyzq, const MvInline &inl, int m);
 void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc, double alpha, int do_es,
                   const int *mv_slot, const int *orig_of_mv, const double4 *mv_new, int m, int *moved_idx, double4 *sf_trial,
                   double *block_part, int *block_cnt, double *out4, long long *dcnt2,
-                  double *host_out /*pinned [9]: the result and, last, the launch number `seq`*/, double seq);
+                  double *host_out /*pinned [9]: the result and, last, the launch number `seq`*/, double seq,
+                  const MvInline *inl = nullptr /*non-null: the move is in here (m <= kMvInline), the device lists are not read*/);
 void launch_commit_positions(hipStream_t st, double4 *xyzq, const int *mv_slot, const double4 *mv_new, int m);
 // polarizable boxes: e_real_trial = e_real + (real-space static field of the pairs with a moved atom, new minus old geometry);
 // dk_part: scratch [n_tiles][m][3]

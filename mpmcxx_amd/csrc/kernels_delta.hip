@@ -35,13 +35,45 @@ __device__ __forceinline__ void pair_terms(const Box &bx, double alpha, int do_e
 	}
 }
 
-// grid (n_tiles, 1); block 64: thread = atom slot j of tile blockIdx.x; loops over the m moved atoms.
-// mv_slot[k]: slot of moved atom k; mv_new[k]: its trial position (+ charge); moved_idx[slot]: k or -1.
-template <bool ORTHO>
-__global__ __launch_bounds__(64) void k_delta_pairs(AtomsDev at, Box bx, double alpha, int do_es, const int *__restrict__ mv_slot,
-                                                    const double4 *__restrict__ mv_new, int m, const int *__restrict__ moved_idx,
-                                                    double *__restrict__ block_part, int *__restrict__ block_cnt) {
-	const int j = blockIdx.x * kTile + threadIdx.x;
+// Where the kernels read the move from: device arrays (any m; staged by one host-to-device copy) or the kernel arguments themselves
+// (MvInline, m <= kMvInline: no copy command at all -- a trial move is launch-bound on the host, and every call counts).
+struct MvDev {
+	const int *slot_, *orig_;
+	const double4 *nw_;
+	__device__ __forceinline__ int slot(int k) const { return slot_[k]; }
+	__device__ __forceinline__ int orig(int k) const { return orig_[k]; }
+	__device__ __forceinline__ double4 nw(int k) const { return nw_[k]; }
+};
+struct MvArg { // every element is read with a STATIC index (scalar loads from the argument segment) and selected: k may differ per lane
+	MvInline d;
+	__device__ __forceinline__ int slot(int k) const {
+		int r = d.slot[0];
+#pragma unroll
+		for (int q = 1; q < kMvInline; ++q) r = (k == q) ? d.slot[q] : r;
+		return r;
+	}
+	__device__ __forceinline__ int orig(int k) const {
+		int r = d.orig[0];
+#pragma unroll
+		for (int q = 1; q < kMvInline; ++q) r = (k == q) ? d.orig[q] : r;
+		return r;
+	}
+	__device__ __forceinline__ double4 nw(int k) const {
+		double4 r = make_double4(d.nw[0][0], d.nw[0][1], d.nw[0][2], d.nw[0][3]);
+#pragma unroll
+		for (int q = 1; q < kMvInline; ++q)
+			if (k == q) r = make_double4(d.nw[q][0], d.nw[q][1], d.nw[q][2], d.nw[q][3]);
+		return r;
+	}
+};
+
+// thread = atom slot j of tile `tile`; loops over the m moved atoms.
+// mv.slot(k): slot of moved atom k; mv.nw(k): its trial position (+ charge); moved_idx[slot]: k or -1.
+template <bool ORTHO, class MV>
+__device__ __forceinline__ void delta_pairs_tile(const AtomsDev &at, const Box &bx, double alpha, int do_es, const MV &mv, int m,
+                                                 const int *__restrict__ moved_idx, double *__restrict__ block_part, int *__restrict__ block_cnt,
+                                                 int tile) {
+	const int j = tile * kTile + threadIdx.x;
 	const double4 pj_old = at.xyzq[j];
 	const double2 lj = at.lj[j];
 	const int2 mj = at.mf[j];
@@ -49,21 +81,21 @@ __global__ __launch_bounds__(64) void k_delta_pairs(AtomsDev at, Box bx, double 
 	if (moved_idx) kj = moved_idx[j];
 	else
 		for (int k = 0; k < m; ++k)
-			if (mv_slot[k] == j) kj = k;
-	const double4 pj_new = (kj >= 0) ? mv_new[kj] : pj_old;
+			if (mv.slot(k) == j) kj = k;
+	const double4 pj_new = (kj >= 0) ? mv.nw(kj) : pj_old;
 	double e_lj = 0, e_re = 0;
 	int n_lj = 0, n_es = 0;
 	if (!(mj.y & AF_PAD)) {
 		for (int k = 0; k < m; ++k) {
 			if (kj >= 0 && kj <= k) continue; // moved-moved pairs once (k < kj), never the atom with itself
-			const int si = mv_slot[k];
+			const int si = mv.slot(k);
 			const int2 mi = at.mf[si];
 			const PairFlags f = pair_flags(mi.x, mi.y, mj.x, mj.y);
 			if (f.frozen) continue;
 			const double2 li = at.lj[si];
 			double sig, eps;
 			lj_mix(mi.y, mj.y, li.x, li.y, lj.x, lj.y, sig, eps);
-			pair_terms<ORTHO>(bx, alpha, do_es, mv_new[k], pj_new, sig, eps, f, 1.0, e_lj, e_re, n_lj, n_es);
+			pair_terms<ORTHO>(bx, alpha, do_es, mv.nw(k), pj_new, sig, eps, f, 1.0, e_lj, e_re, n_lj, n_es);
 			pair_terms<ORTHO>(bx, alpha, do_es, at.xyzq[si], pj_old, sig, eps, f, -1.0, e_lj, e_re, n_lj, n_es);
 		}
 	}
@@ -72,24 +104,24 @@ __global__ __launch_bounds__(64) void k_delta_pairs(AtomsDev at, Box bx, double 
 	n_lj = wave_sum_i(n_lj);
 	n_es = wave_sum_i(n_es);
 	if (threadIdx.x == 0) {
-		block_part[2 * (size_t)blockIdx.x] = e_lj;
-		block_part[2 * (size_t)blockIdx.x + 1] = e_re;
-		block_cnt[2 * (size_t)blockIdx.x] = n_lj;
-		block_cnt[2 * (size_t)blockIdx.x + 1] = n_es;
+		block_part[2 * (size_t)tile] = e_lj;
+		block_part[2 * (size_t)tile + 1] = e_re;
+		block_cnt[2 * (size_t)tile] = n_lj;
+		block_cnt[2 * (size_t)tile + 1] = n_es;
 	}
 }
 
 // change of the intramolecular charge-to-screen sum (coulombic_real :1503-1504) for the moved atoms: one block.
-// orig_of_mv[k]: original index of moved atom k; molecules are contiguous runs of the original order.
-__global__ __launch_bounds__(64) void k_delta_intra(AtomsDev at, const int *__restrict__ slot_of, double alpha, const int *__restrict__ orig_of_mv,
-                                                    const double4 *__restrict__ mv_new, int m, const int *__restrict__ moved_idx,
-                                                    double *__restrict__ out) {
+// mv.orig(k): original index of moved atom k; molecules are contiguous runs of the original order.
+template <class MV>
+__device__ __forceinline__ void delta_intra_block(const AtomsDev &at, const int *__restrict__ slot_of, double alpha, const MV &mv, int m,
+                                                  const int *__restrict__ moved_idx, double *__restrict__ out) {
 	double acc = 0;
 	for (int k = threadIdx.x; k < m; k += 64) {
-		const int i = orig_of_mv[k];
+		const int i = mv.orig(k);
 		const int si = slot_of[i];
 		const int2 mi = at.mf[si];
-		const double4 pi_old = at.xyzq[si], pi_new = mv_new[k];
+		const double4 pi_old = at.xyzq[si], pi_new = mv.nw(k);
 		// walk the molecule of atom i in both directions of the original order
 		for (int dir = -1; dir <= 1; dir += 2)
 			for (int jo = i + dir; jo >= 0 && jo < at.n; jo += dir) {
@@ -100,11 +132,11 @@ __global__ __launch_bounds__(64) void k_delta_intra(AtomsDev at, const int *__re
 				if (moved_idx) kj = moved_idx[sj];
 				else
 					for (int q = 0; q < m; ++q)
-						if (orig_of_mv[q] == jo) kj = q;
+						if (mv.orig(q) == jo) kj = q;
 				if (kj >= 0 && kj < k) continue; // a moved-moved pair is counted once, from its lower list index
 				if (mi.y & mj.y & AF_FROZEN) continue;
 				const double4 pj_old = at.xyzq[sj];
-				const double4 pj_new = (kj >= 0) ? mv_new[kj] : pj_old;
+				const double4 pj_new = (kj >= 0) ? mv.nw(kj) : pj_old;
 				const double qq = pi_old.w * pj_old.w;
 				if (qq == 0.0) continue;
 				for (int pass = 0; pass < 2; ++pass) {
@@ -123,14 +155,14 @@ __global__ __launch_bounds__(64) void k_delta_intra(AtomsDev at, const int *__re
 }
 
 // trial structure factors: sf_trial[k] = sf[k] + sum_moved q (e^{i k.r_new} - e^{i k.r_old}); one wave per k-vector
-__global__ __launch_bounds__(64) void k_delta_recip(AtomsDev at, RecipDev rc, const int *__restrict__ mv_slot, const double4 *__restrict__ mv_new, int m,
-                                                    double4 *__restrict__ sf_trial) {
-	const double4 kv = rc.kvec[blockIdx.x];
+template <class MV>
+__device__ __forceinline__ void delta_recip_k(const AtomsDev &at, const RecipDev &rc, const MV &mv, int m, double4 *__restrict__ sf_trial, int kidx) {
+	const double4 kv = rc.kvec[kidx];
 	double re = 0, im = 0, C = 0, S = 0;
 	for (int k = threadIdx.x; k < m; k += 64) {
-		const int si = mv_slot[k];
+		const int si = mv.slot(k);
 		const int fl = at.mf[si].y;
-		const double4 po = at.xyzq[si], pn = mv_new[k];
+		const double4 po = at.xyzq[si], pn = mv.nw(k);
 		double s0, c0, s1, c1;
 		sincos(((kv.x * po.x) + kv.y * po.y) + kv.z * po.z, &s0, &c0);
 		sincos(((kv.x * pn.x) + kv.y * pn.y) + kv.z * pn.z, &s1, &c1);
@@ -147,9 +179,22 @@ __global__ __launch_bounds__(64) void k_delta_recip(AtomsDev at, RecipDev rc, co
 	C = wave_sum(C);
 	S = wave_sum(S);
 	if (threadIdx.x == 0) {
-		const double4 o = rc.sf[blockIdx.x];
-		sf_trial[blockIdx.x] = make_double4(o.x + re, o.y + im, o.z + C, o.w + S);
+		const double4 o = rc.sf[kidx];
+		sf_trial[kidx] = make_double4(o.x + re, o.y + im, o.z + C, o.w + S);
 	}
+}
+
+// ONE launch for the three parts of a trial that do not depend on one another (they were three): blocks [0, nt) the pair terms of one
+// tile each, block nt the intramolecular term, blocks (nt, nt + 1 + K) one k-vector each.  Without electrostatics the grid is nt.
+template <bool ORTHO, class MV>
+__global__ __launch_bounds__(64) void k_delta_all(AtomsDev at, Box bx, RecipDev rc, const int *__restrict__ slot_of, double alpha, int do_es, MV mv, int m,
+                                                  const int *__restrict__ moved_idx, double4 *__restrict__ sf_trial, double *__restrict__ block_part,
+                                                  int *__restrict__ block_cnt, double *__restrict__ out_intra) {
+	const int nt = at.n_pad / kTile;
+	const int b = blockIdx.x; // (block-uniform roles)
+	if (b < nt) delta_pairs_tile<ORTHO>(at, bx, alpha, do_es, mv, m, moved_idx, block_part, block_cnt, b);
+	else if (b == nt) delta_intra_block(at, slot_of, alpha, mv, m, moved_idx, out_intra);
+	else delta_recip_k(at, rc, mv, m, sf_trial, b - nt - 1);
 }
 
 // sums the per-tile partials, the reciprocal energy of the trial structure factors, into out[0..3] and counts
@@ -353,23 +398,44 @@ __global__ void k_commit_positions(double4 *__restrict__ xyzq, const int *__rest
 }
 void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc, double alpha, int do_es,
                   const int *mv_slot, const int *orig_of_mv, const double4 *mv_new, int m, int *moved_idx, double4 *sf_trial,
-                  double *block_part, int *block_cnt, double *out4, long long *dcnt2, double *host_out, double seq) {
+                  double *block_part, int *block_cnt, double *out4, long long *dcnt2, double *host_out, double seq, const MvInline *inl) {
 	const int nt = at.n_pad / kTile;
+	const int grid = do_es ? nt + 1 + rc.K : nt;
+	if (inl) { // the move travels in the kernel arguments (m <= kMvInline: the lists are scanned in the kernels, no map)
+		MvArg mv;
+		mv.d = *inl;
+		if (bx.ortho)
+			hipLaunchKernelGGL((k_delta_all<true, MvArg>), dim3(grid), dim3(kTile), 0, st, at, bx, rc, slot_of, alpha, do_es, mv, m, nullptr, sf_trial,
+			                   block_part, block_cnt, out4 + 2);
+		else
+			hipLaunchKernelGGL((k_delta_all<false, MvArg>), dim3(grid), dim3(kTile), 0, st, at, bx, rc, slot_of, alpha, do_es, mv, m, nullptr, sf_trial,
+			                   block_part, block_cnt, out4 + 2);
+		hipLaunchKernelGGL(k_delta_finish, dim3(1), dim3(256), 0, st, block_part, block_cnt, nt, rc, sf_trial, bx, do_es, out4, dcnt2, host_out, seq);
+		return;
+	}
 	const bool use_map = (m > 8); // short lists are scanned in the kernels; long ones go through the slot -> list-index map
 	if (use_map) hipLaunchKernelGGL(k_mark_moved, dim3((m + 63) / 64), dim3(64), 0, st, moved_idx, mv_slot, m, 1);
 	else moved_idx = nullptr;
+	const MvDev mv{mv_slot, orig_of_mv, mv_new};
 	if (bx.ortho)
-		hipLaunchKernelGGL(k_delta_pairs<true>, dim3(nt), dim3(kTile), 0, st, at, bx, alpha, do_es, mv_slot, mv_new, m, moved_idx, block_part, block_cnt);
+		hipLaunchKernelGGL((k_delta_all<true, MvDev>), dim3(grid), dim3(kTile), 0, st, at, bx, rc, slot_of, alpha, do_es, mv, m, moved_idx, sf_trial,
+		                   block_part, block_cnt, out4 + 2);
 	else
-		hipLaunchKernelGGL(k_delta_pairs<false>, dim3(nt), dim3(kTile), 0, st, at, bx, alpha, do_es, mv_slot, mv_new, m, moved_idx, block_part, block_cnt);
-	if (do_es) {
-		hipLaunchKernelGGL(k_delta_intra, dim3(1), dim3(64), 0, st, at, slot_of, alpha, orig_of_mv, mv_new, m, moved_idx, out4 + 2);
-		if (rc.K > 0) hipLaunchKernelGGL(k_delta_recip, dim3(rc.K), dim3(64), 0, st, at, rc, mv_slot, mv_new, m, sf_trial);
-	}
+		hipLaunchKernelGGL((k_delta_all<false, MvDev>), dim3(grid), dim3(kTile), 0, st, at, bx, rc, slot_of, alpha, do_es, mv, m, moved_idx, sf_trial,
+		                   block_part, block_cnt, out4 + 2);
 	hipLaunchKernelGGL(k_delta_finish, dim3(1), dim3(256), 0, st, block_part, block_cnt, nt, rc, sf_trial, bx, do_es, out4, dcnt2, host_out, seq);
 	if (use_map) hipLaunchKernelGGL(k_mark_moved, dim3((m + 63) / 64), dim3(64), 0, st, moved_idx, mv_slot, m, 0);
 }
-
+// accept, the move in the kernel arguments
+__global__ void k_commit_positions_arg(double4 *__restrict__ xyzq, MvArg mv, int m) {
+	const int k = threadIdx.x;
+	if (k < m) xyzq[mv.slot(k)] = mv.nw(k);
+}
+void launch_commit_positions_inline(hipStream_t st, double4 *xyzq, const MvInline &inl, int m) {
+	MvArg mv;
+	mv.d = inl;
+	hipLaunchKernelGGL(k_commit_positions_arg, dim3(1), dim3(64), 0, st, xyzq, mv, m);
+}
 void launch_commit_positions(hipStream_t st, double4 *xyzq, const int *mv_slot, const double4 *mv_new, int m) {
 	hipLaunchKernelGGL(k_commit_positions, dim3((m + 63) / 64), dim3(64), 0, st, xyzq, mv_slot, mv_new, m);
 }

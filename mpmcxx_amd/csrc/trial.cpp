@@ -86,7 +86,23 @@ extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
 	if (rc != MPMC_OK) return rc;
 	if ((rc = ensure_trial_buffers(c)) != MPMC_OK) return rc;
 	hipStream_t st = c->stream;
-	{ // one pinned staging record, one host-to-device copy
+	// short moves of non-polarizable boxes travel in the kernel arguments: no staging copy (a trial is launch-bound on the host: every
+	// call saved is ~5 us of a ~25 us move).  The polarizable path keeps the device lists (its field / store kernels read them).
+	static const bool no_inline = [] { const char *e = std::getenv("MPMC_NO_INLINE_MOVE"); return e && e[0] == '1'; }();
+	c->trial_inline = !polar_delta && m <= kMvInline && !no_inline;
+	if (c->trial_inline) {
+		for (int t = 0; t < m; t++) {
+			const int i = c->trial_first + t;
+			c->mv_inline.orig[t] = i;
+			c->mv_inline.slot[t] = c->slot_of[i];
+			for (int d = 0; d < 3; d++) c->mv_inline.nw[t][d] = c->trial_new[3 * t + d];
+			c->mv_inline.nw[t][3] = c->h_q[i];
+		}
+		for (int t = m; t < kMvInline; t++) { // (unused entries: defined values, never selected)
+			c->mv_inline.orig[t] = c->mv_inline.slot[t] = 0;
+			for (int d = 0; d < 4; d++) c->mv_inline.nw[t][d] = 0.0;
+		}
+	} else { // one pinned staging record, one host-to-device copy
 		double4 *nw = reinterpret_cast<double4 *>(c->h_mv_blob);
 		int *slots = reinterpret_cast<int *>(c->h_mv_blob + MPMC_TRIAL_MAX_ATOMS * sizeof(double4));
 		int *origs = slots + MPMC_TRIAL_MAX_ATOMS;
@@ -103,7 +119,7 @@ extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
 		ProfScope p(c, MPMC_K_PAIR);
 		launch_delta(st, atoms_view(c), c->d_slot_of, c->box, recip_view(c), c->ewald_alpha, do_es, c->d_mv_slot, c->d_mv_orig, c->d_mv_new, m,
 		             c->d_moved_idx, c->d_sf_trial, c->d_block_part, c->d_block_cnt, c->d_delta_out, c->d_delta_cnt, c->h_delta_out,
-		             (c->trial_seq += 1.0));
+		             (c->trial_seq += 1.0), c->trial_inline ? &c->mv_inline : nullptr);
 	}
 	HIP_TRY(c, hipGetLastError()); // (k_delta_finish posts the result into h_delta_out itself)
 	c->trial_was_full = false;
@@ -249,7 +265,8 @@ extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
 			std::swap(c->d_e_real, c->d_e_real_trial);
 			c->store_dirty_tiles.clear(); // ... and so is the store
 		} else {
-			launch_commit_positions(c->stream, c->d_xyzq, c->d_mv_slot, c->d_mv_new, m);
+			if (c->trial_inline) launch_commit_positions_inline(c->stream, c->d_xyzq, c->mv_inline, m);
+			else launch_commit_positions(c->stream, c->d_xyzq, c->d_mv_slot, c->d_mv_new, m);
 		}
 		HIP_TRY(c, hipGetLastError());
 		std::swap(c->d_sf, c->d_sf_trial); // the trial structure factors become the accepted ones

@@ -47,13 +47,18 @@ pqr_input box.pqr
 build.build_library()
 exe = os.path.join(wd, "pimc_nvt")
 libdir = os.path.join(ROOT, "mpmcxx_amd")
-subprocess.check_call(["g++", "-std=c++14", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "pimc_nvt.cpp"), "-L", libdir,
+GPROF = os.environ.get("PIMC_BENCH_GPROF") == "1"  # host profile of the driver itself (library and HIP runtime time is not attributed)
+subprocess.check_call(["g++", "-std=c++14", "-O2"] + (["-pg", "-fno-inline-small-functions", "-fno-inline-functions"] if GPROF else []) + ["-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "pimc_nvt.cpp"), "-L", libdir,
                        "-lmpmc_energy", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
 res = {}
 for mode in ("full", "trial"):
     out = os.path.join(wd, mode)
     os.makedirs(out)
-    p = subprocess.run([exe, os.path.join(wd, "pi.in"), "-P", str(P), "-o", out] + (["--trial"] if mode == "trial" else []), stdout=subprocess.PIPE, text=True, check=True)
+    p = subprocess.run([exe, os.path.join(wd, "pi.in"), "-P", str(P), "-o", out] + (["--trial"] if mode == "trial" else []), stdout=subprocess.PIPE, text=True, check=True, cwd=out)
+    if GPROF and os.path.exists(os.path.join(out, "gmon.out")):
+        g = subprocess.run(["gprof", "-b", "-p", exe, os.path.join(out, "gmon.out")], stdout=subprocess.PIPE, text=True).stdout
+        print(f"--- gprof flat profile, mode {mode} (first 14 rows)")
+        print("\n".join(g.splitlines()[:19]))
     res[mode] = json.loads(p.stdout.strip().splitlines()[-1])
     res[mode]["rows"] = [ln.split() for ln in open(os.path.join(out, "pibox.energy.dat")) if not ln.startswith("#")]
 worst = 0.0
