@@ -204,6 +204,9 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	                c->d_sf_trial, c->d_delta_out, c->d_e_real, c->d_e_real_trial, c->d_dk_part};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
+	if (c->h_stage) (void)hipHostFree(c->h_stage);
+	if (c->static_cnt) (void)hipHostFree(c->static_cnt);
+	if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
 	if (c->h_scal) (void)hipHostFree(c->h_scal);
 	if (c->h_flag) (void)hipHostFree(c->h_flag);
 	if (c->h_delta_out) (void)hipHostFree(c->h_delta_out);
@@ -248,6 +251,7 @@ extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *re
 	c->box_in_has_recip = (reciprocal != nullptr);
 	c->k_dirty = true;
 	c->static_dirty = true;
+	c->static_gen++;
 	c->atoms_dirty = true; // the spatial order depends on the cell
 	c->cache_valid = false;
 	return MPMC_OK;
@@ -287,6 +291,7 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 	c->opts_set = true;
 	c->k_dirty = true;
 	c->static_dirty = true;
+	c->static_gen++;
 	c->cache_valid = false;
 	return MPMC_OK;
 }
@@ -346,12 +351,27 @@ static void compute_spatial_order(mpmc_ctx *c) {
 int mpmc::upload_atoms(mpmc_ctx *c) {
 	compute_spatial_order(c);
 	const int n = c->n, np = c->n_pad;
-	std::vector<double4> xyzq(np);
-	std::vector<double2> lj(np);
-	std::vector<int2> mf(np);
-	std::vector<double> al(np, 0.0), ep(np, 0.0), imm(np, 0.0);
-	std::vector<int32_t> perm(np, -1), slot(np, -1);
-	std::vector<double> molmass(n, 0.0); // Molecule::mass = sum of its atoms' masses (System.cpp:687), per atom
+	// One persistent pinned staging block for all per-atom arrays: the copies below are asynchronous for real (from pageable vectors
+	// every one of them was a staged, blocking copy, and a stream synchronisation kept the vectors alive) -- an insertion or removal
+	// (uVT, Gibbs) pays for a sort and eight enqueues here, nothing else.
+	const size_t P = (size_t)c->max_pad;
+	if (!c->h_stage) {
+		HIP_TRY(c, hipHostMalloc((void **)&c->h_stage, P * (sizeof(double4) + sizeof(double2) + sizeof(int2) + 3 * sizeof(double) + 2 * sizeof(int32_t))));
+		HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
+		HIP_TRY(c, hipHostMalloc((void **)&c->static_cnt, 4 * sizeof(long long)));
+		for (int k = 0; k < 4; k++) c->static_cnt[k] = 0;
+	}
+	if (c->stage_in_flight) { // (an upload per evaluation at most, and evaluations are waited for: normally long done)
+		HIP_TRY(c, hipEventSynchronize(c->ev_stage));
+		c->stage_in_flight = false;
+	}
+	double4 *xyzq = reinterpret_cast<double4 *>(c->h_stage);
+	double2 *lj = reinterpret_cast<double2 *>(xyzq + P);
+	int2 *mf = reinterpret_cast<int2 *>(lj + P);
+	double *al = reinterpret_cast<double *>(mf + P), *ep = al + P, *imm = ep + P;
+	int32_t *perm = reinterpret_cast<int32_t *>(imm + P), *slot = perm + P;
+	c->molmass_tmp.assign(n, 0.0); // Molecule::mass = sum of its atoms' masses (System.cpp:687), per atom
+	std::vector<double> &molmass = c->molmass_tmp;
 	if (!c->h_mass.empty())
 		for (int i0 = 0; i0 < n;) {
 			int i1 = i0;
@@ -360,6 +380,7 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 			for (int i = i0; i < i1; i++) molmass[i] = m;
 			i0 = i1;
 		}
+	for (int k = 0; k < np; k++) slot[k] = -1;
 	for (int k = 0; k < np; k++) {
 		if (k < n) {
 			const int i = c->perm[k];
@@ -380,20 +401,25 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 			ep[k] = c->h_eps[i];
 			imm[k] = (molmass[i] > 0.0) ? 1.0 / molmass[i] : 0.0;
 		} else {
+			perm[k] = -1;
+			al[k] = ep[k] = imm[k] = 0.0;
 			xyzq[k] = make_double4(0, 0, 0, 0);
 			lj[k] = make_double2(0, 0);
 			mf[k] = make_int2(-1 - k, AF_PAD | AF_FROZEN | AF_NULL_RD | AF_ZERO_SIGMA | AF_ZERO_Q | AF_ZERO_ALPHA);
 		}
 	}
-	HIP_TRY(c, hipMemcpyAsync(c->d_xyzq, xyzq.data(), np * sizeof(double4), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_lj, lj.data(), np * sizeof(double2), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_mf, mf.data(), np * sizeof(int2), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_alpha, al.data(), np * sizeof(double), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_eps, ep.data(), np * sizeof(double), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_inv_molmass, imm.data(), np * sizeof(double), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_perm, perm.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_slot_of, slot.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-	// position-independent pair-flag counts (diagnostics of pair_exclusions), once per upload
+	HIP_TRY(c, hipMemcpyAsync(c->d_xyzq, xyzq, np * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_lj, lj, np * sizeof(double2), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_mf, mf, np * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_alpha, al, np * sizeof(double), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_eps, ep, np * sizeof(double), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_inv_molmass, imm, np * sizeof(double), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_perm, perm, np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_slot_of, slot, np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipEventRecord(c->ev_stage, c->stream));
+	c->stage_in_flight = true;
+	// position-independent pair-flag counts (diagnostics of pair_exclusions), once per upload; they arrive in pinned memory in front of
+	// the evaluation that follows on this stream, and are read when that evaluation has been waited for
 	{
 		AtomsDev at;
 		at.xyzq = c->d_xyzq;
@@ -405,12 +431,12 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 		at.n = c->n;
 		at.n_pad = c->n_pad;
 		launch_static_counts(c->stream, at, c->d_tile_pairs, c->n_tile_pairs, c->d_block_cnt, c->d_cnt);
+		c->scal_clean = false; // (d_cnt is part of the scalar block: the next evaluation clears it instead of trusting which kernel overwrites what)
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipMemcpyAsync(c->static_cnt, c->d_cnt, 4 * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
 	}
-	HIP_TRY(c, hipStreamSynchronize(c->stream)); // staging vectors die here
-	c->h_xyzq.swap(xyzq);          // slot-ordered mirror for bulk position updates
-	c->h_pos_sorted = c->h_pos;    // where every atom stood when this order was made
+	c->h_xyzq.assign(xyzq, xyzq + np); // slot-ordered mirror for bulk position updates
+	c->h_pos_sorted = c->h_pos;        // where every atom stood when this order was made
 	c->atoms_dirty = false;
 	return MPMC_OK;
 }
@@ -493,6 +519,7 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 	int rc = MPMC_OK;
 	c->atoms_dirty = true; // uploaded (in spatial order) by the next evaluation, when the box is known too
 	c->static_dirty = true;
+	c->static_gen++;
 
 	// upper-triangular tile-pair schedule of the pair kernel
 	const int nt = c->n_tiles;

@@ -92,7 +92,16 @@ struct mpmc_ctx {
 	int cap_solve_args = 0;
 	int last_batch = 1;                 // systems per launch in the last evaluation's solve
 	size_t cap_tile_pairs = 0;
-	long long static_cnt[4] = {0, 0, 0, 0}; // n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent)
+	std::vector<double> molmass_tmp; // (scratch of upload_atoms)
+	long long *static_cnt = nullptr; // pinned [4]: n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent; copied back behind every upload of the atoms)
+	// upload_atoms stages every per-atom array in ONE persistent pinned block (eight truly asynchronous copies, no synchronisation);
+	// ev_stage marks the copies done, the next upload waits for it before it refills the block
+	char *h_stage = nullptr;
+	hipEvent_t ev_stage = nullptr;
+	bool stage_in_flight = false;
+	// the position-independent terms (LRC, Ewald self) ride along with the next general evaluation when they are stale: static_gen
+	// counts the events that make them stale, static_ride_gen is the count the pending evaluation's ride-along belongs to (0: none)
+	unsigned static_gen = 1, static_ride_gen = 0;
 
 	// position-independent scalars (pair LRC, self LRC, Ewald self term): functions of the atom parameters, the cell and the options
 	// only -- computed once (k_atom_terms) whenever one of those changed, kept on the host, added when a result is assembled
@@ -284,7 +293,7 @@ enum : unsigned {
 	RUN_PAIR = 1, RUN_PAIR_ES = 2, RUN_RECIP = 4, RUN_ATOMTERMS = 8, RUN_FIELD = 16, RUN_SOLVE = 32, RUN_WOLF = 64,
 	RUN_STORE = 128 // tile classes + the Thole tensor store alone (no energies, no field): trial moves of polarizable boxes
 };
-int prepare(mpmc_ctx *c);                        // uploads what is dirty, (re)builds the k tables, resolves the solver (evaluate.cpp)
+int prepare(mpmc_ctx *c, bool defer_static = false); // uploads what is dirty, (re)builds the k tables; the position-independent terms unless deferred (evaluate.cpp)
 int enqueue(mpmc_ctx *c, unsigned mask);         // one evaluation (the pieces in `mask`) on the context's streams (evaluate.cpp)
 int wait_and_fill(mpmc_ctx *c, mpmc_result *out); // waits for it and assembles the result (evaluate.cpp)
 unsigned full_mask(const mpmc_ctx *c);           // what double System::energy() runs under the current options

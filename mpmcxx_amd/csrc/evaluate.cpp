@@ -136,7 +136,7 @@ static int resolve_solver(mpmc_ctx *c) {
 }
 
 // resolve alpha defaults, rebuild k tables when box/options changed
-int mpmc::prepare(mpmc_ctx *c) {
+int mpmc::prepare(mpmc_ctx *c, bool defer_static) {
 	if (!c->box_set) return fail(c, MPMC_ERR_BOX, "energy: no box set (mpmc_set_box)");
 	if (!c->atoms_set) return fail(c, MPMC_ERR_INVALID_DATUM, "energy: no atoms set (mpmc_set_atoms)");
 	HIP_TRY(c, hipSetDevice(c->device));
@@ -154,10 +154,11 @@ int mpmc::prepare(mpmc_ctx *c) {
 		if (rc != MPMC_OK) return rc;
 		c->k_dirty = false;
 	}
-	if (c->static_dirty) { // pair LRC (O(N) moment form), self LRC, Ewald self term: position independent (lj_lrc_corr / lj_lrc_self :1036-1096, coulombic_self :1626-1643)
-		// (the kernel ADDS into its three slots: they start from zero here whatever came before, and the block counts as used afterwards)
-		HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (S_COUNT + C_COUNT) * sizeof(double), c->stream));
-		c->scal_clean = false;
+	// pair LRC (O(N) moment form), self LRC, Ewald self term: position independent (lj_lrc_corr / lj_lrc_self :1036-1096, coulombic_self
+	// :1626-1643), cached in h_static.  A general evaluation takes them along when they are stale (defer_static: enqueue() launches the
+	// kernel behind its clear of the scalar block and wait_and_fill adopts the three values); everybody else gets them here and now.
+	if (c->static_dirty && !defer_static) {
+		c->scal_clean = false; // (the kernel writes its slots of the scalar block: the next evaluation clears the block first)
 		launch_atom_terms(c->stream, atoms_view(c), recip_view(c), c->box, c->ewald_alpha, c->opts.rd_lrc, /*self term*/ 2, c->d_scal);
 		HIP_TRY(c, hipGetLastError());
 		double tmp[S_COUNT];
@@ -197,8 +198,13 @@ RecipDev mpmc::recip_view(const mpmc_ctx *c) {
 // which pieces of energy() to run
 
 int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
-	int rc = prepare(c);
+	// stale position-independent terms ride along with this evaluation (an insertion / removal makes them stale every time) -- unless
+	// the solve is deferred to the lockstep driver of pi.cpp, which reads the scalar block back itself
+	const bool may_ride = !c->defer_solve;
+	int rc = prepare(c, may_ride);
 	if (rc != MPMC_OK) return rc;
+	const bool static_ride = c->static_dirty; // (only possible with may_ride)
+	c->static_ride_gen = 0;
 	const AtomsDev at = atoms_view(c);
 	const RecipDev rcp = recip_view(c);
 	const mpmc_options &o = c->opts;
@@ -210,7 +216,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 
 	c->last_was_single = false;
 	c->spin_on_post = false;
-	if (c->single_launch && mask == (RUN_PAIR | RUN_ATOMTERMS) && !o.feynman_hibbs && c->n_tiles <= kSingleLaunchTiles && !c->prof) {
+	if (c->single_launch && mask == (RUN_PAIR | RUN_ATOMTERMS) && !o.feynman_hibbs && c->n_tiles <= kSingleLaunchTiles && !c->prof && !static_ride) {
 		// small LJ box (BASELINE configs[1]): the whole evaluation is one launch -- pair sweep without classes, the block that finishes last
 		// folds the partials into the pinned result vector; the LRC terms are the cached position-independent ones
 		FusedParams fp{};
@@ -227,6 +233,11 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	// (the static-terms pass, the lockstep path of pi.cpp, an evaluation that failed half way)
 	if (!c->scal_clean) HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (S_COUNT + C_COUNT) * sizeof(double), st));
 	c->scal_clean = false;
+	if (static_ride) { // first thing on the main stream: its slots are nobody else's (S_LRC_PAIR, S_LRC_SELF, S_ES_SELF)
+		launch_atom_terms(st, at, rcp, c->box, c->ewald_alpha, o.rd_lrc, /*self term*/ 2, c->d_scal);
+		HIP_TRY(c, hipGetLastError());
+		c->static_ride_gen = c->static_gen;
+	}
 
 	if (mask & (RUN_FIELD | RUN_SOLVE | RUN_STORE)) {
 		if ((rc = ensure_polar_buffers(c)) != MPMC_OK) return rc;
@@ -558,6 +569,15 @@ int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 	if (!out) return MPMC_OK;
 	std::memset(out, 0, sizeof(*out));
 	const double *s = c->h_scal;
+	if (c->static_ride_gen) { // the position-independent terms came along: adopt them, unless something made them stale again meanwhile
+		if (c->static_ride_gen == c->static_gen) {
+			c->h_static[0] = s[S_LRC_PAIR];
+			c->h_static[1] = s[S_LRC_SELF];
+			c->h_static[2] = s[S_ES_SELF];
+			c->static_dirty = false;
+		}
+		c->static_ride_gen = 0;
+	}
 	const bool lrc = (c->run_mask & RUN_ATOMTERMS) && c->opts.rd_lrc;
 	out->lj_pairs = s[S_LJ];
 	out->lrc_pair = lrc ? c->h_static[0] : 0.0;

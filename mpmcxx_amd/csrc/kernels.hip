@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_atom_terms(AtomsDev at, RecipDev rc, Bo
 		const double p12 = (0.5 * (s12 - d12) - 0.5 * (f12 - df12)) / 4096.0; // sum_{pairs} eps_ij sig_ij^12
 		const double rc3 = bx.cutoff * bx.cutoff * bx.cutoff, rc9 = rc3 * rc3 * rc3;
 		scal[S_LRC_PAIR] = rd_lrc ? (16.0 / 3.0) * kPi * (p12 / (3.0 * rc9) - p6 / rc3) / bx.volume : 0.0;
-		scal[S_ES_RECIP] = e * (4.0 * kPi / bx.volume);
+		if (do_es != 2) scal[S_ES_RECIP] = e * (4.0 * kPi / bx.volume); // (the self-terms call leaves the reciprocal energy's slot alone)
 		scal[S_ES_SELF] = self;
 		scal[S_LRC_SELF] = lrc;
 	}

@@ -153,3 +153,31 @@ def test_molecule_flag_is_the_last_atom_row():
     assert movable[0] == 1 and movable[1] == 0
     assert S.observables["N"] == float(np.count_nonzero(movable))
     S.close()
+
+
+def test_counts_after_a_drift_resort_without_electrostatics(monkeypatch):
+    """Guard of an invariant, not of a bug that was seen: an atom that drifts more than the re-sort threshold makes the next evaluation
+    upload the atoms in a new spatial order, and that upload leaves the position-independent pair counts in the device's count block,
+    which the evaluation no longer clears as a matter of course (the kernel that posts the results leaves it zeroed).  The counts and
+    the energy after such a re-sort must equal those of a fresh context -- here on the general path of a box without electrostatics,
+    where the in-cutoff count of coulombic_real is a slot only the final reduction of the pair sweep writes."""
+    atoms, basis, opts = util.load_fixture("water64_polar")
+    opts = dict(opts, polarization=0, polar_iterative=0, polar_ewald=0, rd_only=1)
+    monkeypatch.setenv("MPMC_NO_SINGLE_LAUNCH", "1")  # the general path (the one-launch form of small LJ boxes bypasses the block)
+    S = energy.System(atoms, basis, opts)
+    S.energy()
+    assert S.observables["n_rd_excluded"] > 0 and S.observables["n_es_in_cutoff"] == 0
+    ids = atoms["mol_id"]
+    b = int(np.nonzero(ids != ids[0])[0][0])
+    pos = atoms["pos"].copy()
+    pos[:b] += np.array([3.0, 0.5, -0.25])  # further than the 2 A re-sort drift
+    S.update_positions(0, pos[:b])
+    e = S.energy()
+    F = energy.System(dict(atoms, pos=pos), basis, opts)
+    ef = F.energy()
+    for k in ("n_es_in_cutoff", "n_lj_in_cutoff", "n_rd_excluded", "n_es_excluded", "n_intra", "n_frozen"):
+        assert S.observables[k] == F.observables[k], k
+    assert S.observables["n_es_in_cutoff"] == 0
+    assert abs(e - ef) <= 1e-12 * abs(ef)
+    S.close()
+    F.close()

@@ -42,6 +42,28 @@ name = sys.argv[1] if len(sys.argv) > 1 else "ion216_polar"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 atoms, basis, opts = util.load_fixture(name)
 S = energy.System(atoms, basis, opts)
+if len(sys.argv) > 3 and sys.argv[3] == "resize":  # us per N-changing move (uVT / Gibbs insert or remove): set_atoms + full evaluation
+    import numpy as np
+
+    ids = atoms["mol_id"]
+    last = int(np.nonzero(ids == ids[-1])[0][0])
+    fewer = {k: (v[:last].copy() if isinstance(v, np.ndarray) and len(v) == len(ids) else v) for k, v in atoms.items()}
+    S.energy()
+    t_set = t_en = 0.0
+    for it in range(n + 10):
+        if it == 10:
+            t_set = t_en = 0.0
+        a = fewer if it % 2 == 0 else atoms
+        t0 = time.perf_counter()
+        S.set_atoms(a)
+        t1 = time.perf_counter()
+        S.energy()
+        t2 = time.perf_counter()
+        t_set += t1 - t0
+        t_en += t2 - t1
+    print(f"{name}: {len(ids)} atoms, remove / insert the last molecule ({len(ids) - last} atoms): set_atoms {t_set / n * 1e6:.1f} us + energy {t_en / n * 1e6:.1f} us (python loop)")
+    S.close()
+    sys.exit(0)
 if len(sys.argv) > 3 and sys.argv[3] == "trial":  # us per trial move: trial_energy + reject, and trial_energy + accept
     import numpy as np
 
