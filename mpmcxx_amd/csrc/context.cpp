@@ -155,15 +155,12 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	if (const char *e = std::getenv("MPMC_PAIR_WAVES")) c->pair_waves = (std::atoi(e) == 4) ? 4 : (std::atoi(e) == 1 ? 1 : 0);
 	if (const char *e = std::getenv("MPMC_NO_RECIP_TAB")) c->no_recip_tab = (e[0] == '1');
 	const size_t P = (size_t)c->max_pad;
-	A(dev_alloc(c, &c->d_xyzq, P));
-	A(dev_alloc(c, &c->d_lj, P));
-	A(dev_alloc(c, &c->d_mf, P));
-	A(dev_alloc(c, &c->d_alpha, P));
-	A(dev_alloc(c, &c->d_eps, P));
-	A(dev_alloc(c, &c->d_inv_molmass, P));
+	A(dev_alloc(c, &c->d_atoms_blob, P * kAtomRecordBytes)); // every per-atom array, one block (layout: atom_block_layout)
+	if (rc == MPMC_OK)
+		atom_block_layout(c->d_atoms_blob, P, [c](double4 *xyzq, double2 *lj, int2 *mf, double *al, double *ep, double *imm, int32_t *perm, int32_t *slot) {
+			c->d_xyzq = xyzq, c->d_lj = lj, c->d_mf = mf, c->d_alpha = al, c->d_eps = ep, c->d_inv_molmass = imm, c->d_perm = perm, c->d_slot_of = slot;
+		});
 	A(dev_alloc(c, &c->d_tile_bounds, 12 * (P / kTile)));
-	A(dev_alloc(c, &c->d_slot_of, P));
-	A(dev_alloc(c, &c->d_perm, P));
 	A(dev_alloc(c, &c->d_scal, (size_t)S_COUNT + (size_t)C_COUNT)); // scalars and counts share one buffer: one clear, one read-back
 	if (rc == MPMC_OK) c->d_cnt = reinterpret_cast<long long *>(c->d_scal + S_COUNT);
 	A(dev_alloc(c, &c->d_flag, (size_t)4)); // [0]: Gauss-Seidel's per-sweep flag; [1..3]: iteration control of the precision-terminated Jacobi solve
@@ -198,9 +195,9 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	for (auto &e : c->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-	void *ptrs[] = {c->d_xyzq, c->d_lj, c->d_mf, c->d_alpha, c->d_eps, c->d_inv_molmass, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal,
+	void *ptrs[] = {c->d_atoms_blob, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal,
 	                c->d_flag, c->d_counter, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_slot_of, c->d_perm, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_panels, c->d_seg, c->d_gpart, c->d_trace, c->d_mv_blob, c->d_moved_idx,
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_panels, c->d_seg, c->d_gpart, c->d_trace, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out, c->d_e_real, c->d_e_real_trial, c->d_dk_part};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -253,6 +250,7 @@ extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *re
 	c->static_dirty = true;
 	c->static_gen++;
 	c->atoms_dirty = true; // the spatial order depends on the cell
+	c->atoms_dirty_order = true;
 	c->cache_valid = false;
 	return MPMC_OK;
 }
@@ -285,7 +283,7 @@ extern "C" int mpmc_set_options(mpmc_ctx *c, const mpmc_options *o) {
 	  // changes -- through polar_gs, polarization or rd_only, or on the first options after an upload under the defaults -- re-upload
 		auto atom_order = [](const mpmc_options &q) { return q.polar_gs && q.polarization && !q.rd_only; };
 		const bool was = c->opts_set && atom_order(c->opts);
-		if (was != (bool)atom_order(*o)) c->atoms_dirty = true;
+		if (was != (bool)atom_order(*o)) c->atoms_dirty = c->atoms_dirty_order = true;
 	}
 	c->opts = *o;
 	c->opts_set = true;
@@ -346,17 +344,60 @@ static void compute_spatial_order(mpmc_ctx *c) {
 		}
 	}
 	for (int k = 0; k < n; k++) c->slot_of[c->perm[k]] = k;
+	c->order_sorted = enable;
+	c->edits_since_sort = 0;
+}
+
+// set_atoms with a list that differs from the one before by ONE contiguous run of atoms (inserted or removed): positions before the run
+// and behind it are bitwise those of the old list.  Brings perm / slot_of up to date without sorting; false = not such an edit.
+static bool carry_spatial_order(mpmc_ctx *c, const double *new_pos, int n_new) {
+	const int n_old = (int)c->perm.size();
+	if (!c->order_sorted || c->atoms_dirty_order || n_old == 0 || (int)c->h_pos.size() != 3 * n_old) return false;
+	if (n_new <= 2 * kTile || n_new == n_old) return false; // (small systems keep the identity order; same size = not an insertion / removal)
+	const int diff = n_new - n_old, m = diff > 0 ? diff : -diff, lo = std::min(n_old, n_new);
+	if (m > kTile || c->edits_since_sort + m > kTile) return false; // time for a real sort
+	const double *old_pos = c->h_pos.data();
+	int p = 0;
+	while (p < lo && old_pos[3 * p] == new_pos[3 * p] && old_pos[3 * p + 1] == new_pos[3 * p + 1] && old_pos[3 * p + 2] == new_pos[3 * p + 2]) p++;
+	int s = 0;
+	while (s < lo - p && old_pos[3 * (n_old - 1 - s)] == new_pos[3 * (n_new - 1 - s)] && old_pos[3 * (n_old - 1 - s) + 1] == new_pos[3 * (n_new - 1 - s) + 1] &&
+	       old_pos[3 * (n_old - 1 - s) + 2] == new_pos[3 * (n_new - 1 - s) + 2])
+		s++;
+	if (p + s != lo) return false; // more than one run changed (or atoms moved as well): sort
+	std::vector<int32_t> np_;
+	np_.reserve(n_new);
+	for (int k = 0; k < n_old; k++) {
+		const int i = c->perm[k];
+		if (i < p) np_.push_back(i);
+		else if (i >= n_old - s) np_.push_back(i + diff);
+		// else: removed
+	}
+	for (int i = p; i < n_new - s; i++) np_.push_back(i); // inserted atoms: appended (the last tile loses some locality until the next sort)
+	if ((int)np_.size() != n_new) return false;
+	c->perm.swap(np_);
+	c->slot_of.assign(n_new, -1);
+	for (int k = 0; k < n_new; k++) c->slot_of[c->perm[k]] = k;
+	c->edits_since_sort += m;
+	return true;
 }
 
 int mpmc::upload_atoms(mpmc_ctx *c) {
-	compute_spatial_order(c);
+	static const bool no_carry = [] { const char *e = std::getenv("MPMC_NO_ORDER_CARRY"); return e && e[0] == '1'; }();
+	if (!c->order_carried || no_carry || (int)c->perm.size() != c->n) {
+		compute_spatial_order(c);
+		c->n_uploads_sorted++;
+	} else {
+		c->n_uploads_carried++;
+	}
+	c->order_carried = false;
+	c->atoms_dirty_order = false;
 	const int n = c->n, np = c->n_pad;
 	// One persistent pinned staging block for all per-atom arrays: the copies below are asynchronous for real (from pageable vectors
 	// every one of them was a staged, blocking copy, and a stream synchronisation kept the vectors alive) -- an insertion or removal
 	// (uVT, Gibbs) pays for a sort and eight enqueues here, nothing else.
 	const size_t P = (size_t)c->max_pad;
 	if (!c->h_stage) {
-		HIP_TRY(c, hipHostMalloc((void **)&c->h_stage, P * (sizeof(double4) + sizeof(double2) + sizeof(int2) + 3 * sizeof(double) + 2 * sizeof(int32_t))));
+		HIP_TRY(c, hipHostMalloc((void **)&c->h_stage, P * kAtomRecordBytes));
 		HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
 		HIP_TRY(c, hipHostMalloc((void **)&c->static_cnt, 4 * sizeof(long long)));
 		for (int k = 0; k < 4; k++) c->static_cnt[k] = 0;
@@ -365,11 +406,14 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 		HIP_TRY(c, hipEventSynchronize(c->ev_stage));
 		c->stage_in_flight = false;
 	}
-	double4 *xyzq = reinterpret_cast<double4 *>(c->h_stage);
-	double2 *lj = reinterpret_cast<double2 *>(xyzq + P);
-	int2 *mf = reinterpret_cast<int2 *>(lj + P);
-	double *al = reinterpret_cast<double *>(mf + P), *ep = al + P, *imm = ep + P;
-	int32_t *perm = reinterpret_cast<int32_t *>(imm + P), *slot = perm + P;
+	double4 *xyzq = nullptr;
+	double2 *lj = nullptr;
+	int2 *mf = nullptr;
+	double *al = nullptr, *ep = nullptr, *imm = nullptr;
+	int32_t *perm = nullptr, *slot = nullptr;
+	atom_block_layout(c->h_stage, P, [&](double4 *a0, double2 *a1, int2 *a2, double *a3, double *a4, double *a5, int32_t *a6, int32_t *a7) {
+		xyzq = a0, lj = a1, mf = a2, al = a3, ep = a4, imm = a5, perm = a6, slot = a7;
+	});
 	c->molmass_tmp.assign(n, 0.0); // Molecule::mass = sum of its atoms' masses (System.cpp:687), per atom
 	std::vector<double> &molmass = c->molmass_tmp;
 	if (!c->h_mass.empty())
@@ -408,14 +452,27 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 			mf[k] = make_int2(-1 - k, AF_PAD | AF_FROZEN | AF_NULL_RD | AF_ZERO_SIGMA | AF_ZERO_Q | AF_ZERO_ALPHA);
 		}
 	}
-	HIP_TRY(c, hipMemcpyAsync(c->d_xyzq, xyzq, np * sizeof(double4), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_lj, lj, np * sizeof(double2), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_mf, mf, np * sizeof(int2), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_alpha, al, np * sizeof(double), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_eps, ep, np * sizeof(double), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_inv_molmass, imm, np * sizeof(double), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_perm, perm, np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(c->d_slot_of, slot, np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+	// ONE copy: the device block has the layout of the staging block (the tails beyond n_pad travel along; nobody reads them)
+	if (np < (int)P && (size_t)np * 2 >= P)
+		for (size_t k = (size_t)np; k < P; k++) { // (the tails travel along with the single copy: defined values)
+			xyzq[k] = make_double4(0, 0, 0, 0);
+			lj[k] = make_double2(0, 0);
+			mf[k] = make_int2(-1 - (int)k, AF_PAD | AF_FROZEN | AF_NULL_RD | AF_ZERO_SIGMA | AF_ZERO_Q | AF_ZERO_ALPHA);
+			al[k] = ep[k] = imm[k] = 0.0;
+			perm[k] = slot[k] = -1;
+		}
+	if ((size_t)np * 2 >= P) {
+		HIP_TRY(c, hipMemcpyAsync(c->d_atoms_blob, c->h_stage, P * kAtomRecordBytes, hipMemcpyHostToDevice, c->stream));
+	} else { // a context created with much more room than atoms: the used prefix of every array instead of the whole block
+		HIP_TRY(c, hipMemcpyAsync(c->d_xyzq, xyzq, np * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_lj, lj, np * sizeof(double2), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_mf, mf, np * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_alpha, al, np * sizeof(double), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_eps, ep, np * sizeof(double), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_inv_molmass, imm, np * sizeof(double), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_perm, perm, np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_slot_of, slot, np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+	}
 	HIP_TRY(c, hipEventRecord(c->ev_stage, c->stream));
 	c->stage_in_flight = true;
 	// position-independent pair-flag counts (diagnostics of pair_exclusions), once per upload; they arrive in pinned memory in front of
@@ -461,6 +518,8 @@ static int grow_capacity(mpmc_ctx *c, int n) {
 	}
 	f->prof = c->prof;
 	f->tim = c->tim;
+	f->n_uploads_carried = c->n_uploads_carried; // (diagnostics survive the growth; the order itself does not: the new context sorts)
+	f->n_uploads_sorted = c->n_uploads_sorted;
 	std::swap(*c, *f);
 	mpmc_ctx_destroy(f); // now owns the old, smaller buffers
 	return MPMC_OK;
@@ -492,6 +551,8 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 	c->n = n;
 	c->n_pad = ((n + kTile - 1) / kTile) * kTile;
 	c->n_tiles = c->n_pad / kTile;
+	// (before the old positions go: is this the list of before with one run of atoms inserted or removed?  Then the spatial order is carried)
+	c->order_carried = carry_spatial_order(c, pos, n);
 	c->h_pos.assign(pos, pos + 3 * (size_t)n);
 	c->h_q.assign(charge, charge + n);
 	c->h_alpha.assign(polarizability, polarizability + n);
@@ -589,7 +650,7 @@ extern "C" int mpmc_update_positions(mpmc_ctx *c, int first, int count, const do
 			if (d2 > worst) worst = d2;
 		}
 		if (c->h_pos_sorted.empty() || !(worst <= kResortDrift * kResortDrift)) {
-			c->atoms_dirty = true;
+			c->atoms_dirty = c->atoms_dirty_order = true;
 			return MPMC_OK;
 		}
 		for (int t = 0; t < count; t++) {
@@ -672,6 +733,14 @@ extern "C" int mpmc_get_tile_stats(mpmc_ctx *c, int64_t out4[4]) {
 		if (v & CLS_BEYOND_CUTOFF) out4[3]++;
 	}
 	return MPMC_OK;
+}
+
+// diagnostics only (tests assert that the order was really carried): uploads of the atom list that kept the order / that sorted
+extern "C" int mpmc_debug_upload_counts(mpmc_ctx *c, long long *out2) {
+	if (!c || !out2) return -1;
+	out2[0] = c->n_uploads_carried;
+	out2[1] = c->n_uploads_sorted;
+	return 0;
 }
 
 // measurement only: per-workgroup time stamps of the last panel launch (tools/panel_trace.py); 0 entries unless MPMC_TRACE_PANEL=1

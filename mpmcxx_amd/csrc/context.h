@@ -55,6 +55,9 @@ struct mpmc_ctx {
 	bool atoms_dirty = true; // host mirror newer than the device arrays (full upload pending)
 
 	// device atom arrays
+	// the per-atom arrays below are pieces of ONE device block laid out like the pinned staging block of upload_atoms
+	// ([xyzq][lj][mf][alpha][eps][inv_molmass][perm][slot_of], each max_pad long): an upload of the atoms is one copy
+	char *d_atoms_blob = nullptr;
 	double4 *d_xyzq = nullptr;
 	double2 *d_lj = nullptr;
 	int2 *d_mf = nullptr;
@@ -79,6 +82,14 @@ struct mpmc_ctx {
 	bool panels_built = false;       // this evaluation's classes carry CLS_GROUPED bits and d_panels is valid
 	std::vector<double4> h_xyzq;     // host mirror of d_xyzq (slot order), for bulk position updates
 	std::vector<double> h_pos_sorted; // positions at the time of the last spatial sort
+	// The spatial order is a locality heuristic: ANY permutation gives the same physics (sums in another order).  A contiguous insertion
+	// or removal (uVT / Gibbs) therefore carries the order it finds -- the survivors keep their sequence, inserted atoms are appended --
+	// instead of paying an O(N log N) host sort per move; a real sort follows once kTile atoms have come or gone since the last one.
+	bool order_sorted = false;  // perm is a spatial sort of the current atom list (not the identity of small / Gauss-Seidel systems)
+	bool order_carried = false; // set_atoms has already brought perm / slot_of up to date: upload_atoms does not sort
+	bool atoms_dirty_order = false; // a NEW sort was asked for (cell, options, drift) and is pending: nothing is carried across it
+	long long n_uploads_carried = 0, n_uploads_sorted = 0; // (diagnostics: mpmc_debug_upload_counts)
+	int edits_since_sort = 0;   // atoms inserted + removed since the last real sort
 	double sort_origin_f[3] = {0, 0, 0}; // fractional coordinate at which the spatial sort cuts the periodic wrap
 	bool no_uniform = false;         // MPMC_NO_UNI=1
 	double thole_far_x = kTholeFarX; // lambda r beyond which a tile pair's tensors are not stored (MPMC_THOLE_FAR_X)
@@ -209,6 +220,19 @@ struct mpmc_ctx {
 
 namespace mpmc { // internal helpers: mangled names, nothing here can collide with a symbol of the host program
 
+constexpr size_t kAtomRecordBytes = sizeof(double4) + sizeof(double2) + sizeof(int2) + 3 * sizeof(double) + 2 * sizeof(int32_t); // per atom, all arrays of the block
+template <typename T>
+inline int dev_alloc(mpmc_ctx *c, T **p, size_t count);
+// carve the per-atom arrays out of a block of P records (device block and pinned staging block share the layout)
+template <typename F>
+inline void atom_block_layout(char *base, size_t P, F &&set) {
+	double4 *xyzq = reinterpret_cast<double4 *>(base);
+	double2 *lj = reinterpret_cast<double2 *>(xyzq + P);
+	int2 *mf = reinterpret_cast<int2 *>(lj + P);
+	double *al = reinterpret_cast<double *>(mf + P), *ep = al + P, *imm = ep + P;
+	int32_t *perm = reinterpret_cast<int32_t *>(imm + P), *slot = perm + P;
+	set(xyzq, lj, mf, al, ep, imm, perm, slot);
+}
 template <typename T>
 inline int dev_alloc(mpmc_ctx *c, T **p, size_t count) {
 	const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
