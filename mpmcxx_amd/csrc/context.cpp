@@ -202,6 +202,10 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (c->h_stage) (void)hipHostFree(c->h_stage);
+	if (c->h_xyzq) (void)hipHostFree(c->h_xyzq);
+	if (c->ev_xyzq) (void)hipEventDestroy(c->ev_xyzq);
+	if (c->h_kstage) (void)hipHostFree(c->h_kstage);
+	if (c->ev_kstage) (void)hipEventDestroy(c->ev_kstage);
 	if (c->static_cnt) (void)hipHostFree(c->static_cnt);
 	if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
 	if (c->h_scal) (void)hipHostFree(c->h_scal);
@@ -249,8 +253,9 @@ extern "C" int mpmc_set_box(mpmc_ctx *c, const double basis[9], const double *re
 	c->k_dirty = true;
 	c->static_dirty = true;
 	c->static_gen++;
-	c->atoms_dirty = true; // the spatial order depends on the cell
-	c->atoms_dirty_order = true;
+	// (No re-sort, no upload of the atoms: the spatial order is a locality heuristic and a new cell leaves it as good as the positions
+	// leave it -- a volume move scales both together; atoms that really wander are caught by the drift check of mpmc_update_positions.
+	// The fractional origin of the last sort stays valid too: it only says where the tile bounds cut the periodic wrap.)
 	c->cache_valid = false;
 	return MPMC_OK;
 }
@@ -398,6 +403,8 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 	const size_t P = (size_t)c->max_pad;
 	if (!c->h_stage) {
 		HIP_TRY(c, hipHostMalloc((void **)&c->h_stage, P * kAtomRecordBytes));
+		HIP_TRY(c, hipHostMalloc((void **)&c->h_xyzq, P * sizeof(double4)));
+		HIP_TRY(c, hipEventCreateWithFlags(&c->ev_xyzq, hipEventDisableTiming));
 		HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
 		HIP_TRY(c, hipHostMalloc((void **)&c->static_cnt, 4 * sizeof(long long)));
 		for (int k = 0; k < 4; k++) c->static_cnt[k] = 0;
@@ -492,7 +499,11 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipMemcpyAsync(c->static_cnt, c->d_cnt, 4 * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
 	}
-	c->h_xyzq.assign(xyzq, xyzq + np); // slot-ordered mirror for bulk position updates
+	{ // slot-ordered mirror for later position updates
+		const int rc_g = mirror_guard(c);
+		if (rc_g != MPMC_OK) return rc_g;
+		std::memcpy(c->h_xyzq, xyzq, (size_t)np * sizeof(double4));
+	}
 	c->h_pos_sorted = c->h_pos;        // where every atom stood when this order was made
 	c->atoms_dirty = false;
 	return MPMC_OK;
@@ -653,22 +664,28 @@ extern "C" int mpmc_update_positions(mpmc_ctx *c, int first, int count, const do
 			c->atoms_dirty = c->atoms_dirty_order = true;
 			return MPMC_OK;
 		}
+	}
+	// the atoms keep their slots; their new positions go through the pinned slot-ordered mirror: one asynchronous copy of the whole array
+	// (a handful of atoms: one small copy each), an event behind it.  No stream synchronisation: the next writer of the mirror waits
+	// for this copy (mirror_guard), nobody waits for the evaluations that may be queued in front of it.
+	{
+		const int rc_g = mirror_guard(c);
+		if (rc_g != MPMC_OK) return rc_g;
+	}
+	for (int t = 0; t < count; t++) {
+		const int i = first + t;
+		c->h_xyzq[c->slot_of[i]] = make_double4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], c->h_q[i]);
+	}
+	if (count > 4) {
+		HIP_TRY(c, hipMemcpyAsync(c->d_xyzq, c->h_xyzq, (size_t)c->n_pad * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+	} else {
 		for (int t = 0; t < count; t++) {
-			const int i = first + t;
-			c->h_xyzq[c->slot_of[i]] = make_double4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], c->h_q[i]);
+			const int k = c->slot_of[first + t];
+			HIP_TRY(c, hipMemcpyAsync(c->d_xyzq + k, c->h_xyzq + k, sizeof(double4), hipMemcpyHostToDevice, c->stream));
 		}
-		HIP_TRY(c, hipMemcpyAsync(c->d_xyzq, c->h_xyzq.data(), (size_t)c->n_pad * sizeof(double4), hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(c, hipStreamSynchronize(c->stream));
-		return MPMC_OK;
 	}
-	for (int t = 0; t < count; t++) { // the moved atoms keep their slots (the order only matters for speed)
-		const int i = first + t, k = c->slot_of[i];
-		// through the slot-ordered host mirror: a later bulk update uploads that mirror as a whole, and the source of an asynchronous
-		// copy has to outlive the call
-		c->h_xyzq[k] = make_double4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], c->h_q[i]);
-		HIP_TRY(c, hipMemcpyAsync(c->d_xyzq + k, &c->h_xyzq[k], sizeof(double4), hipMemcpyHostToDevice, c->stream));
-	}
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	HIP_TRY(c, hipEventRecord(c->ev_xyzq, c->stream));
+	c->xyzq_in_flight = true;
 	return MPMC_OK;
 }
 
@@ -688,7 +705,11 @@ extern "C" int mpmc_set_positions_device(mpmc_ctx *c, const double *pos_device) 
 	// keep the host mirror coherent (update_com / later partial updates read it)
 	HIP_TRY(c, hipMemcpyAsync(c->h_pos.data(), pos_device, 3 * (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	for (int i = 0; i < c->n; i++) { // ... and the slot-ordered mirror a later bulk mpmc_update_positions uploads as a whole
+	{
+		const int rc_g = mirror_guard(c);
+		if (rc_g != MPMC_OK) return rc_g;
+	}
+	for (int i = 0; i < c->n; i++) { // ... and the slot-ordered mirror a later mpmc_update_positions uploads as a whole
 		double4 &v = c->h_xyzq[c->slot_of[i]];
 		v.x = c->h_pos[3 * (size_t)i], v.y = c->h_pos[3 * (size_t)i + 1], v.z = c->h_pos[3 * (size_t)i + 2];
 	}

@@ -80,7 +80,9 @@ struct mpmc_ctx {
 	int n_panel_entries = 0, seg_tiles = -1; // entries of the table / the tile count its layout was made for
 	bool use_panels = true;          // MPMC_NO_PANELS=1: every tile pair through the single-tile-pair kernel (A/B comparisons)
 	bool panels_built = false;       // this evaluation's classes carry CLS_GROUPED bits and d_panels is valid
-	std::vector<double4> h_xyzq;     // host mirror of d_xyzq (slot order), for bulk position updates
+	double4 *h_xyzq = nullptr;       // PINNED host mirror of d_xyzq (slot order, max_pad entries): position updates copy from it asynchronously;
+	hipEvent_t ev_xyzq = nullptr;    // marks the last copy out of it done -- whoever is about to write the mirror waits for that copy only
+	bool xyzq_in_flight = false;     // (mirror_guard), not for the evaluations queued behind it
 	std::vector<double> h_pos_sorted; // positions at the time of the last spatial sort
 	// The spatial order is a locality heuristic: ANY permutation gives the same physics (sums in another order).  A contiguous insertion
 	// or removal (uVT / Gibbs) therefore carries the order it finds -- the survivors keep their sequence, inserted atoms are appended --
@@ -107,6 +109,11 @@ struct mpmc_ctx {
 	long long *static_cnt = nullptr; // pinned [4]: n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent; copied back behind every upload of the atoms)
 	// upload_atoms stages every per-atom array in ONE persistent pinned block (eight truly asynchronous copies, no synchronisation);
 	// ev_stage marks the copies done, the next upload waits for it before it refills the block
+	char *h_kstage = nullptr; // the same for the k-vector tables of build_k_tables ([kvec][kw][w_en][lvec], each cap_kstage long)
+	size_t cap_kstage = 0;
+	hipEvent_t ev_kstage = nullptr;
+	bool kstage_in_flight = false;
+	int lvec_kmax = -1;       // the integer l-vectors on the device belong to this kmax (they depend on nothing else)
 	char *h_stage = nullptr;
 	hipEvent_t ev_stage = nullptr;
 	bool stage_in_flight = false;
@@ -244,6 +251,14 @@ inline int dev_alloc(mpmc_ctx *c, T **p, size_t count) {
 	HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	c->bytes_total += (int64_t)(count * sizeof(T));
+	return MPMC_OK;
+}
+// before the slot-ordered mirror is written: the last asynchronous copy out of it must have read it
+inline int mirror_guard(mpmc_ctx *c) {
+	if (c->xyzq_in_flight) {
+		HIP_TRY(c, hipEventSynchronize(c->ev_xyzq));
+		c->xyzq_in_flight = false;
+	}
 	return MPMC_OK;
 }
 template <typename T>

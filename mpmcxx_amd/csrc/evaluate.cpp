@@ -12,33 +12,22 @@ using namespace mpmc;
 static int build_k_tables(mpmc_ctx *c) {
 	const int kmax = c->opts.ewald_kmax;
 	const double alpha = c->ewald_alpha, ea = c->polar_ewald_alpha;
-	std::vector<double4> kvec, kw;
-	std::vector<double> wen;
-	std::vector<int4> lvec;
+	// the set of l-vectors depends on kmax alone: count it, make room (device tables and ONE persistent pinned staging block), fill the
+	// staging block in place and copy asynchronously -- a volume move rebuilds these tables every time, and four blocking copies from
+	// pageable vectors plus a stream synchronisation cost more than the reciprocal-space kernels they feed
+	int K = 0;
 	int l[3];
 	for (l[0] = 0; l[0] <= kmax; l[0]++)
 		for (l[1] = (!l[0] ? 0 : -kmax); l[1] <= kmax; l[1]++)
-			for (l[2] = ((!l[0] && !l[1]) ? 1 : -kmax); l[2] <= kmax; l[2]++) {
-				if (l[0] * l[0] + l[1] * l[1] + l[2] * l[2] > kmax * kmax) continue;
-				double k[3];
-				for (int p = 0; p < 3; p++) {
-					k[p] = 0;
-					for (int q = 0; q < 3; q++) k[p] += 2.0 * kPi * c->box.r[3 * p + q] * l[q];
-				}
-				const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
-				kvec.push_back(make_double4(k[0], k[1], k[2], k2));
-				lvec.push_back(make_int4(l[0], l[1], l[2], 0));
-				wen.push_back(std::exp(-k2 / (4.0 * alpha * alpha)) / k2);
-				const double g = std::exp(-k2 / (4.0 * ea * ea));
-				kw.push_back(make_double4(k[0] / k2 * g, k[1] / k2 * g, k[2] / k2 * g, 0.0));
-			}
-	const int K = (int)kvec.size();
+			for (l[2] = ((!l[0] && !l[1]) ? 1 : -kmax); l[2] <= kmax; l[2]++)
+				if (l[0] * l[0] + l[1] * l[1] + l[2] * l[2] <= kmax * kmax) K++;
 	if (K > c->cap_K) {
 		dev_free(c, &c->d_kvec, (size_t)c->cap_K);
 		dev_free(c, &c->d_kw, (size_t)c->cap_K);
 		dev_free(c, &c->d_lvec, (size_t)c->cap_K);
 		dev_free(c, &c->d_w_en, (size_t)c->cap_K);
 		c->cap_K = 0;
+		c->lvec_kmax = -1;
 		int rc;
 		if ((rc = dev_alloc(c, &c->d_kvec, (size_t)K)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_kw, (size_t)K)) != MPMC_OK) return rc;
@@ -54,12 +43,48 @@ static int build_k_tables(mpmc_ctx *c) {
 		c->cap_sf = K;
 	}
 	if (K > 0) {
-		// on the context's stream (ordered against whatever it still runs), then waited for: the staging vectors die with this scope
-		HIP_TRY(c, hipMemcpyAsync(c->d_kvec, kvec.data(), K * sizeof(double4), hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(c, hipMemcpyAsync(c->d_kw, kw.data(), K * sizeof(double4), hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(c, hipMemcpyAsync(c->d_lvec, lvec.data(), K * sizeof(int4), hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(c, hipMemcpyAsync(c->d_w_en, wen.data(), K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		if (c->kstage_in_flight) { // (one rebuild per evaluation at most, and evaluations are waited for: normally long done)
+			HIP_TRY(c, hipEventSynchronize(c->ev_kstage));
+			c->kstage_in_flight = false;
+		}
+		if ((size_t)K > c->cap_kstage) {
+			if (c->h_kstage) HIP_TRY(c, hipHostFree(c->h_kstage));
+			c->h_kstage = nullptr;
+			c->cap_kstage = 0;
+			HIP_TRY(c, hipHostMalloc((void **)&c->h_kstage, (size_t)K * (2 * sizeof(double4) + sizeof(double) + sizeof(int4))));
+			c->cap_kstage = (size_t)K;
+			if (!c->ev_kstage) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_kstage, hipEventDisableTiming));
+		}
+		double4 *kvec = reinterpret_cast<double4 *>(c->h_kstage), *kw = kvec + c->cap_kstage;
+		double *wen = reinterpret_cast<double *>(kw + c->cap_kstage);
+		int4 *lvec = reinterpret_cast<int4 *>(wen + c->cap_kstage);
+		int n = 0;
+		for (l[0] = 0; l[0] <= kmax; l[0]++)
+			for (l[1] = (!l[0] ? 0 : -kmax); l[1] <= kmax; l[1]++)
+				for (l[2] = ((!l[0] && !l[1]) ? 1 : -kmax); l[2] <= kmax; l[2]++) {
+					if (l[0] * l[0] + l[1] * l[1] + l[2] * l[2] > kmax * kmax) continue;
+					double k[3];
+					for (int p = 0; p < 3; p++) {
+						k[p] = 0;
+						for (int q = 0; q < 3; q++) k[p] += 2.0 * kPi * c->box.r[3 * p + q] * l[q];
+					}
+					const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+					kvec[n] = make_double4(k[0], k[1], k[2], k2);
+					lvec[n] = make_int4(l[0], l[1], l[2], 0);
+					wen[n] = std::exp(-k2 / (4.0 * alpha * alpha)) / k2;
+					const double g = std::exp(-k2 / (4.0 * ea * ea));
+					kw[n] = make_double4(k[0] / k2 * g, k[1] / k2 * g, k[2] / k2 * g, 0.0);
+					n++;
+				}
+		HIP_TRY(c, hipMemcpyAsync(c->d_kvec, kvec, K * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_kw, kw, K * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_w_en, wen, K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+		if (c->lvec_kmax != kmax) {
+			HIP_TRY(c, hipMemcpyAsync(c->d_lvec, lvec, K * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+			c->lvec_kmax = kmax;
+		}
+		HIP_TRY(c, hipEventRecord(c->ev_kstage, c->stream));
+		c->kstage_in_flight = true;
 	}
 	c->K = K;
 	return MPMC_OK;

@@ -274,7 +274,11 @@ extern "C" int mpmc_trial_accept(mpmc_ctx *c) {
 		// (no wait: whatever comes next on this context is enqueued behind the commit on the same stream, and the host mirrors below are
 		// the host's own -- the stream synchronisation that stood here cost 13 us of a 41 us accepted move)
 		for (int t = 0; t < 3 * m; t++) c->h_pos[3 * (size_t)c->trial_first + t] = c->trial_new[t];
-		for (int t = 0; t < m; t++) { // the slot-ordered mirror follows (a later bulk position update uploads it as a whole)
+		{
+			const int rc_g = mirror_guard(c);
+			if (rc_g != MPMC_OK) return rc_g;
+		}
+		for (int t = 0; t < m; t++) { // the slot-ordered mirror follows (a later position update uploads it as a whole)
 			double4 &v = c->h_xyzq[c->slot_of[c->trial_first + t]];
 			v.x = c->trial_new[3 * t], v.y = c->trial_new[3 * t + 1], v.z = c->trial_new[3 * t + 2];
 		}

@@ -42,6 +42,27 @@ name = sys.argv[1] if len(sys.argv) > 1 else "ion216_polar"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 atoms, basis, opts = util.load_fixture(name)
 S = energy.System(atoms, basis, opts)
+if len(sys.argv) > 3 and sys.argv[3] == "volume":  # us per volume move (NPT / Gibbs): set_box with scaled positions + full evaluation
+    import numpy as np
+
+    pos0 = atoms["pos"].copy()
+    S.energy()
+    t_set = t_en = 0.0
+    for it in range(n + 10):
+        if it == 10:
+            t_set = t_en = 0.0
+        f = 1.0 + 0.002 * ((it % 2) * 2 - 1)
+        t0 = time.perf_counter()
+        S.set_box(basis * f)
+        S.update_positions(0, pos0 * f)
+        t1 = time.perf_counter()
+        S.energy()
+        t2 = time.perf_counter()
+        t_set += t1 - t0
+        t_en += t2 - t1
+    print(f"{name}: {len(pos0)} atoms, volume move: set_box + positions {t_set / n * 1e6:.1f} us + energy {t_en / n * 1e6:.1f} us (python loop)")
+    S.close()
+    sys.exit(0)
 if len(sys.argv) > 3 and sys.argv[3] == "resize":  # us per N-changing move (uVT / Gibbs insert or remove): set_atoms + full evaluation
     import numpy as np
 
