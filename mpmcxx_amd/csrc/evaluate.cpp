@@ -568,6 +568,39 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 }
 
 
+// measurement only (bench.py's roofline, cross-check): the panel Jacobi kernel `reps` times back to back between ONE pair of HIP events
+// on the context's stream, per launch.  It agrees with the profiling mode's per-launch event brackets (92.7 against 92.9 us): what
+// separates both from rocprofv3's kernel trace (86 us) is the dispatch / completion time between consecutive kernels of a stream, not
+// the event records.  Needs the state a polarizable evaluation of a box on the panel path leaves behind; the partial slots it
+// overwrites are dead by then.
+extern "C" int mpmc_debug_time_panel(mpmc_ctx *c, int reps, double *ms_per_launch) {
+	if (!c || !ms_per_launch || reps <= 0) return MPMC_ERR_ARG;
+	if (c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_debug_time_panel: an evaluation is in flight");
+	if (!c->have_polar || !c->panels_built || !c->jacobi_hybrid || c->solver_used != MPMC_SOLVER_COMPACT)
+		return fail(c, MPMC_ERR_ARG, "mpmc_debug_time_panel: the last evaluation did not run the panel kernel");
+	HIP_TRY(c, hipSetDevice(c->device));
+	const AtomsDev at = atoms_view(c);
+	hipEvent_t e0, e1;
+	HIP_TRY(c, hipEventCreate(&e0));
+	HIP_TRY(c, hipEventCreate(&e1));
+	for (int r = 0; r < 3; r++) // (warm)
+		launch_dipole_iter_panel(c->stream, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels, c->n_panel_entries,
+		                         c->d_ab, c->d_part, c->d_gpart, nullptr, nullptr);
+	HIP_TRY(c, hipEventRecord(e0, c->stream));
+	for (int r = 0; r < reps; r++)
+		launch_dipole_iter_panel(c->stream, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels, c->n_panel_entries,
+		                         c->d_ab, c->d_part, c->d_gpart, nullptr, nullptr);
+	HIP_TRY(c, hipEventRecord(e1, c->stream));
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipEventSynchronize(e1));
+	float ms = 0;
+	HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	*ms_per_launch = (double)ms / reps;
+	return MPMC_OK;
+}
+
 int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 	if (!c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_energy_wait: nothing enqueued");
 	HIP_TRY(c, hipSetDevice(c->device));
