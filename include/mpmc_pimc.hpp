@@ -176,7 +176,15 @@ public:
 				register_move(move, true);
 				potential_current = potential_trial;
 				if (use_trial_moves)
-					for (SystemT *s : systems) s->accept_trial();
+					{
+						const int n_img = (int)systems.size();
+						int err_img = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_img < 4 ? n_img : 4) if (n_img > 1)
+#endif
+						for (int b = 0; b < n_img; b++) each_image_guarded(err_img, [&] { systems[b]->accept_trial(); });
+						if (err_img) throw err_img;
+					}
 				// same geometry: the potential of the trial evaluation stands, the kinetic part is new.  It is a pure function of
 				// the geometry (O(P N) host work), so the delta-energy mode computes it when a row is written instead of per accept.
 				if (!use_trial_moves) PI_calculate_energy(false);

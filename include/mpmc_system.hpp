@@ -374,6 +374,20 @@ public:
 // values in bead order.  With one process it may be left empty.
 // (The reference keeps all P images on every MPI rank, so its kinetic estimator needs no exchange; with the beads
 // sharded over ranks the ring of adjacent images crosses ranks and the centres of mass are gathered once per call.)
+// one image's share of a loop that may run under OpenMP: the facade reports errors by throwing an int, and an exception must not
+// leave a parallel region -- the first one is kept and thrown again behind the loop
+template <class F>
+inline void each_image_guarded(int &first_error, F &&body) {
+	try {
+		body();
+	} catch (int e) {
+#ifdef _OPENMP
+#pragma omp critical(mpmc_image_error)
+#endif
+		if (!first_error) first_error = e;
+	}
+}
+
 template <class SystemT>
 class PathIntegralEnsembleT {
 public:
@@ -403,7 +417,15 @@ public:
 	// configuration until accept_trial() / reject_trial()
 	double PI_trial_potential(int first, int count, const std::vector<std::vector<double>> &new_pos) {
 		const int n_local = (int)systems.size();
-		for (int b = 0; b < n_local; b++) systems[b]->energy_trial_async(first, count, new_pos[b].data());
+		int err_img = 0;
+		// The images' enqueues are independent (one context, one stream each) and a trial is bound by the host's HIP calls, not by the GPU:
+		// built with -fopenmp the images are enqueued by a few threads, as the reference's own bead loop is (PathIntegral.cpp:759-775);
+		// without it this is the plain loop.  The waits and the sums below stay in image order: the result does not depend on threads.
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_local < 4 ? n_local : 4) if (n_local > 1)
+#endif
+		for (int b = 0; b < n_local; b++) each_image_guarded(err_img, [&] { systems[b]->energy_trial_async(first, count, new_pos[b].data()); });
+		if (err_img) throw err_img;
 		std::vector<double> mine(4 * (size_t)n_local);
 		for (int b = 0; b < n_local; b++) {
 			systems[b]->energy_trial_wait();
@@ -484,7 +506,13 @@ public:
 
 	double PI_calculate_potential() {
 		const int n_local = (int)systems.size();
-		for (SystemT *s : systems) s->energy_async(); // every bead enqueued on its own stream before the first wait
+		int err_img = 0;
+		// every bead enqueued on its own stream before the first wait (by a few threads when built with -fopenmp, see PI_trial_potential)
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_local < 4 ? n_local : 4) if (n_local > 1)
+#endif
+		for (int b = 0; b < n_local; b++) each_image_guarded(err_img, [&] { systems[b]->energy_async(); });
+		if (err_img) throw err_img;
 		std::vector<double> mine(4 * (size_t)n_local);
 		for (int b = 0; b < n_local; b++) {
 			systems[b]->energy_wait();

@@ -104,13 +104,15 @@ def test_driver_refuses_what_it_does_not_cover(pimc_check, tmp_path):
     assert out.returncode == 1 and json.loads(out.stdout)["error"] == 9003  # the Trotter number must be a power of two >= 4
 
 
-@pytest.fixture(scope="module")
-def pimc_nvt(tmp_path_factory):
+@pytest.fixture(scope="module", params=[False, True], ids=["plain", "openmp"])
+def pimc_nvt(tmp_path_factory, request):
+    """the example driver, built without and with -fopenmp (the facade's loops over the images then run on a few host threads, as the
+    reference's bead loop does: PathIntegral.cpp:759-775) -- both builds have to reproduce the stock binary"""
     from mpmcxx_amd import build as mbuild
 
     mbuild.build_library()
     exe = str(tmp_path_factory.mktemp("pimc") / "pimc_nvt")
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-I", os.path.join(util.ROOT, "include"), os.path.join(util.ROOT, "examples", "pimc_nvt.cpp"),
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall"] + (["-fopenmp"] if request.param else []) + ["-I", os.path.join(util.ROOT, "include"), os.path.join(util.ROOT, "examples", "pimc_nvt.cpp"),
                            "-L", LIBDIR, "-lmpmc_energy", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     return exe
 

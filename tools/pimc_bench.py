@@ -48,7 +48,8 @@ build.build_library()
 exe = os.path.join(wd, "pimc_nvt")
 libdir = os.path.join(ROOT, "mpmcxx_amd")
 GPROF = os.environ.get("PIMC_BENCH_GPROF") == "1"  # host profile of the driver itself (library and HIP runtime time is not attributed)
-subprocess.check_call(["g++", "-std=c++14", "-O2"] + (["-pg", "-fno-inline-small-functions", "-fno-inline-functions"] if GPROF else []) + ["-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "pimc_nvt.cpp"), "-L", libdir,
+OMP = os.environ.get("PIMC_BENCH_OPENMP") == "1"  # the images' enqueues by a few host threads (the facade's optional OpenMP loops)
+subprocess.check_call(["g++", "-std=c++14", "-O2"] + (["-fopenmp"] if OMP else []) + (["-pg", "-fno-inline-small-functions", "-fno-inline-functions"] if GPROF else []) + ["-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "pimc_nvt.cpp"), "-L", libdir,
                        "-lmpmc_energy", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
 res = {}
 for mode in ("full", "trial"):
