@@ -181,3 +181,38 @@ def test_counts_after_a_drift_resort_without_electrostatics(monkeypatch):
     assert abs(e - ef) <= 1e-12 * abs(ef)
     S.close()
     F.close()
+
+
+@pytest.mark.parametrize("name", ["ion64_es", "lj1000", "ion1000_polar"])
+def test_positions_for_the_next_evaluation_while_one_is_in_flight(name):
+    """mpmc_update_positions no longer waits for the stream: it copies from a pinned mirror and only waits, before it writes that mirror
+    again, for the copy that last read it (context.h mirror_guard).  A caller that pipelines -- positions A, evaluation A enqueued,
+    positions B handed over BEFORE evaluation A is waited for -- must get A's energy for A and B's for B, whole-array and single-molecule
+    updates alike."""
+    atoms, basis, opts = util.load_fixture(name)
+    rng = np.random.default_rng(9)
+    pos0 = atoms["pos"].copy()
+    ids = atoms["mol_id"]
+    b = int(np.nonzero(ids != ids[0])[0][0]) if (ids != ids[0]).any() else len(ids)
+    S = energy.System(atoms, basis, opts)
+    S.energy()
+    for bulk in (True, False):
+        lo, hi = (0, len(pos0)) if bulk else (0, b)
+        pa, pb = pos0.copy(), pos0.copy()
+        pa[lo:hi] += rng.normal(scale=0.05, size=(hi - lo, 3))
+        pb[lo:hi] += rng.normal(scale=0.05, size=(hi - lo, 3))
+        buf = pa[lo:hi].copy()
+        S.update_positions(lo, buf)
+        buf[:] = 1.0e6  # the caller's array is its own again as soon as the call returns
+        S.energy_async()
+        S.update_positions(lo, pb[lo:hi])  # evaluation A is still in flight
+        ea = S.energy_wait()
+        eb = S.energy()
+        for p, e in ((pa, ea), (pb, eb)):
+            F = energy.System(dict(atoms, pos=p), basis, opts)
+            ef = F.energy()
+            F.close()
+            assert abs(e - ef) <= 1e-11 * max(abs(ef), 1.0), (name, bulk, e, ef)
+        S.update_positions(0, pos0)
+        S.energy()
+    S.close()
