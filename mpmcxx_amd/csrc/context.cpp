@@ -165,6 +165,7 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	if (rc == MPMC_OK) c->d_cnt = reinterpret_cast<long long *>(c->d_scal + S_COUNT);
 	A(dev_alloc(c, &c->d_flag, (size_t)4)); // [0]: Gauss-Seidel's per-sweep flag; [1..3]: iteration control of the precision-terminated Jacobi solve
 	A(dev_alloc(c, &c->d_counter, (size_t)1));
+	A(dev_alloc(c, &c->d_atom_part, kAtomTermScratch));
 	static_assert(sizeof(long long) == sizeof(double), "scalars and counts share one buffer");
 	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_scal, (S_COUNT + C_COUNT + 1) * sizeof(double)) != hipSuccess) rc = MPMC_ERR_HIP;
 	if (rc == MPMC_OK) c->h_cnt = reinterpret_cast<long long *>(c->h_scal + S_COUNT);
@@ -195,7 +196,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	for (auto &e : c->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-	void *ptrs[] = {c->d_atoms_blob, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal,
+	void *ptrs[] = {c->d_atoms_blob, c->d_atom_part, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal,
 	                c->d_flag, c->d_counter, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
 	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_panels, c->d_seg, c->d_gpart, c->d_trace, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out, c->d_e_real, c->d_e_real_trial, c->d_dk_part};

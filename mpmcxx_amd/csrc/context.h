@@ -132,6 +132,7 @@ struct mpmc_ctx {
 	bool last_was_single = false;   // the pending evaluation wrote h_scal from the device: nothing to copy back
 	double single_seq = 0;          // launch number the single-launch kernel posts behind its results (host polls h_scal[S_COUNT + C_COUNT])
 	// scalars
+	double *d_atom_part = nullptr;   // scratch of launch_atom_terms (per-block partial sums)
 	double *d_scal = nullptr;
 	long long *d_cnt = nullptr;
 	double *h_scal = nullptr; // pinned

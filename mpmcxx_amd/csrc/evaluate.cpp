@@ -184,7 +184,7 @@ int mpmc::prepare(mpmc_ctx *c, bool defer_static) {
 	// kernel behind its clear of the scalar block and wait_and_fill adopts the three values); everybody else gets them here and now.
 	if (c->static_dirty && !defer_static) {
 		c->scal_clean = false; // (the kernel writes its slots of the scalar block: the next evaluation clears the block first)
-		launch_atom_terms(c->stream, atoms_view(c), recip_view(c), c->box, c->ewald_alpha, c->opts.rd_lrc, /*self term*/ 2, c->d_scal);
+		launch_atom_terms(c->stream, atoms_view(c), c->box, c->ewald_alpha, c->opts.rd_lrc, /*self term*/ 1, c->d_atom_part, c->d_scal);
 		HIP_TRY(c, hipGetLastError());
 		double tmp[S_COUNT];
 		HIP_TRY(c, hipMemcpyAsync(tmp, c->d_scal, sizeof(tmp), hipMemcpyDeviceToHost, c->stream));
@@ -259,7 +259,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	if (!c->scal_clean) HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (S_COUNT + C_COUNT) * sizeof(double), st));
 	c->scal_clean = false;
 	if (static_ride) { // first thing on the main stream: its slots are nobody else's (S_LRC_PAIR, S_LRC_SELF, S_ES_SELF)
-		launch_atom_terms(st, at, rcp, c->box, c->ewald_alpha, o.rd_lrc, /*self term*/ 2, c->d_scal);
+		launch_atom_terms(st, at, c->box, c->ewald_alpha, o.rd_lrc, /*self term*/ 1, c->d_atom_part, c->d_scal);
 		HIP_TRY(c, hipGetLastError());
 		c->static_ride_gen = c->static_gen;
 	}

@@ -76,8 +76,10 @@ constexpr int kRecipTabMaxK = 15; // phase tables of 3 x 64 x (kmax+1) complex n
 void launch_recip_sf(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double4 *sf_part);
 // reciprocal energy + O(N) atom terms: coulombic_self, lj_lrc_self, and the PAIR long-range correction summed in O(N)
 // through moments of (sqrt(eps), |sigma|) (Lorentz-Berthelot makes the pair term a polynomial in sigma_i + sigma_j)
-void launch_atom_terms(hipStream_t st, const AtomsDev &at, const RecipDev &rc, const Box &bx, double ewald_alpha, int rd_lrc,
-                       int do_es, double *scal);
+// position-independent terms (pair LRC, self LRC, Ewald self) into their three slots of the scalar block; part_scratch: kAtomTermScratch doubles
+constexpr size_t kAtomTermScratch = 64 * 32;
+void launch_atom_terms(hipStream_t st, const AtomsDev &at, const Box &bx, double ewald_alpha, int rd_lrc, int do_es, double *part_scratch,
+                       double *scal);
 
 // static field
 void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double *e_recip /*[recip_ksplit(n_pad)][n_pad][3]*/);

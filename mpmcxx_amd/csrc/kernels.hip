@@ -160,19 +160,17 @@ __device__ const double kBinom12[13] = {1, 12, 66, 220, 495, 792, 924, 792, 495,
 //   sum_{i<j} sqe_i sqe_j (s_i+s_j)^m = 1/2 [ sum_k C(m,k) M_k M_{m-k} - sum_i sqe_i^2 (2 s_i)^m ],   M_k = sum_i sqe_i s_i^k
 // over the atoms with eps != 0, sigma > 0 (sigma == 0 or < 0 gives sig_ij or eps_ij = 0), minus the same sum over the
 // frozen subset (frozen-frozen pairs are excluded, :1049).  O(N) instead of O(N^2), position independent.
-__global__ __launch_bounds__(256) void k_atom_terms(AtomsDev at, RecipDev rc, Box bx, double ewald_alpha, int rd_lrc, int do_es,
-                                                    double *__restrict__ scal) {
-	__shared__ double sh[4];
-	double e = 0, self = 0, lrc = 0;
+// Two launches: the per-atom sums over as many 256-thread blocks as there are atoms for (one block looping over 10 000 atoms with thirteen
+// dependent multiplies each took 81 us -- most of an evaluation it rides along with after every insertion, removal or volume move),
+// 32 partial sums per block; then one wave adds the blocks' partials in block order (reproducible) and forms the three results.
+constexpr int kAtomTermSums = 32, kAtomTermBlocks = 64; // self, lrc, M_0..12, Mfrozen_0..12, d6, d12, df6, df12
+static_assert((size_t)kAtomTermSums * kAtomTermBlocks <= kAtomTermScratch, "scratch of launch_atom_terms");
+__global__ __launch_bounds__(256) void k_atom_terms_part(AtomsDev at, Box bx, double ewald_alpha, int rd_lrc, int do_es,
+                                                         double *__restrict__ part /*[gridDim.x][kAtomTermSums]*/) {
+	double self = 0, lrc = 0;
 	double m[13], mf[13], d6 = 0, d12 = 0, df6 = 0, df12 = 0;
 	for (int k = 0; k < 13; ++k) m[k] = mf[k] = 0;
-	if (do_es == 1) { // (do_es == 2: the self term alone -- the cached position-independent call of prepare())
-		for (int k = threadIdx.x; k < rc.K; k += 256) {
-			const double4 sf = rc.sf[k];
-			e += rc.w_en[k] * (sf.x * sf.x + sf.y * sf.y);
-		}
-	}
-	for (int a = threadIdx.x; a < at.n; a += 256) {
+	for (int a = blockIdx.x * 256 + threadIdx.x; a < at.n; a += gridDim.x * 256) {
 		const int fl = at.mf[a].y;
 		const double2 l = at.lj[a];
 		if (rd_lrc && !(fl & (AF_NULL_RD | AF_NEG_SIGMA))) {
@@ -196,18 +194,40 @@ __global__ __launch_bounds__(256) void k_atom_terms(AtomsDev at, RecipDev rc, Bo
 		if (do_es) self -= ewald_alpha * q * q / sqrt(kPi);
 		if (rd_lrc && !(fl & AF_NULL_RD)) lrc += lrc_term(l.x, at.eps[a], bx.cutoff, bx.volume);
 	}
-	e = block_sum_256(e, sh);
-	self = block_sum_256(self, sh);
-	lrc = block_sum_256(lrc, sh);
+	// the 32 sums of the block: every wave reduces all of them, ONE barrier, then 32 threads fold the four waves in wave order (the order
+	// block_sum_256 uses -- 32 calls of it were 64 barriers and most of the kernel's 15 us)
+	__shared__ double s_w[4][kAtomTermSums];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	auto put = [&](int slot, double v) {
+		v = wave_sum(v);
+		if (lane == 0) s_w[w][slot] = v;
+	};
+	put(0, self);
+	put(1, lrc);
 	for (int k = 0; k < 13; ++k) {
-		m[k] = block_sum_256(m[k], sh);
-		mf[k] = block_sum_256(mf[k], sh);
+		put(2 + k, m[k]);
+		put(15 + k, mf[k]);
 	}
-	d6 = block_sum_256(d6, sh);
-	d12 = block_sum_256(d12, sh);
-	df6 = block_sum_256(df6, sh);
-	df12 = block_sum_256(df12, sh);
+	put(28, d6);
+	put(29, d12);
+	put(30, df6);
+	put(31, df12);
+	__syncthreads();
+	if (threadIdx.x < kAtomTermSums)
+		part[(size_t)blockIdx.x * kAtomTermSums + threadIdx.x] = ((s_w[0][threadIdx.x] + s_w[1][threadIdx.x]) + s_w[2][threadIdx.x]) + s_w[3][threadIdx.x];
+}
+__global__ __launch_bounds__(64) void k_atom_terms_finish(const double *__restrict__ part, int nb, Box bx, int rd_lrc, double *__restrict__ scal) {
+	__shared__ double s[kAtomTermSums];
+	if (threadIdx.x < kAtomTermSums) {
+		double v = 0;
+#pragma unroll 8
+		for (int b = 0; b < nb; ++b) v += part[(size_t)b * kAtomTermSums + threadIdx.x]; // block order: the same whatever ran first (unrolled: loads in flight together)
+		s[threadIdx.x] = v;
+	}
+	__syncthreads();
 	if (threadIdx.x == 0) {
+		const double *m = s + 2, *mf = s + 15;
+		const double d6 = s[28], d12 = s[29], df6 = s[30], df12 = s[31];
 		double s6 = 0, s12 = 0, f6 = 0, f12 = 0;
 		for (int k = 0; k <= 6; ++k) {
 			s6 += kBinom6[k] * m[k] * m[6 - k];
@@ -221,9 +241,8 @@ __global__ __launch_bounds__(256) void k_atom_terms(AtomsDev at, RecipDev rc, Bo
 		const double p12 = (0.5 * (s12 - d12) - 0.5 * (f12 - df12)) / 4096.0; // sum_{pairs} eps_ij sig_ij^12
 		const double rc3 = bx.cutoff * bx.cutoff * bx.cutoff, rc9 = rc3 * rc3 * rc3;
 		scal[S_LRC_PAIR] = rd_lrc ? (16.0 / 3.0) * kPi * (p12 / (3.0 * rc9) - p6 / rc3) / bx.volume : 0.0;
-		if (do_es != 2) scal[S_ES_RECIP] = e * (4.0 * kPi / bx.volume); // (the self-terms call leaves the reciprocal energy's slot alone)
-		scal[S_ES_SELF] = self;
-		scal[S_LRC_SELF] = lrc;
+		scal[S_ES_SELF] = s[0];
+		scal[S_LRC_SELF] = s[1];
 	}
 }
 
@@ -326,9 +345,11 @@ void launch_recip_sf(hipStream_t st, const AtomsDev &at, const Box &bx, const Re
 	}
 	hipLaunchKernelGGL(k_recip_sf, dim3(rc.K), dim3(256), 0, st, at, rc);
 }
-void launch_atom_terms(hipStream_t st, const AtomsDev &at, const RecipDev &rc, const Box &bx, double ewald_alpha, int rd_lrc, int do_es,
+void launch_atom_terms(hipStream_t st, const AtomsDev &at, const Box &bx, double ewald_alpha, int rd_lrc, int do_es, double *part_scratch,
                        double *scal) {
-	hipLaunchKernelGGL(k_atom_terms, dim3(1), dim3(256), 0, st, at, rc, bx, ewald_alpha, rd_lrc, do_es, scal);
+	const int nb = std::max(1, std::min(kAtomTermBlocks, (at.n + 255) / 256));
+	hipLaunchKernelGGL(k_atom_terms_part, dim3(nb), dim3(256), 0, st, at, bx, ewald_alpha, rd_lrc, do_es, part_scratch);
+	hipLaunchKernelGGL(k_atom_terms_finish, dim3(1), dim3(64), 0, st, part_scratch, nb, bx, rd_lrc, scal);
 }
 
 // the position-dependent part of coulombic_reciprocal alone (:1609-1618): (4 pi / V) sum_k w_k |S_k|^2 -- K terms, one block
