@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void k_reduce_pairs(const double *__restrict__
 	__shared__ long long shc[256];
 	double s0 = 0, s1 = 0;
 	long long c0 = 0, c1 = 0;
-	for (int b = threadIdx.x; b < nb; b += 256) {
+#pragma unroll 4
+	for (int b = threadIdx.x; b < nb; b += 256) { // (one block over all tile pairs' partials: unrolled, the loads overlap; same order of sums)
 		s0 += block_part[2 * (size_t)b];
 		s1 += block_part[2 * (size_t)b + 1];
 		c0 += block_cnt[2 * (size_t)b];
@@ -604,7 +605,8 @@ __device__ __forceinline__ void polar_energy_block(const AtomsDev &at, const dou
                                                    const double *__restrict__ rrms_atom, double *__restrict__ scal) {
 	__shared__ double sh[4];
 	double u = 0, rr = 0;
-	for (int i = threadIdx.x; i < at.n; i += 256) {
+#pragma unroll 4
+	for (int i = threadIdx.x; i < at.n; i += 256) { // (one block: unrolled so that the loads of four atoms are in flight together; same order of sums)
 		const size_t b = 3 * (size_t)i;
 		u += ((mu[b] * e_static[b]) + mu[b + 1] * e_static[b + 1]) + mu[b + 2] * e_static[b + 2];
 		if (rrms_atom) {
