@@ -100,7 +100,8 @@ __global__ __launch_bounds__(64) void k_static_counts(AtomsDev at, const int2 *_
 __global__ __launch_bounds__(256) void k_reduce_counts4(const int *__restrict__ block_cnt, int nb, long long *__restrict__ cnt4) {
 	__shared__ long long shc[256];
 	long long c[4] = {0, 0, 0, 0};
-	for (int b = threadIdx.x; b < nb; b += 256)
+#pragma unroll 4
+	for (int b = threadIdx.x; b < nb; b += 256) // (one block over all tile pairs: unrolled, the loads overlap)
 		for (int k = 0; k < 4; ++k) c[k] += block_cnt[4 * (size_t)b + k];
 	for (int k = 0; k < 4; ++k) {
 		__syncthreads();
