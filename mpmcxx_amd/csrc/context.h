@@ -109,7 +109,7 @@ struct mpmc_ctx {
 	long long *static_cnt = nullptr; // pinned [4]: n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent; copied back behind every upload of the atoms)
 	// upload_atoms stages every per-atom array in ONE persistent pinned block (eight truly asynchronous copies, no synchronisation);
 	// ev_stage marks the copies done, the next upload waits for it before it refills the block
-	char *h_kstage = nullptr; // the same for the k-vector tables of build_k_tables ([kvec][kw][w_en][lvec], each cap_kstage long)
+	char *h_kstage = nullptr; // the same for the k-vector tables of build_k_tables ([kvec][kw][lvec][w_en], each cap_kstage long: 16-byte types first)
 	size_t cap_kstage = 0;
 	hipEvent_t ev_kstage = nullptr;
 	bool kstage_in_flight = false;

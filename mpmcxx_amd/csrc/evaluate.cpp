@@ -55,9 +55,10 @@ static int build_k_tables(mpmc_ctx *c) {
 			c->cap_kstage = (size_t)K;
 			if (!c->ev_kstage) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_kstage, hipEventDisableTiming));
 		}
+		// (the 16-byte types first: behind an odd number of doubles an int4 array would be misaligned -- found by tools/host_asan.sh)
 		double4 *kvec = reinterpret_cast<double4 *>(c->h_kstage), *kw = kvec + c->cap_kstage;
-		double *wen = reinterpret_cast<double *>(kw + c->cap_kstage);
-		int4 *lvec = reinterpret_cast<int4 *>(wen + c->cap_kstage);
+		int4 *lvec = reinterpret_cast<int4 *>(kw + c->cap_kstage);
+		double *wen = reinterpret_cast<double *>(lvec + c->cap_kstage);
 		int n = 0;
 		for (l[0] = 0; l[0] <= kmax; l[0]++)
 			for (l[1] = (!l[0] ? 0 : -kmax); l[1] <= kmax; l[1]++)
