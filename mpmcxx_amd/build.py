@@ -17,9 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, ".obj")
 LIB = os.path.join(HERE, "libmpmc_energy.so")
-SOURCES = ["kernels.hip", "kernels_sym.hip", "kernels_panel.hip", "kernels_delta.hip", "kernels_gs.hip", "kernels_dense.hip", "context.cpp", "evaluate.cpp",
+SOURCES = ["kernels.hip", "kernels_sym.hip", "kernels_panel.hip", "kernels_pair.hip", "erfc_table.cpp", "kernels_delta.hip", "kernels_gs.hip", "kernels_dense.hip", "context.cpp", "evaluate.cpp",
            "trial.cpp", "pi.cpp", "comm.cpp", "gibbs.cpp"]
-HEADERS = ["kernels.h", "context.h", "pair_math.h", "erfcx_coeffs.h", "device_math.h", os.path.join("..", "..", "include", "mpmc_energy.h")]
+HEADERS = ["kernels.h", "context.h", "pair_math.h", "erfcx_coeffs.h", "device_math.h", "erfc_table.inc", os.path.join("..", "..", "include", "mpmc_energy.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared", "-ldl", "-lpthread"]
 FLAGS = CFLAGS + LDFLAGS  # (kept for tools that print the build line)

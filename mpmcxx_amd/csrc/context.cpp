@@ -119,6 +119,8 @@ static int rot_selftest(mpmc_ctx *c) {
 	return MPMC_OK;
 }
 
+static int g_default_pair_kernel = 0; // (mpmc_debug_configure with a null context)
+
 // ---- lifetime --------------------------------------------------------------------------------------------
 extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	if (!out || max_atoms <= 0) return fail(nullptr, MPMC_ERR_ARG, "mpmc_ctx_create: bad argument");
@@ -145,6 +147,7 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 		delete c;
 		return fail(nullptr, MPMC_ERR_HIP, "mpmc_ctx_create: hipStreamCreate failed");
 	}
+	c->pair_kernel = g_default_pair_kernel;
 	if (const char *e = std::getenv("MPMC_ONE_STREAM")) c->stream_mode = (e[0] == '1') ? 0 : 1;
 	c->two_streams = (c->stream_mode != 0);
 	if (const char *e = std::getenv("MPMC_JACOBI")) c->jacobi_hybrid = (e[0] != 's');
@@ -166,6 +169,14 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	A(dev_alloc(c, &c->d_flag, (size_t)4)); // [0]: Gauss-Seidel's per-sweep flag; [1..3]: iteration control of the precision-terminated Jacobi solve
 	A(dev_alloc(c, &c->d_counter, (size_t)1));
 	A(dev_alloc(c, &c->d_atom_part, kAtomTermScratch));
+	A(dev_alloc(c, &c->d_erf_tab, (size_t)kErfTableDouble2));
+	if (rc == MPMC_OK) { // the erfc table of the pair sweep: 24 KB, once per context
+		std::vector<double2> tab(kErfTableDouble2);
+		erfc_table_device_layout(tab.data());
+		if (hipMemcpyAsync(c->d_erf_tab, tab.data(), tab.size() * sizeof(double2), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+		    hipStreamSynchronize(c->stream) != hipSuccess)
+			rc = MPMC_ERR_HIP;
+	}
 	static_assert(sizeof(long long) == sizeof(double), "scalars and counts share one buffer");
 	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_scal, (S_COUNT + C_COUNT + 1) * sizeof(double)) != hipSuccess) rc = MPMC_ERR_HIP;
 	if (rc == MPMC_OK) c->h_cnt = reinterpret_cast<long long *>(c->h_scal + S_COUNT);
@@ -199,7 +210,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	void *ptrs[] = {c->d_atoms_blob, c->d_atom_part, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal,
 	                c->d_flag, c->d_counter, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
 	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_panels, c->d_seg, c->d_gpart, c->d_trace, c->d_mv_blob, c->d_moved_idx,
-	                c->d_sf_trial, c->d_delta_out, c->d_e_real, c->d_e_real_trial, c->d_dk_part};
+	                c->d_sf_trial, c->d_delta_out, c->d_e_real, c->d_e_real_trial, c->d_dk_part, c->d_erf_tab, c->d_sweep_blocks, c->d_generic_list};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -460,6 +471,30 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 			mf[k] = make_int2(-1 - k, AF_PAD | AF_FROZEN | AF_NULL_RD | AF_ZERO_SIGMA | AF_ZERO_Q | AF_ZERO_ALPHA);
 		}
 	}
+	{ // tile pairs with a "special" atom (what pair_flags / lj_mix look at) are the generic pair kernel's: their list, in tile-pair order
+		constexpr int kSpecial = AF_FROZEN | AF_NULL_RD | AF_HAS_DISP | AF_NEG_SIGMA | AF_ZERO_SIGMA | AF_ZERO_Q;
+		const int nt = c->n_tiles;
+		std::vector<char> special((size_t)nt, 0);
+		bool any = false;
+		for (int k = 0; k < n; k++)
+			if (mf[k].y & kSpecial) special[k / kTile] = 1, any = true;
+		c->h_generic.clear();
+		if (any)
+			for (int I = 0, t = 0; I < nt; I++)
+				for (int J = I; J < nt; J++, t++)
+					if (special[I] || special[J]) c->h_generic.push_back(t);
+		c->n_generic = (int)c->h_generic.size();
+		if (c->n_generic > 0) {
+			if ((size_t)c->n_generic > c->cap_generic) {
+				dev_free(c, &c->d_generic_list, c->cap_generic);
+				c->cap_generic = 0;
+				const int rc_a = dev_alloc(c, &c->d_generic_list, (size_t)c->n_tile_pairs);
+				if (rc_a != MPMC_OK) return rc_a;
+				c->cap_generic = (size_t)c->n_tile_pairs;
+			}
+			HIP_TRY(c, hipMemcpyAsync(c->d_generic_list, c->h_generic.data(), (size_t)c->n_generic * sizeof(int), hipMemcpyHostToDevice, c->stream));
+		}
+	}
 	// ONE copy: the device block has the layout of the staging block (the tails beyond n_pad travel along; nobody reads them)
 	if (np < (int)P && (size_t)np * 2 >= P)
 		for (size_t k = (size_t)np; k < P; k++) { // (the tails travel along with the single copy: defined values)
@@ -530,6 +565,7 @@ static int grow_capacity(mpmc_ctx *c, int n) {
 	}
 	f->prof = c->prof;
 	f->tim = c->tim;
+	f->pair_kernel = c->pair_kernel;
 	f->n_uploads_carried = c->n_uploads_carried; // (diagnostics survive the growth; the order itself does not: the new context sorts)
 	f->n_uploads_sorted = c->n_uploads_sorted;
 	std::swap(*c, *f);
@@ -620,6 +656,22 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 	HIP_TRY(c, hipMemcpyAsync(c->d_tile_pairs, tp.data(), ntp * sizeof(int2), hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream)); // `tp` dies with this function
 	c->n_tile_pairs = (int)ntp;
+
+	if (c->sweep_tiles != nt) { // work table of the fast pair sweep: a function of the tile count
+		const int nb = pair_sweep_blocks(nt, nullptr);
+		std::vector<int2> blocks((size_t)nb);
+		pair_sweep_blocks(nt, blocks.data());
+		if ((size_t)nb > c->cap_sweep_blocks) {
+			dev_free(c, &c->d_sweep_blocks, c->cap_sweep_blocks);
+			c->cap_sweep_blocks = 0;
+			if ((rc = dev_alloc(c, &c->d_sweep_blocks, (size_t)nb)) != MPMC_OK) return rc;
+			c->cap_sweep_blocks = (size_t)nb;
+		}
+		HIP_TRY(c, hipMemcpyAsync(c->d_sweep_blocks, blocks.data(), (size_t)nb * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream)); // `blocks` dies here
+		c->n_sweep_blocks = nb;
+		c->sweep_tiles = nt;
+	}
 
 	// j-range split of the per-atom (row) kernels: aim for >= ~4096 one-wave blocks
 	c->n_split = std::max(1, std::min(nt, (4096 + nt - 1) / nt));
@@ -756,6 +808,24 @@ extern "C" int mpmc_get_tile_stats(mpmc_ctx *c, int64_t out4[4]) {
 	}
 	return MPMC_OK;
 }
+
+// Measurement / A-B switches.  With a context: that context, from its next evaluation on; with a null context: the default that contexts
+// created afterwards in this process start from.  Nothing here changes a result beyond the last bits.
+//   pair_kernel   0 the fast sweep (kernels_pair.hip) where it applies and the table is large, 1 never (k_pair_fused), 2 wherever it applies
+extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) {
+	if (!key) return MPMC_ERR_ARG;
+	const std::string k(key);
+	if (k == "pair_kernel") {
+		const int v = (int)value;
+		if (v < 0 || v > 2) return MPMC_ERR_ARG;
+		if (c) c->pair_kernel = v;
+		else g_default_pair_kernel = v;
+		return MPMC_OK;
+	}
+	return MPMC_ERR_ARG;
+}
+// which kernel ran the pair pass of the last evaluation: 1 the fast sweep, 0 k_pair_fused
+extern "C" int mpmc_debug_last_pair_kernel(mpmc_ctx *c) { return c ? (c->last_pair_was_sweep ? 1 : 0) : -1; }
 
 // diagnostics only (tests assert that the order was really carried): uploads of the atom list that kept the order / that sorted
 extern "C" int mpmc_debug_upload_counts(mpmc_ctx *c, long long *out2) {

@@ -80,6 +80,18 @@ struct mpmc_ctx {
 	int n_panel_entries = 0, seg_tiles = -1; // entries of the table / the tile count its layout was made for
 	bool use_panels = true;          // MPMC_NO_PANELS=1: every tile pair through the single-tile-pair kernel (A/B comparisons)
 	bool panels_built = false;       // this evaluation's classes carry CLS_GROUPED bits and d_panels is valid
+	// the fast pair sweep (kernels_pair.hip): its erfc table, its work table { J, I0 } (depends on the tile count only) and the list of
+	// tile pairs it leaves to k_pair_fused (a tile with a frozen / chargeless / sigma- or epsilon-less atom: rebuilt with every upload)
+	double2 *d_erf_tab = nullptr;
+	int2 *d_sweep_blocks = nullptr;
+	size_t cap_sweep_blocks = 0;
+	int n_sweep_blocks = 0, sweep_tiles = -1;
+	int *d_generic_list = nullptr;
+	size_t cap_generic = 0;
+	int n_generic = 0;
+	std::vector<int> h_generic;
+	int pair_kernel = 0;             // 0: the sweep where it applies and the table is large (> kPairSplitMax tile pairs); 1: never; 2: wherever it applies (mpmc_debug_configure)
+	bool last_pair_was_sweep = false; // (diagnostics: which kernel the last evaluation's pair pass ran)
 	double4 *h_xyzq = nullptr;       // PINNED host mirror of d_xyzq (slot order, max_pad entries): position updates copy from it asynchronously;
 	hipEvent_t ev_xyzq = nullptr;    // marks the last copy out of it done -- whoever is about to write the mirror waits for that copy only
 	bool xyzq_in_flight = false;     // (mirror_guard), not for the evaluations queued behind it

@@ -385,7 +385,20 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			c->panels_built = true;
 		}
 		ProfScope p(c, MPMC_K_PAIR);
-		if (!(fp.store_only && !compact)) // (a store-only pass without a store to fill has nothing to do beyond the classes)
+		// the fast sweep (kernels_pair.hip) where it applies -- orthorhombic cell, Ewald electrostatics, alpha r_c inside its erfc table --
+		// and, by default, where the table is large (small tables: four waves per tile pair in k_pair_fused, a latency matter); the tile
+		// pairs with a special atom, which it skips, go through k_pair_fused on their list
+		const bool sweep = c->pair_kernel != 1 && c->use_dpp && c->d_sweep_blocks && (c->pair_kernel == 2 || fp.pair_waves == 1) &&
+		                   pair_sweep_covers(c->box, fp, c->ewald_alpha);
+		c->last_pair_was_sweep = sweep;
+		if (sweep) {
+			launch_pair_sweep(st, at, c->box, fp, c->n_molecules != c->n, c->d_sweep_blocks, c->n_sweep_blocks, c->d_cls,
+			                  (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->d_erf_tab, c->d_block_part, c->d_block_cnt, c->d_part,
+			                  compact ? c->d_ab : nullptr);
+			if (c->n_generic > 0)
+				launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_generic, c->d_block_part, c->d_block_cnt, c->d_part,
+				                  compact ? c->d_ab : nullptr, c->d_generic_list);
+		} else if (!(fp.store_only && !compact)) // (a store-only pass without a store to fill has nothing to do beyond the classes)
 			launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
 			                  compact ? c->d_ab : nullptr);
 	}

@@ -137,8 +137,30 @@ constexpr int kOneStreamMaxPairs = 1536;
 constexpr int kPairSplitMax = 8192;
 // every unordered pair once: energies + counts (block partials), static-field partials fpart[nt][n_pad][3],
 // Thole store ab[n_tile_pairs][64*64] (double2 = 16 B per pair)
+// tp_list (may be null): the launch covers the tile pairs tp_list[0 .. n_tile_pairs) only -- what the fast sweep below leaves to it
 void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
-                       const int *cls, int n_tile_pairs, double *block_part /*[ntp][2]*/, int *block_cnt /*[ntp][2]*/, double *fpart, double2 *ab);
+                       const int *cls, int n_tile_pairs, double *block_part /*[ntp][2]*/, int *block_cnt /*[ntp][2]*/, double *fpart, double2 *ab,
+                       const int *tp_list = nullptr);
+// ---- the fast pair sweep (kernels_pair.hip): orthorhombic cells, Ewald electrostatics, tile pairs of "plain" atoms ----
+struct PairSweepParams {
+	double ewald_alpha, polar_damp, thole_far_x;
+	int store;      // write the Thole tensor store
+	int nt;         // tiles
+	int have_shift; // tp_shift / CLS_UNIFORM_* are valid
+};
+// host: the device layout of the erfc table, 3 * 512 double2 = (c0,c1)[512], (c2,c3)[512], (c4,G)[512]  (erfc_table.cpp)
+constexpr int kErfTableDouble2 = 3 * 512;
+void erfc_table_device_layout(double2 *out /*[kErfTableDouble2]*/);
+// work table of the sweep: one workgroup per entry { J, I0 }, its four waves take the tile pairs (I0 .. I0+3, J); returns the
+// number of entries (out may be null: count only)
+int pair_sweep_blocks(int n_tiles, int2 *out);
+// whether the sweep can serve this evaluation (cell, switches, alpha r_c inside the erfc table); tile pairs with a special atom
+// (frozen, chargeless, sigma / epsilon zero or negative, dispersion coefficients) are skipped by it and must go through
+// launch_pair_fused with their list
+bool pair_sweep_covers(const Box &bx, const FusedParams &fp, double ewald_alpha);
+void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, bool intra /*some molecule has more than one atom*/,
+                       const int2 *blocks, int n_blocks, const int *cls, const double4 *tp_shift /*null: no uniform images*/,
+                       const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab);
 void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt);
 // LJ (+ counts) of a small system in ONE launch: no tile classes, the last-arriving block folds the partials and writes the scalar
 // vector [S_COUNT doubles][C_COUNT int64][seq] into pinned host memory (seq last: a host polling that slot finds the results

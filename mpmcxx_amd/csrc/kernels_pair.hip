@@ -1,0 +1,323 @@
+// kernels_pair.hip -- the pair sweep of the production path (orthorhombic cells, Ewald electrostatics), rebuilt for VALU issue.
+//
+// Same work as k_pair_fused (kernels_sym.hip): lj() (src/System.Energy.cpp:897-993), the erfc part of coulombic_real() (:1484-1510), the
+// real-space static field real_term() (:2900-2940, both atoms of a pair), the in-cutoff pair counts, and the Thole tensor store
+// (thole_amatrix :2694-2767 as 16 B per unordered pair) -- every unordered pair once, one wave per tile pair of 64 x 64 atoms, lane l
+// owning i-atom l, the j-side field accumulators rotating by one lane per step.  What changed is the instruction stream: the generic
+// kernel issues 160 VALU instructions per pair of which 97 are fp64 arithmetic (profiles/r02_pmc_stalls.txt), this one ~80:
+//
+//  * erfc and the Gaussian come from a TABLE in LDS instead of a degree-20 polynomial plus a range-reduced exp: 512 pieces of width
+//    1/128 in x = alpha r, per piece a degree-4 interpolant of erfcx(x) = exp(x^2) erfc(x) and G_k = exp(-x_k^2); exp(-x^2) =
+//    G_k exp(t) with |t| < 0.032 (degree 6).  Three ds_read_b128 gathers and 23 VALU instructions replace 57; relative error of erfc
+//    1.7e-14 over [0, 4) (tools/fit_erfc_table.py, tests/test_erfc_table.py).  The table is why a workgroup is four waves: they share it;
+//  * the four waves of a workgroup take four tile pairs (I0 .. I0+3, J) behind ONE j-tile image in LDS, stored as three double2
+//    arrays (x,y | z,q | sigma/2, 2 sqrt(eps)) and read with three ds_read_b128 per step (twice over, so that l + s never wraps);
+//  * per dimension with a tile-pair-wide periodic image (CLS_UNIFORM_*, k_classify) the displacement is  (x_i - x_j) - B img : two
+//    subtractions that round exactly like the reference's  d - B rint(R d)  (same operands, same order), instead of five operations.
+//    The squared distance is still  ((dx^2) + dy^2) + dz^2  unfused: pair inclusion stays bit-exact (pair_math.h);
+//  * tile pairs of "plain" atoms only (no frozen / chargeless / sigma- or epsilon-less atoms; padding is handled): no flag words, the
+//    exclusion logic is "same molecule" (INTRA) or nothing at all (every molecule one atom); everything else is left to k_pair_fused,
+//    which the host launches on the list of tile pairs with a special atom (launch_pair_fused ... tp_list);
+//  * in-cutoff counts are popcounts of the execution mask on the scalar unit, not per-lane counters; LJ / Coulomb / field code is
+//    spelled with fma where the reference's rounding does not decide a predicate.
+#include "kernels.h"
+#include "device_math.h"
+#include "erfc_table.inc"
+
+namespace mpmc {
+
+constexpr int kSweepWaves = 4;
+constexpr int kSpecialAtom = AF_FROZEN | AF_NULL_RD | AF_HAS_DISP | AF_NEG_SIGMA | AF_ZERO_SIGMA | AF_ZERO_Q; // (what pair_flags / lj_mix look at)
+constexpr double kTwoOverSqrtPi = 2.0 * kOneOverSqrtPi;
+
+__device__ __forceinline__ int sweep_tp_index(int I, int J, int nt) { return I * nt - (I * (I - 1)) / 2 + (J - I); }
+
+struct SweepI { // the i-atom a lane owns
+	double x, y, z, q, hs, e2; // position, charge, sigma / 2, 2 sqrt(epsilon)
+	int mol;
+};
+struct SweepAcc {
+	double e_lj, e_re;
+	double ex, ey, ez; // field on the i-atom
+	double gx, gy, gz; // field on the j-atom this lane is paired with (rotates)
+};
+
+// one step: lane l against j = slot jl of the (doubled) j-tile image
+template <int UM, bool FIELD, bool INTRA, bool PAD>
+__device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zq, const double2 *__restrict__ s_se,
+                                           const int *__restrict__ s_mol, const double2 *__restrict__ s_tab, const int jl, const int lane,
+                                           const SweepI &I, const double shx, const double shy, const double shz, const Box &bx,
+                                           const PairSweepParams &pp, const bool half, const bool i_real, const bool store,
+                                           double2 *__restrict__ ab_row /*this step's 64 slots of the tensor store (wave-uniform)*/, SweepAcc &A, int &n_lj,
+                                           int &n_es) {
+	const double2 xy = s_xy[jl], zq = s_zq[jl];
+	const double dx = I.x - xy.x, dy = I.y - xy.y, dz = I.z - zq.x;
+	// minimum image (src/System.cpp:1228-1246), diagonal cell: d - B rint(R d); with a tile-pair-wide image index B rint(R d) is shx
+	double ox, oy, oz;
+	if (UM & 1) ox = dx - shx;
+	else ox = dx - bx.b[0] * rint(bx.r[0] * dx);
+	if (UM & 2) oy = dy - shy;
+	else oy = dy - bx.b[4] * rint(bx.r[4] * dy);
+	if (UM & 4) oz = dz - shz;
+	else oz = dz - bx.b[8] * rint(bx.r[8] * dz);
+	const double ri2 = ((ox * ox) + oy * oy) + oz * oz;
+	const double ir = fast_rsqrt_1(ri2);
+	const double r = ri2 * ir;
+	int molj = 0;
+	if (INTRA) molj = s_mol[jl];
+	// lanes that form a real pair at this step: all of them, except in tile pairs with padding slots (PAD: the last tile) and in the
+	// closing half step of a diagonal tile pair (half, wave-uniform: the compiler peels that step)
+	bool ok = true;
+	if (PAD) ok = i_real && (s_mol[jl] >= 0);
+	if (half) ok = ok && (lane < 32);
+	const bool intra = INTRA && (I.mol == molj);
+
+	if (store) { // thole_amatrix couples every pair: no cutoff, no exclusions (:2694-2767)
+		const double ir2 = ir * ir;
+		const double ir3 = ir2 * ir, ir5 = (ir2 * ir2) * ir;
+		const double lr = pp.polar_damp * r;
+		double damp1 = 1.0, damp2 = 1.0;
+		if (__any(lr < pp.thole_far_x)) { // wave-uniform: beyond lambda r = kTholeFarX the damping is dropped (as in CLS_THOLE_FAR)
+			const double explr = exp_fast(-lr);
+			damp1 = fma(-explr, fma(lr, fma(0.5, lr, 1.0), 1.0), 1.0); // 1 - e^{-lr} (lr^2/2 + lr + 1)
+			damp2 = fma(-explr, (lr * lr) * (lr * (1.0 / 6.0)), damp1); // damp1 - e^{-lr} lr^3/6
+		}
+		double ta = damp1 * ir3, tb = (3.0 * damp2) * ir5;
+		if (PAD || half) {
+			ta = ok ? ta : 0.0;
+			tb = ok ? tb : 0.0;
+		}
+		ab_row[lane] = make_double2(ta, tb);
+	}
+
+	// the inclusion predicates, and the counts of the pairs they admit: wave-level masks and popcounts (scalar unit), taken OUTSIDE the
+	// divergent region.  t_es <= t_lj (pair_math.h Box), so the Coulomb pairs are a subset of the LJ shell.
+	const bool in_lj = ok && (ri2 <= bx.t_lj);          // rimg - 1e-12 < rc  (lj :934)
+	const bool in_es = ok && (ri2 <= bx.t_es);         // (implies in_lj)  !(rimg > rc)  (coulombic_real :1490, real_term :2917)
+	const bool lj_on = in_lj && !intra;                  // plain atoms: rd_excluded = es_excluded = same molecule (src/System.cpp:1035-1197)
+	n_lj += __popcll(__builtin_amdgcn_ballot_w64(lj_on));
+	n_es += __popcll(__builtin_amdgcn_ballot_w64(in_es && !intra));
+	asm volatile("" : "+s"(n_lj), "+s"(n_es)); // (the sums are wanted HERE, in scalar registers: sunk behind the divergent region the masks make a round trip through VGPRs)
+	if (in_lj) {
+		const double2 se = s_se[jl];
+		if (lj_on) {
+			const double sig = I.hs + se.x, e4 = I.e2 * se.y; // Lorentz-Berthelot: (s_i + s_j)/2, 4 sqrt(e_i e_j)
+			const double sr = sig * ir;
+			const double s3 = (sr * sr) * sr;
+			const double s6 = s3 * s3;
+			A.e_lj = fma(e4, fma(s6, s6, -s6), A.e_lj); // 4 eps (s^12 - s^6)  (:965-993)
+		}
+		if (in_es) {
+			const double x = r * pp.ewald_alpha;
+			const double xs = x * MPMC_ERFTAB_INV_H;
+			const int it = (int)xs;
+			const double dd = __builtin_amdgcn_fract(xs) - 0.5;
+			const double2 c01 = s_tab[it], c23 = s_tab[MPMC_ERFTAB_PIECES + it], c4g = s_tab[2 * MPMC_ERFTAB_PIECES + it];
+			const double w = fma(fma(fma(fma(c4g.x, dd, c23.y), dd, c23.x), dd, c01.y), dd, c01.x); // erfcx(x)
+			const double d = dd * (1.0 / MPMC_ERFTAB_INV_H);
+			const double t = -(d * fma(2.0, x, -d)); // x_k^2 - x^2
+			constexpr double e[MPMC_ERFTAB_EXP_DEG + 1] = {MPMC_ERFTAB_EXP_COEFFS};
+			double p = e[MPMC_ERFTAB_EXP_DEG];
+#pragma unroll
+			for (int k = MPMC_ERFTAB_EXP_DEG - 1; k >= 0; --k) p = hstep(p, t, e[k]);
+			const double G = c4g.y * p; // exp(-x^2)
+			if (!intra) A.e_re = fma((I.q * zq.y) * (G * w), ir, A.e_re); // q_i q_j erfc(alpha r) / r
+			if (FIELD) { // real_term :2919-2934: (2 alpha r / sqrt(pi) exp(-alpha^2 r^2) + erfc) / r^3, erf form (= that - 1) for excluded pairs
+				double B = G * fma(kTwoOverSqrtPi, x, w);
+				if (INTRA) B -= intra ? 1.0 : 0.0;
+				const double fac = B * ((ir * ir) * ir);
+				const double fj = fac * zq.y, fi = fac * I.q;
+				A.ex = fma(fj, ox, A.ex);
+				A.ey = fma(fj, oy, A.ey);
+				A.ez = fma(fj, oz, A.ez);
+				A.gx = fma(-fi, ox, A.gx);
+				A.gy = fma(-fi, oy, A.gy);
+				A.gz = fma(-fi, oz, A.gz);
+			}
+		}
+	}
+}
+
+template <int UM, bool FIELD, bool INTRA, bool PAD>
+__device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zq, const double2 *__restrict__ s_se,
+                                        const int *__restrict__ s_mol, const double2 *__restrict__ s_tab, const int lane, const SweepI &I,
+                                        const double shx, const double shy, const double shz, const Box &bx, const PairSweepParams &pp,
+                                        const bool diag, const bool i_real, const bool store,
+                                        double2 *__restrict__ ab_tile, SweepAcc &A, int &n_lj, int &n_es) {
+	// diagonal tile pair: s = 1..32, the last one with lanes 0..31 only (each pair once); off-diagonal: s = 0..63
+	const int s0 = diag ? 1 : 0, n = diag ? 32 : 64;
+	const int src4 = ((lane + 1) & 63) * 4;
+	for (int k = 0; k < n; ++k) {
+		const int s = s0 + k;
+		const bool last = (k == n - 1);
+		sweep_step<UM, FIELD, INTRA, PAD>(s_xy, s_zq, s_se, s_mol, s_tab, lane + s, lane, I, shx, shy, shz, bx, pp, diag && last, i_real, store,
+		                                  ab_tile + s * kTile, A, n_lj, n_es);
+		if (FIELD && !last) {
+			A.gx = rot_from_next<true>(A.gx, src4);
+			A.gy = rot_from_next<true>(A.gy, src4);
+			A.gz = rot_from_next<true>(A.gz, src4);
+		}
+	}
+}
+
+// blocks: { J, I0 } -- the workgroup's waves take the tile pairs (I0 + w, J), w = 0..3, as far as I0 + w <= J
+template <bool FIELD, bool INTRA>
+__global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Box bx, PairSweepParams pp, const int2 *__restrict__ blocks,
+                                                                 const int *__restrict__ cls, const double4 *__restrict__ tp_shift,
+                                                                 const double2 *__restrict__ erf_tab, double *__restrict__ block_part,
+                                                                 int *__restrict__ block_cnt, double *__restrict__ fpart /*[nt][n_pad][3]*/,
+                                                                 double2 *__restrict__ ab) {
+	__shared__ double2 s_tab[3 * MPMC_ERFTAB_PIECES];
+	__shared__ double2 s_xy[2 * kTile], s_zq[2 * kTile], s_se[2 * kTile];
+	__shared__ int s_mol[2 * kTile];
+	__shared__ int s_jflags[2];
+	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int2 blk = blocks[blockIdx.x];
+	const int J = __builtin_amdgcn_readfirstlane(blk.x), I = __builtin_amdgcn_readfirstlane(blk.y) + w;
+	const int j0 = J * kTile;
+#pragma unroll
+	for (int k = 0; k < (3 * MPMC_ERFTAB_PIECES) / (64 * kSweepWaves); ++k) s_tab[threadIdx.x + k * 64 * kSweepWaves] = erf_tab[threadIdx.x + k * 64 * kSweepWaves];
+	if (w == 0) { // the j-tile, every value twice (slot l + s never wraps)
+		const double4 pj = at.xyzq[j0 + lane];
+		const double2 lj = at.lj[j0 + lane];
+		const int2 mj = at.mf[j0 + lane];
+		s_xy[lane] = s_xy[lane + kTile] = make_double2(pj.x, pj.y);
+		s_zq[lane] = s_zq[lane + kTile] = make_double2(pj.z, pj.w);
+		s_se[lane] = s_se[lane + kTile] = make_double2(0.5 * lj.x, 2.0 * lj.y);
+		s_mol[lane] = s_mol[lane + kTile] = mj.x; // (padding slots carry negative ids)
+		const bool padj = (mj.y & AF_PAD) != 0;
+		const int any_spec = __any(!padj && (mj.y & kSpecialAtom) != 0), any_pad = __any(padj);
+		if (lane == 0) {
+			s_jflags[0] = any_spec;
+			s_jflags[1] = any_pad;
+		}
+	}
+	__syncthreads();
+	if (I > J) return; // (a j-tile's last workgroup may have fewer than four tile pairs)
+	const int nt = pp.nt;
+	const int tp = sweep_tp_index(I, J, nt);
+	const int i = I * kTile + lane;
+	const double4 pi = at.xyzq[i];
+	const double2 li = at.lj[i];
+	const int2 mi = at.mf[i];
+	const bool i_real = !(mi.y & AF_PAD);
+	// a tile pair with a special atom belongs to the generic kernel (the host launches it on exactly these: same predicate)
+	if (__builtin_amdgcn_readfirstlane(s_jflags[0]) || __any(i_real && (mi.y & kSpecialAtom) != 0)) return;
+	const bool pad = __builtin_amdgcn_readfirstlane(s_jflags[1]) || __any(!i_real);
+	const bool diag = (I == J);
+	const int cl = cls[tp];
+	const bool beyond = (cl & CLS_BEYOND_CUTOFF) != 0;
+	const bool store = pp.store && !(cl & CLS_THOLE_FAR);
+	const int nt_pad3 = at.n_pad * 3;
+	// (a tile pair beyond the cutoff whose tensors are stored all the same -- a cutoff shorter than the damping range -- takes the
+	// ordinary walk: no pair of it passes a cutoff predicate, by the class's construction)
+	if (beyond && !store) { // nothing to do: publish zeros so that the fixed-shape reductions stay valid
+		if (FIELD) {
+			double *oi = fpart + (size_t)J * nt_pad3 + 3 * (size_t)i;
+			double *oj = fpart + (size_t)I * nt_pad3 + 3 * (size_t)(j0 + lane);
+			oi[0] = oi[1] = oi[2] = 0.0;
+			oj[0] = oj[1] = oj[2] = 0.0;
+		}
+		if (lane == 0) {
+			block_part[2 * (size_t)tp] = 0.0;
+			block_part[2 * (size_t)tp + 1] = 0.0;
+			block_cnt[2 * (size_t)tp] = 0;
+			block_cnt[2 * (size_t)tp + 1] = 0;
+		}
+		return;
+	}
+	SweepI Ai;
+	Ai.x = pi.x, Ai.y = pi.y, Ai.z = pi.z, Ai.q = pi.w;
+	Ai.hs = 0.5 * li.x, Ai.e2 = 2.0 * li.y;
+	Ai.mol = mi.x;
+	const int um = (pp.have_shift && !pad) ? ((cl / CLS_UNIFORM_X) & 7) : 0; // (the padded tile's pairs take the general image path: one variant)
+	double shx = 0.0, shy = 0.0, shz = 0.0; // B img of the tile pair's common image, per uniform dimension (wave-uniform: scalar loads)
+	if (pp.have_shift) {
+		const double4 sh = tp_shift[tp];
+		shx = sh.x, shy = sh.y, shz = sh.z;
+	}
+	SweepAcc A = {};
+	int n_lj = 0, n_es = 0;
+	double2 *ab_tile = store ? ab + (size_t)tp * (kTile * kTile) : nullptr;
+#define MPMC_SWEEP(M) sweep_walk<M, FIELD, INTRA, false>(s_xy, s_zq, s_se, s_mol, s_tab, lane, Ai, shx, shy, shz, bx, pp, diag, i_real, store, ab_tile, A, n_lj, n_es)
+	switch (um) {
+	case 0:
+		if (pad) sweep_walk<0, FIELD, INTRA, true>(s_xy, s_zq, s_se, s_mol, s_tab, lane, Ai, shx, shy, shz, bx, pp, diag, i_real, store, ab_tile, A, n_lj, n_es);
+		else MPMC_SWEEP(0);
+		break;
+	case 1: MPMC_SWEEP(1); break;
+	case 2: MPMC_SWEEP(2); break;
+	case 3: MPMC_SWEEP(3); break;
+	case 4: MPMC_SWEEP(4); break;
+	case 5: MPMC_SWEEP(5); break;
+	case 6: MPMC_SWEEP(6); break;
+	default: MPMC_SWEEP(7); break;
+	}
+#undef MPMC_SWEEP
+
+	if (FIELD) {
+		const int jown = (lane + (diag ? 32 : 63)) & 63; // the j-atom whose accumulator this lane ended up holding
+		if (diag) { // both sides are the same 64 atoms: one slot [I][I atoms]; atom a's j-side sum sits in lane (a + 32) & 63 = a ^ 32
+			double *o = fpart + (size_t)I * nt_pad3 + 3 * (size_t)i;
+			o[0] = A.ex + __shfl(A.gx, lane ^ 32, 64);
+			o[1] = A.ey + __shfl(A.gy, lane ^ 32, 64);
+			o[2] = A.ez + __shfl(A.gz, lane ^ 32, 64);
+		} else {
+			double *oi = fpart + (size_t)J * nt_pad3 + 3 * (size_t)i; // i-atoms, contribution of tile J
+			oi[0] = A.ex;
+			oi[1] = A.ey;
+			oi[2] = A.ez;
+			double *oj = fpart + (size_t)I * nt_pad3 + 3 * (size_t)(j0 + jown); // j-atoms, contribution of tile I
+			oj[0] = A.gx;
+			oj[1] = A.gy;
+			oj[2] = A.gz;
+		}
+	}
+	const double e_lj = wave_sum(A.e_lj), e_re = wave_sum(A.e_re);
+	if (lane == 0) {
+		block_part[2 * (size_t)tp] = e_lj;
+		block_part[2 * (size_t)tp + 1] = e_re;
+		block_cnt[2 * (size_t)tp] = n_lj;
+		block_cnt[2 * (size_t)tp + 1] = n_es;
+	}
+}
+
+int pair_sweep_blocks(int n_tiles, int2 *out) {
+	int n = 0;
+	for (int J = 0; J < n_tiles; ++J)
+		for (int I0 = 0; I0 <= J; I0 += kSweepWaves) {
+			if (out) out[n] = make_int2(J, I0);
+			n++;
+		}
+	return n;
+}
+
+bool pair_sweep_covers(const Box &bx, const FusedParams &fp, double ewald_alpha) {
+	if (!bx.ortho || !fp.do_es || fp.do_field == 2 || fp.wolf || fp.fh_order || fp.store_only) return false;
+	if (fp.do_field == 1 && fp.polar_ewald_alpha != fp.ewald_alpha) return false;
+	const double tmax = (bx.t_lj > bx.t_es) ? bx.t_lj : bx.t_es;
+	return ewald_alpha * std::sqrt(tmax) * (1.0 + 1e-9) < MPMC_ERFTAB_XMAX; // every in-cutoff pair inside the table
+}
+
+void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, bool intra, const int2 *blocks, int n_blocks,
+                       const int *cls, const double4 *tp_shift, const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab) {
+	PairSweepParams pp;
+	pp.ewald_alpha = fp.ewald_alpha;
+	pp.polar_damp = fp.polar_damp;
+	pp.thole_far_x = fp.thole_far_x;
+	pp.store = (fp.do_thole && ab) ? 1 : 0;
+	pp.nt = at.n_pad / kTile;
+	pp.have_shift = tp_shift ? 1 : 0;
+	dim3 grid(n_blocks), block(64 * kSweepWaves);
+#define MPMC_PS(F, N) hipLaunchKernelGGL((k_pair_sweep<F, N>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab)
+	if (fp.do_field == 1) {
+		if (intra) MPMC_PS(true, true);
+		else MPMC_PS(true, false);
+	} else {
+		if (intra) MPMC_PS(false, true);
+		else MPMC_PS(false, false);
+	}
+#undef MPMC_PS
+}
+
+} // namespace mpmc

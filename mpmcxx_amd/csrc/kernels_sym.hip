@@ -61,7 +61,8 @@ struct PairTail {
 template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP, bool EXT = false, bool ALPHA2 = false, bool TAIL = false, int WAVES = (TAIL ? 4 : 1)>
 __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, FusedParams fp, const int2 *__restrict__ tile_pairs,
                                                    const int *__restrict__ cls, double *__restrict__ block_part, int *__restrict__ block_cnt,
-                                                   double *__restrict__ fpart /*[nt][n_pad][3]*/, double2 *__restrict__ ab, PairTail tail = PairTail{}) {
+                                                   double *__restrict__ fpart /*[nt][n_pad][3]*/, double2 *__restrict__ ab, PairTail tail = PairTail{},
+                                                   const int *__restrict__ tp_list = nullptr /*the tile pairs of this launch (null: all, block = tile pair)*/) {
 	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_q[kTile], s_sig[kTile], s_sqe[kTile];
 	__shared__ int s_mol[kTile], s_fl[kTile];
 	__shared__ double s_g[3 * kTile];
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, 
 	static_assert(!TAIL || WAVES == 4, "the single-launch form is the four-wave form");
 	constexpr int W = WAVES;
 	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int2 IJ = tile_pairs[blockIdx.x];
+	const int tp = (!TAIL && tp_list) ? tp_list[blockIdx.x] : (int)blockIdx.x;
+	const int2 IJ = tile_pairs[tp];
 	if (THOLE && fp.store_only && fp.touch_n >= 0) { // (block-uniform) a trial move: only the tile pairs of the moved atoms' tiles are rebuilt
 		bool hit = false;
 		for (int k = 0; k < fp.touch_n; ++k) hit = hit || (IJ.x == fp.touch[k]) || (IJ.y == fp.touch[k]);
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, 
 	const int j0 = IJ.y * kTile;
 	const int src4 = ((lane + 1) & 63) * 4;
 	// tile-pair class (wave-uniform): whole tile pair beyond the cutoff / beyond the Thole damping range
-	const int cl = TAIL ? 0 : cls[blockIdx.x]; // (the single-launch form of small systems carries no classes: every tile pair is "near")
+	const int cl = TAIL ? 0 : cls[tp]; // (the single-launch form of small systems carries no classes: every tile pair is "near")
 	const bool beyond = (cl & CLS_BEYOND_CUTOFF) != 0;
 	const bool store_thole = THOLE && !(cl & CLS_THOLE_FAR);
 	if (beyond && !store_thole) { // nothing position dependent to do: publish zeros so the fixed-shape reductions stay valid
@@ -93,10 +95,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, 
 			oj[0] = oj[1] = oj[2] = 0.0;
 		}
 		if (lane == 0) {
-			block_part[2 * (size_t)blockIdx.x] = 0.0;
-			block_part[2 * (size_t)blockIdx.x + 1] = 0.0;
-			block_cnt[2 * (size_t)blockIdx.x] = 0;
-			block_cnt[2 * (size_t)blockIdx.x + 1] = 0;
+			block_part[2 * (size_t)tp] = 0.0;
+			block_part[2 * (size_t)tp + 1] = 0.0;
+			block_cnt[2 * (size_t)tp] = 0;
+			block_cnt[2 * (size_t)tp + 1] = 0;
 		}
 		return;
 	}
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, 
 
 	// step order: diagonal tiles s = 1..32; off-diagonal tiles walk all 64 steps starting at a per-block offset
 	// (multiple of 4) so that concurrently running waves do not hit the same HBM channels in lock step
-	const int s_first = diag ? 1 : stagger_start(blockIdx.x), n_steps = diag ? 32 : 64;
-	double2 *ab_tile = store_thole ? ab + (size_t)blockIdx.x * (kTile * kTile) : nullptr;
+	const int s_first = diag ? 1 : stagger_start(tp), n_steps = diag ? 32 : 64;
+	double2 *ab_tile = store_thole ? ab + (size_t)tp * (kTile * kTile) : nullptr;
 
 	// "plain" tile pair (wave-uniform): no atom of either tile is frozen, padded, chargeless, has a zero / negative
 	// sigma, zero epsilon or dispersion coefficients -- then the exclusion logic of pair_exclusions collapses to
@@ -369,10 +371,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, 
 		}
 	}
 	if (lane == 0) {
-		block_part[2 * (size_t)blockIdx.x] = e_lj;
-		block_part[2 * (size_t)blockIdx.x + 1] = e_re;
-		block_cnt[2 * (size_t)blockIdx.x] = n_lj;
-		block_cnt[2 * (size_t)blockIdx.x + 1] = n_es;
+		block_part[2 * (size_t)tp] = e_lj;
+		block_part[2 * (size_t)tp + 1] = e_re;
+		block_cnt[2 * (size_t)tp] = n_lj;
+		block_cnt[2 * (size_t)tp + 1] = n_es;
 	}
 	if (TAIL) {
 		// last-arriving block: everybody publishes its partials (release), takes a ticket; the holder of the last ticket sees them all
@@ -419,50 +421,50 @@ __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, 
 
 template <bool ORTHO, bool ES, int FIELD, bool THOLE>
 static void launch_fused_t(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, const int *cls,
-                           int ntp, double *bpart, int *bcnt, double *fpart, double2 *ab) {
+                           int ntp, double *bpart, int *bcnt, double *fpart, double2 *ab, const int *tp_list) {
 	if (FIELD == 1 && fp.polar_ewald_alpha != fp.ewald_alpha) { // two different Ewald alphas: every extension compiled in, ds_bpermute or DPP
 		if (dpp)
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
 		else
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
 		return;
 	}
 	if ((ES && fp.wolf) || fp.fh_order) { // extended variant (Wolf / Feynman-Hibbs): DPP rotation only when the self-test allows it
 		if (dpp)
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
 		else
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
 		return;
 	}
 	if (fp.pair_waves == 4) { // small table: four waves per tile pair
 		if (dpp)
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, false, false, false, 4>), dim3(ntp), dim3(4 * kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, false, false, false, 4>), dim3(ntp), dim3(4 * kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
 		else
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, false, false, false, 4>), dim3(ntp), dim3(4 * kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, false, false, false, 4>), dim3(ntp), dim3(4 * kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
 		return;
 	}
 	if (dpp)
-		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
 	else
-		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab);
+		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
 }
 
 template <bool ORTHO>
 static void launch_fused_o(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, const int *cls,
-                           int ntp, double *bpart, int *bcnt, double *fpart, double2 *ab) {
+                           int ntp, double *bpart, int *bcnt, double *fpart, double2 *ab, const int *tp_list) {
 	const bool thole = fp.do_thole && ab;
 	if (!fp.do_es && thole) // (store-only sweeps of polarizable trial moves)
-		launch_fused_t<ORTHO, false, 0, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
+		launch_fused_t<ORTHO, false, 0, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
 	else if (!fp.do_es)
-		launch_fused_t<ORTHO, false, 0, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
+		launch_fused_t<ORTHO, false, 0, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
 	else if (fp.do_field == 0)
-		launch_fused_t<ORTHO, true, 0, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
+		launch_fused_t<ORTHO, true, 0, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
 	else if (fp.do_field == 1) {
-		if (thole) launch_fused_t<ORTHO, true, 1, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
-		else launch_fused_t<ORTHO, true, 1, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
+		if (thole) launch_fused_t<ORTHO, true, 1, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
+		else launch_fused_t<ORTHO, true, 1, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
 	} else {
-		if (thole) launch_fused_t<ORTHO, true, 2, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
-		else launch_fused_t<ORTHO, true, 2, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab);
+		if (thole) launch_fused_t<ORTHO, true, 2, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
+		else launch_fused_t<ORTHO, true, 2, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
 	}
 }
 
@@ -484,9 +486,10 @@ void launch_pair_lj_single(hipStream_t st, bool dpp, const AtomsDev &at, const B
 }
 
 void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
-                       const int *cls, int n_tile_pairs, double *block_part, int *block_cnt, double *fpart, double2 *ab) {
-	if (bx.ortho) launch_fused_o<true>(st, dpp, at, bx, fp, tile_pairs, cls, n_tile_pairs, block_part, block_cnt, fpart, ab);
-	else launch_fused_o<false>(st, dpp, at, bx, fp, tile_pairs, cls, n_tile_pairs, block_part, block_cnt, fpart, ab);
+                       const int *cls, int n_tile_pairs, double *block_part, int *block_cnt, double *fpart, double2 *ab, const int *tp_list) {
+	if (n_tile_pairs <= 0) return;
+	if (bx.ortho) launch_fused_o<true>(st, dpp, at, bx, fp, tile_pairs, cls, n_tile_pairs, block_part, block_cnt, fpart, ab, tp_list);
+	else launch_fused_o<false>(st, dpp, at, bx, fp, tile_pairs, cls, n_tile_pairs, block_part, block_cnt, fpart, ab, tp_list);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -141,8 +141,18 @@ def lib():
     L.mpmc_comm_allgather_f64.argtypes = [vp, dp, C.c_int64, dp]
     L.mpmc_pi_gather_beads.argtypes = [vp, dp, C.c_int, C.c_int, dp]
     L.mpmc_pi_allreduce.argtypes = [C.POINTER(vp), C.c_int, dp, C.POINTER(Result), C.POINTER(C.c_int)]
+    L.mpmc_debug_configure.argtypes = [vp, C.c_char_p, C.c_double]
+    L.mpmc_debug_last_pair_kernel.argtypes = [vp]
+    L.mpmc_debug_erfc_table.argtypes = [C.c_double, dp, dp]
     _lib = L
     return L
+
+
+def configure(key: str, value: float):
+    """measurement / A-B switch for contexts created AFTER this call (mpmc_debug_configure with a null context)."""
+    rc = lib().mpmc_debug_configure(None, key.encode(), float(value))
+    if rc != MPMC_OK:
+        raise MpmcError(rc, f"mpmc_debug_configure: unknown key or bad value: {key}={value}")
 
 
 def _dp(a: Optional[np.ndarray]):
@@ -228,6 +238,13 @@ class System:
     @property
     def handle(self) -> C.c_void_p:
         return self._h
+
+    def configure(self, key: str, value: float):
+        """measurement / A-B switch of THIS context (see mpmc_debug_configure in csrc/context.cpp)."""
+        self._check(self._L.mpmc_debug_configure(self._h, key.encode(), float(value)))
+
+    def last_pair_kernel(self) -> str:
+        return "sweep" if self._L.mpmc_debug_last_pair_kernel(self._h) == 1 else "fused"
 
     # -- state ------------------------------------------------------------------------------------------------
     def set_box(self, basis: np.ndarray):
