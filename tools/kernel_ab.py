@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Same-process A/B of kernel variants on ONE bead of the benchmark box (10 000 polarizable atoms).
 
-usage: python tools/kernel_ab.py "label:ENV=v,ENV=v" ...        (an empty env list = defaults)
+usage: python tools/kernel_ab.py "label:ENV=v,@key=v" ...        (an empty list = defaults; @key=v: energy.configure(key, v), i.e.
+       mpmc_debug_configure -- e.g. "fused:@pair_kernel=1" "sweep:@pair_kernel=2")
 
 Each variant gets a fresh context created under its environment (the library reads its MPMC_* toggles at
 mpmc_ctx_create), 2 warm-up evaluations, then `reps` profiled evaluations; prints HIP-event ms per launch of every
@@ -27,11 +28,18 @@ for rnd in (1, 2):
     for spec in specs:
         label, _, envs = spec.partition(":")
         added = []
+        cfg = []
         for kv in filter(None, envs.split(",")):
             k, _, v = kv.partition("=")
-            os.environ[k] = v
-            added.append(k)
+            if k.startswith("@"):
+                energy.configure(k[1:], float(v))
+                cfg.append(k[1:])
+            else:
+                os.environ[k] = v
+                added.append(k)
         S = energy.System(atoms, basis, opts)
+        for k in cfg:
+            energy.configure(k, 0)
         for _ in range(2):
             e = S.energy()
         S.set_profiling(True)
