@@ -37,17 +37,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# Algorithmic fp64 flops per unordered pair, counted the way the 78.6 TFLOP/s peak is: one FMA = 2 flops.
-#   Jacobi contraction, tensor (a, b) read from the store: d = r_i - r_j 3, minimum image 3 x (mul, rint, fma) 9 [rint not counted],
-#     mu_j.d and mu_i.d 2 x (mul + 2 fma) 10, b x dot 2, E_i += a mu_j - (b mu_j.d) d and the same for E_j 2 x 6 fma 24         = 48
-#   ... tensor recomputed (far field): + r^2 (mul + 2 fma) 5, 1/r = rsq + one Newton step 7, 1/r^3 and 3/r^5 4                 = 64
-#   pair sweep: d + minimum image 12, r^2 5, 1/r 8 = 25 for every pair; inside the cutoff (52.3 % of the pairs of the benchmark box)
-#     LJ 11, erfc(x) exp(-x^2) 85 (two Horner polynomials of 20 + 11 FMA, range reduction, one reciprocal), Coulomb 4, field factor and
-#     both atoms 20 = 120; Thole damping + (a, b) 49 for the pairs of the stored tile pairs (36 %)          25 + 0.523 x 120 + 0.36 x 49 = 105
-#   reciprocal space: K N (6 + ~40) for the structure factors, the same again for the field                      2 x 0.33 GFLOP
-FLOP_PAIR_STORED, FLOP_PAIR_FAR, FLOP_PAIR_SWEEP = 48.0, 64.0, 105.0
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec; the fp64 matrix peak is the same number)
+# Algorithmic fp64 flops per unordered pair, counted the way the peak is: FMA = 2, add / sub / mul = 1, v_rsq / v_rcp = 1;
+# rounding (v_rndne), conversions, compares and lane moves are NOT flops.  "nu" = dimensions of the pair's tile pair WITHOUT a
+# tile-pair-wide periodic image (k_classify): there the minimum image costs mul + (rint) + fma = 3 (Jacobi kernels, which may fuse) or
+# mul + (rint) + mul + sub = 3 (pair sweep, unfused: the squared distance decides pair inclusion and must round like the reference);
+# a uniform dimension costs nothing in the Jacobi kernels (the i-atom is shifted once) and 1 subtraction in the pair sweep.
+#   Jacobi contraction, (a, b) read from the store:  d 3,  mu_j.d and mu_i.d 2 x (mul + 2 fma) 10,  b x dot 2,
+#       F_i += -a mu_j + (b mu_j.d) d and the same for F_j: 12 fma 24                                                   = 39 + 3 nu
+#   ... recomputed (far field): + r^2 (mul + 2 fma) 5, 1/r = rsq 1 + one Newton step (2 mul + 2 fma) 6, 1/r^3 and 3/r^5 4   = 55 + 3 nu
+#   pair sweep (k_pair_sweep), every walked pair: d 3, image nu x 3 + (3 - nu) x 1, r^2 (3 mul + 2 add) 5, 1/r 7, r 1  = 19 + 2 nu
+#       inside the cutoff: LJ (add, 6 mul, 2 fma) 11 - 1 = 10;  erfc and Gaussian from the LDS table: x, x / h, centring 3, degree-4
+#       interpolant 8, t = x_k^2 - x^2 4, exp(t) degree 6 12, G_k exp(t) 1, q_i q_j erfc / r (3 mul + fma) 5 = 33;  field factor
+#       (fma, 5 mul) 7 + 6 fma 12 + 1 = 20                                                                           = 63
+#       Thole damping and (a, b) for the pairs of the stored tile pairs: 1/r^3, 1/r^5 4, lambda r 1, exp 28, polynomials 11, a, b 3   = 47
+#   reciprocal space: K N (6 + ~40) for the structure factors, the same again for the field
+FLOP_JAC_STORED, FLOP_JAC_FAR, FLOP_JAC_PER_NU = 39.0, 55.0, 3.0
+FLOP_SWEEP_BASE, FLOP_SWEEP_PER_NU, FLOP_SWEEP_CUTOFF, FLOP_SWEEP_STORE = 19.0, 2.0, 63.0, 47.0
 FLOP_RECIP_PER_K_ATOM = 2 * 46.0
-FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec)
 
 
 def build_case(natoms: int, workdir: str):
@@ -163,12 +170,25 @@ def main():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the multi-rank path on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this device")
+    ap.add_argument("--beads-per-gpu-rehearsal", type=int, default=0,
+                    help="one GPU, N beads in flight on it -- the per-GPU load of an (--beads / N)-GPU run, everything else as in that run: the "
+                         "rate a GPU of the multi-GPU job can reach before the 4-double collective (N = 4: the 8-GPU case); NOT the headline")
+    ap.add_argument("--configure", action="append", default=[], metavar="KEY=VALUE",
+                    help="measurement switch for every context of this run (mpmc_debug_configure, e.g. side_stream=0 pair_kernel=1); repeatable")
     args = ap.parse_args()
 
+    # RCCL and CUDA-tensor sharing between the processes of one node go through dmabuf IPC on this pool: the host driver does not support
+    # the legacy IPC mode, and without this variable the first multi-process collective fails with "hipIpcGetMemHandle: invalid argument".
+    # It must be in the environment before the HIP runtime starts, i.e. before torch is imported (a no-op for one rank).
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
     from mpmcxx_amd import energy, pi
+
+    for kv in args.configure:
+        k_, _, v_ = kv.partition("=")
+        energy.configure(k_, float(v_))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -201,7 +221,10 @@ def main():
         # rank 0 makes the RCCL unique id, the launcher's channel (torch.distributed) carries its 128 bytes, every rank joins.
         # ncclCommInitRank blocks until ALL ranks have called it, so first make sure every rank can open RCCL below Python at all.
         ok = 1
-        ready = torch.tensor([1 if rccl_ver else 0], dtype=torch.int32, device=dev)
+        # ... and that everything a rank does on its own before the blocking ncclCommInitRank can succeed there (device index valid, RCCL
+        # symbols resolved): a rank that failed one of these alone would leave the others waiting inside the collective initialisation
+        ready_here = 1 if (rccl_ver and 0 <= local_rank < energy.device_count()) else 0
+        ready = torch.tensor([ready_here], dtype=torch.int32, device=dev)
         dist.all_reduce(ready, op=dist.ReduceOp.MIN)
         uid = [None]
         if int(ready.item()) == 1:
@@ -230,6 +253,11 @@ def main():
     P = args.beads
     if P % world:
         raise SystemExit("--beads must be a multiple of --gpus")
+    rehearsal = int(args.beads_per_gpu_rehearsal)
+    if rehearsal:
+        if world != 1:
+            raise SystemExit("--beads-per-gpu-rehearsal is a one-GPU run")
+        P = rehearsal
     workdir = tempfile.mkdtemp(prefix="mpmc_bench_")
     atoms, basis, opts = build_case(args.natoms, workdir)
     opts = dict(opts)
@@ -247,14 +275,16 @@ def main():
     state = {"host_positions": bool(args.host_positions), "per": None}
 
     def local_eval():
-        if state["host_positions"]:  # the boundary as the reference's adapter uses it: positions arrive in host memory every call
-            for s, hp in zip(beads, host_pos):
-                s.update_positions(0, hp)
+        # host_positions: the boundary as a host program with its own coordinates uses it -- every bead's positions arrive in host memory
+        # inside the call (mpmc_pi_potential_local_host: bead b's upload is followed at once by its enqueue)
+        hp = host_pos if state["host_positions"] else None
         if args.concurrency == "async":
-            _, per, failed = energy.pi_potential_local(beads)
+            _, per, failed = energy.pi_potential_local(beads, host_positions=hp)
         else:
             per = []
-            for s in beads:
+            for k, s in enumerate(beads):
+                if hp is not None:
+                    s.update_positions(0, hp[k])
                 s.energy()
                 per.append(s.observables)
         state["per"] = per
@@ -320,81 +350,60 @@ def main():
         d2, _, _ = timed(k_pcie)
         state["host_positions"] = False
         pcie = {"value": P * k_pcie / d2, "steps": k_pcie,
-                "what": "the same step with every bead's 10 000 positions handed over in host memory (mpmc_update_positions: one 320 KB upload per "
-                        "bead) inside every timed step -- the boundary as the reference-side adapter uses it"}
+                "what": "the same step with every bead's 10 000 positions handed over in host memory inside every timed step "
+                        "(mpmc_pi_potential_local_host: one 320 KB upload per bead from the context's pinned mirror, bead b's upload followed at "
+                        "once by its enqueue) -- the boundary as a host program that owns the coordinates uses it"}
 
-    # ---- the kernels with NOTHING else on the GPU: untimed passes, one bead at a time on one stream (HIP events again) ----------
-    iso = iso_split = None
-    back_to_back = {}  # kernel -> ms per launch, many launches back to back between one pair of HIP events (isolated pass)
+    # ---- the kernels with NOTHING else on the GPU: untimed pass, one bead on one stream (HIP events on that stream) -------------
+    iso = None
+    back_to_back = {}  # kernel class -> ms per launch, 100 launches back to back between ONE pair of HIP events
+    pairs = beads[0].pair_stats() if beads else {}
     if rank == 0 and not args.no_extra_passes and world == 1:  # (with several ranks nobody is kept waiting in a barrier: in-region durations only)
-        def fresh(env, count):
-            old = {k: os.environ.get(k) for k in env}
-            os.environ.update(env)
+        energy.configure("side_stream", 0)  # one stream: every kernel alone on the GPU
+        try:
+            a = dict(atoms)
+            a["pos"] = bead_positions(atoms["pos"], mine[0])
+            S1 = energy.System(a, basis, opts, device=local_rank)
+        finally:
+            energy.configure("side_stream", -1)
+        S1.energy()  # warm-up (uploads, buffers)
+        S1.set_profiling(True)
+        for _ in range(3):
+            S1.energy()
+        iso = collect([S1])
+        S1.set_profiling(False)
+        S1.energy()
+        for which, key in (("panel", "dipole_iter"), ("pair", "pair")):
             try:
-                out = []
-                for b in mine[:count]:
-                    a = dict(atoms)
-                    a["pos"] = bead_positions(atoms["pos"], b)
-                    out.append(energy.System(a, basis, opts, device=local_rank))
-            finally:
-                for k_, v_ in old.items():
-                    if v_ is None:
-                        os.environ.pop(k_, None)
-                    else:
-                        os.environ[k_] = v_
-            return out
-
-        def run_iso(systems, reps=3, time_panel=False):
-            for s in systems:
-                s.energy()  # warm-up (uploads, buffers)
-                s.set_profiling(True)
-            for _ in range(reps):
-                for s in systems:
-                    s.energy()
-            t = collect(systems)
-            if time_panel and args.solver != "dense":
-                # the dominant kernel 100 times back to back between ONE pair of HIP events on its stream: a launch's duration without the
-                # two event records that bracket every single launch in the profiling mode above
-                import ctypes as C_
-                L_ = energy.lib()
-                L_.mpmc_debug_time_panel.argtypes = [C_.c_void_p, C_.c_int, C_.POINTER(C_.c_double)]
-                systems[0].set_profiling(False)
-                systems[0].energy()
-                v = C_.c_double(0.0)
-                if L_.mpmc_debug_time_panel(systems[0].handle, 100, C_.byref(v)) == 0 and v.value > 0:
-                    back_to_back["dipole_iter"] = v.value
-            for s in systems:
-                s.close()
-            return t
-
-        iso = run_iso(fresh({"MPMC_ONE_STREAM": "1"}, 1), time_panel=True)  # production kernels, one stream: every kernel alone on the GPU
-        # the Jacobi contraction as two kernels (MPMC_JACOBI=split): k_dipole_iter_stream is the pure HBM-streaming part,
-        # k_dipole_iter_far the pure fp64 part of the default single-launch kernel
-        iso_split = run_iso(fresh({"MPMC_JACOBI": "split", "MPMC_ONE_STREAM": "1"}, 1), reps=2)
+                back_to_back[key] = S1.time_kernel(which, 100 if which == "panel" else 30)
+            except energy.MpmcError:
+                pass  # (dense / matrix-free solver: no panel kernel)
+        pair_kernel_name = "k_pair_sweep" if S1.last_pair_kernel() == "sweep" else "k_pair_fused"
+        S1.close()
+    else:
+        pair_kernel_name = "k_pair_sweep"
     if world > 1:
         dist.barrier()
 
-    try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
-        pmc_traffic = {}
-        for rnd in ("r01", "r02"):
+    try:  # per-launch PMC figures of the committed profiling passes (rocprofv3 cannot run inside this process): HBM bytes, executed flops
+        pmc = {}
+        for rnd in ("r01", "r02", "r03"):
             pth = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
             if os.path.exists(pth):
                 with open(pth) as f:
-                    pmc_traffic.update(json.load(f))
+                    pmc.update(json.load(f))
     except (OSError, ValueError):
-        pmc_traffic = {}
-    n_pairs_all = n * (n - 1) // 2
-    n_pairs_stored = tiles["thole_stored"] * 4096
-    n_pairs_far = tiles["thole_far"] * 4096
+        pmc = {}
     K = 709 if int(opts.get("ewald_kmax", 7)) == 7 else None
-    flops_jacobi = FLOP_PAIR_STORED * n_pairs_stored + FLOP_PAIR_FAR * n_pairs_far
-    flops_pair = FLOP_PAIR_SWEEP * n_pairs_all
+    cut_frac = 0.0
+    if gpu_bead0 and pairs.get("pairs"):
+        cut_frac = float(gpu_bead0["n_es_in_cutoff"]) / pairs["pairs"]
+    flops_jacobi = (FLOP_JAC_STORED * pairs.get("pairs_stored", 0) + FLOP_JAC_FAR * pairs.get("pairs_far", 0)
+                    + FLOP_JAC_PER_NU * (pairs.get("nonuniform_dims_x_pairs_stored", 0) + pairs.get("nonuniform_dims_x_pairs_far", 0)))
+    flops_pair = (FLOP_SWEEP_BASE * pairs.get("pairs_swept", 0) + FLOP_SWEEP_PER_NU * pairs.get("nonuniform_dims_x_pairs_swept", 0)
+                  + FLOP_SWEEP_CUTOFF * cut_frac * pairs.get("pairs", 0) + FLOP_SWEEP_STORE * pairs.get("pairs_stored", 0))
     flops_eval = flops_pair + iters * flops_jacobi + (FLOP_RECIP_PER_K_ATOM * K * n if K else 0.0)
-    bytes_jacobi = 16.0 * n_pairs_stored + n * 80.0
-
-    def avg_ms(t, k):
-        tv = (t or {}).get(k, {"ms": 0.0, "launches": 0})
-        return tv["ms"] / tv["launches"] if tv["launches"] else None
+    bytes_jacobi = 16.0 * 4096 * pairs.get("tile_pairs_stored", 0) + n * 80.0
 
     if rank == 0:
         evals = P * args.steps
@@ -404,22 +413,35 @@ def main():
         solver_used = "dense" if args.solver == "dense" else ("compact" if mem_tensor > 0 else "matrix_free")
         in_region = {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in agg.items() if tv["launches"]}
         alone = {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in (iso or {}).items() if tv["launches"]}
-        split = {k: round(tv["ms"] / max(tv["launches"], 1), 6) for k, tv in (iso_split or {}).items() if tv["launches"]}
 
-        def compute_entry(kernel, ms, flops, launches_per_step, extra=None):
+        def compute_entry(kernel, cls_key, src, flops, launches_per_step):
+            """fp64 vector-issue roofline of one kernel.  avg_launch_ms: HIP events on the kernel's stream (alone on the GPU where the
+            isolated pass ran); achieved = algorithmic flops / that duration."""
+            ms = back_to_back.get(cls_key) or src.get(cls_key) or 1e30
             ach = flops / (ms * 1e-3) / 1e12
-            e = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
-                 "traffic": None, "avg_launch_ms": ms, "launches_per_step": launches_per_step, "algorithmic_flops_per_launch": flops,
-                 "consistent": bool(ms * launches_per_step <= ms_per_step)}
-            if extra:
-                e.update(extra)
+            e = {"bound": "fp64_valu", "kernel": kernel, "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": ach / FP64_VALU_PEAK_TFLOPS, "frac_algorithmic": ach / FP64_VALU_PEAK_TFLOPS, "frac_executed": None, "traffic": None,
+                 "avg_launch_ms": ms, "launches_per_step": launches_per_step, "algorithmic_flops_per_launch": flops,
+                 "consistent": bool(ms * launches_per_step <= ms_per_step),
+                 "clock": ("100 launches back to back between ONE pair of HIP events on the kernel's stream, per launch (kernel alone on the GPU)"
+                           if back_to_back.get(cls_key) else "HIP events around every launch on the kernel's stream")}
+            if src.get(cls_key) and back_to_back.get(cls_key):
+                e["avg_launch_ms_event_pair_per_launch"] = src[cls_key]
+            t = pmc.get(kernel)
+            if t and t.get("natoms") == n:
+                e["traffic"] = t.get("hbm_bytes_per_launch")
+                e["pmc"] = t
+                if t.get("trace_avg_launch_ms"):
+                    e["frac_by_trace_clock"] = flops / (t["trace_avg_launch_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
+                if t.get("executed_flops_per_launch"):
+                    e["frac_executed"] = t["executed_flops_per_launch"] / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
             return e
 
         # dominant kernel: the one with the largest share of the device time of an evaluation (alone-on-the-GPU durations)
         src = alone if alone else in_region
         share = {"dipole_iter": (src.get("dipole_iter") or 0.0) * iters, "pair": src.get("pair") or 0.0}
         dom = max(share, key=share.get) if any(share.values()) else "dipole_iter"
-        jac_kernel = "k_dense_matvec" if solver_used == "dense" else ("k_dipole_iter_panel" if not os.environ.get("MPMC_NO_PANELS") else "k_dipole_iter_hybrid")
+        jac_kernel = "k_dense_matvec" if solver_used == "dense" else ("k_dipole_iter_panel" if solver_used == "compact" else "k_dipole_iter_hybrid")
         if solver_used == "dense":  # the reference's 3N x 3N layout, contraction on v_mfma_f64_16x16x4_f64: HBM-bound
             n3 = 3 * ((n + 63) // 64 * 64)
             ms = src.get("dipole_iter") or 1e30
@@ -430,32 +452,24 @@ def main():
                     "consistent": bool(ms * iters * n_local <= ms_per_step),
                     "mfma_side": {"issued_tflops": 2.0 * n3 * n3 * 16 / (ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS, "useful_fraction": 1.0 / 16.0}}
         elif dom == "pair":
-            roof = compute_entry("k_pair_fused", src["pair"], flops_pair, n_local)
+            roof = compute_entry(pair_kernel_name, "pair", src, flops_pair, n_local)
         else:
-            ms = src.get("dipole_iter") or 1e30
-            roof = compute_entry(jac_kernel, ms, flops_jacobi, iters * n_local)
-            if alone and back_to_back.get("dipole_iter"):
-                # cross-check of the per-launch event brackets: 100 launches back to back between ONE pair of events.  The two agree
-                # (92.7 against 92.9 us when this was written): the event records are not what separates them from rocprofv3's kernel trace
-                # (86 us) -- that is the dispatch / completion time between consecutive kernels of a stream, which the trace's begin and end
-                # stamps leave out and any wall-clock measure of a launch includes
-                roof["avg_launch_ms_back_to_back"] = back_to_back["dipole_iter"]
-            tr = pmc_traffic.get(jac_kernel)
-            if tr and tr.get("natoms") == n:
-                roof["traffic"] = tr["hbm_bytes_per_launch"]
-                roof["traffic_source"] = tr["source"]
+            roof = compute_entry(jac_kernel, "dipole_iter", src, flops_jacobi, iters * n_local)
+            ms = roof["avg_launch_ms"]
             roof["hbm_side"] = {"achieved": bytes_jacobi / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": bytes_jacobi / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_jacobi}
-        roof["measured"] = ("HIP events on the stream the kernel is launched on, extra pass right after the timed region: one bead, one stream, the kernel "
-                            "ALONE on the GPU, every launch between two event records of its own"
-                            + ("; avg_launch_ms_back_to_back = 100 launches between ONE pair of events, per launch (agrees: the brackets cost nothing "
-                               "measurable).  rocprofv3 --kernel-trace reports ~6 us less for the same kernel (profiles/*_serial_kernel_stats.csv): its stamps "
-                               "leave out the dispatch / completion time between consecutive kernels of a stream, which a launch as timed here includes"
-                               if back_to_back.get("dipole_iter") and dom != "pair" and solver_used != "dense" else "") if alone else
-                            "HIP events on one bead's stream over the timed region (beads overlap: stretched durations)")
+        roof["measured"] = ("extra pass right after the timed region: ONE bead on ONE stream, every kernel alone on the GPU.  rocprofv3 --kernel-trace "
+                            "reports less for the same launch (profiles/*_serial_kernel_stats.csv; frac_by_trace_clock): its begin / end stamps leave "
+                            "out the dispatch and completion time between consecutive kernels of a stream, which every wall-clock measure includes"
+                            if alone else "HIP events on one bead's stream over the timed region (beads overlap: stretched durations)")
         if not roof["consistent"]:  # cannot happen while other kernels share the step; if it does, the whole-step figure is the honest one
             roof["note_inconsistent"] = "avg_launch_ms x launches_per_step exceeds ms_per_step: use whole_step"
         roof["tile_pairs"] = tiles
+        roof["pairs"] = dict(pairs, in_cutoff_fraction=cut_frac)
+        roof["flop_model"] = {"jacobi_stored": FLOP_JAC_STORED, "jacobi_far": FLOP_JAC_FAR, "jacobi_per_nonuniform_dim": FLOP_JAC_PER_NU,
+                              "sweep_base": FLOP_SWEEP_BASE, "sweep_per_nonuniform_dim": FLOP_SWEEP_PER_NU, "sweep_in_cutoff": FLOP_SWEEP_CUTOFF,
+                              "sweep_stored": FLOP_SWEEP_STORE, "what": "fp64 flops per unordered atom pair, FMA = 2 (top of bench.py, DESIGN.md section 3); "
+                                                                        "pair counts are exact atom pairs per tile-pair class (mpmc_debug_pair_stats)"}
         roof["share_of_device_time_alone"] = share[dom] / max(sum((src.get(k) or 0.0) * (iters if k in ("dipole_iter", "reduce") else 1) for k in src), 1e-30)
         # whole-step view, which overlap cannot distort: algorithmic flops of one evaluation x evaluations per second per GPU
         roof["whole_step"] = {"algorithmic_flops_per_eval": flops_eval, "achieved": flops_eval * value / world / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
@@ -465,26 +479,16 @@ def main():
         roof["in_timed_region"] = {"kernel_ms": in_region,
                                    "note": f"{args.concurrency}: {n_local} beads in flight on this GPU, HIP events on one bead's stream; a launch here "
                                            "shares the CUs with other beads' kernels, so its duration is stretched -- not a kernel time"}
-        if in_region.get("dipole_iter") and solver_used != "dense":
-            roof["in_timed_region"]["dipole_iter_frac_if_taken_as_kernel_time"] = flops_jacobi / (in_region["dipole_iter"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
         other = {}
         if alone.get("pair") and dom != "pair":
-            other["pair"] = compute_entry("k_pair_fused", alone["pair"], flops_pair, n_local)
+            other["pair"] = compute_entry(pair_kernel_name, "pair", src, flops_pair, n_local)
         if alone.get("dipole_iter") and dom == "pair" and solver_used != "dense":
-            other["dipole_iter"] = compute_entry(jac_kernel, alone["dipole_iter"], flops_jacobi, iters * n_local)
-        if split.get("dipole_iter") and split.get("dipole_far"):
-            ms = split["dipole_iter"]
-            other["dipole_iter_stream_only"] = {"bound": "hbm", "kernel": "k_dipole_iter_stream", "achieved": bytes_jacobi / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                                "unit": "GB/s", "frac": bytes_jacobi / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms,
-                                                "algorithmic_bytes_per_launch": bytes_jacobi, "what": "MPMC_JACOBI=split: the stored tile pairs alone"}
-            other["dipole_iter_far_only"] = compute_entry("k_dipole_iter_far", split["dipole_far"], FLOP_PAIR_FAR * n_pairs_far, iters * n_local,
-                                                          {"what": "MPMC_JACOBI=split: the recomputed far-field tile pairs alone"})
+            other["dipole_iter"] = compute_entry(jac_kernel, "dipole_iter", src, flops_jacobi, iters * n_local)
         roof["other_kernels"] = other
         roof["alone_kernel_ms"] = alone
-        roof["pmc_sources"] = "profiles/r02_final_pmc_serial_summary.md (SQ_* counters, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes; tools/profile.sh)"
-        roof["note"] = ("fp64 VALU bound: MI355X fp64 vector and matrix peaks are both 78.6 TFLOP/s, the kernel issues v_fma_f64.  One launch per Jacobi "
-                        "iteration over ALL tile pairs (panels of two tile pairs per workgroup of four waves): 48 flop per streamed pair (16 B of stored "
-                        "tensor), 64 flop per recomputed far-field pair (FMA = 2).  Tensors are stored for the tile pairs within lambda r = 30 only.")
+        roof["note"] = ("fp64 vector-issue bound: the kernels issue v_fma_f64 / v_mul_f64 / v_add_f64 (MI355X fp64 vector and matrix peaks are both 78.6 "
+                        "TFLOP/s).  One launch per Jacobi iteration over ALL tile pairs (panels of two tile pairs per workgroup of four waves); tensors "
+                        "are stored (16 B per pair) for the tile pairs within lambda r = 30 only, the rest is recomputed from the positions.")
 
         out = {
             "metric": "energy-evals/sec (10k-atom LJ+Ewald+polar box); 1/2/4/8-GPU scaling",
@@ -496,17 +500,21 @@ def main():
                        "natoms": n, "beads": P, "beads_per_gpu": P // world, "polar_solver": solver_used, "combine": args.combine,
                        "parallelism": f"beads sharded round-robin over {world} GPU(s); one {'all_gather' if args.combine == 'gather' else 'all_reduce'} of 4 fp64 per bead per step",
                        "dist_backend": (args.dist_backend if world > 1 else "none (one rank)"), "world_size": world, "combine_impl": combine_impl,
-                       "rccl_version": rccl_ver},
+                       "rccl_version": rccl_ver, "configure": args.configure},
             "V_mean_K": v, "obs_rd_es_pol_vdw": [float(x) for x in obs],
             "kernel_ms": in_region,
             "device_bytes_per_bead": mem_total,
             "roofline": roof,
         }
+        if rehearsal:
+            out["config"]["rehearsal"] = (f"{rehearsal} beads in flight on ONE GPU: the per-GPU load of a {args.beads // rehearsal}-GPU run of the "
+                                          f"{args.beads}-bead ensemble, without the 4-double collective; value x {args.beads // rehearsal} is what that "
+                                          "run can reach at most.  NOT the headline workload")
         if pcie is not None:
             out["pcie_inclusive_value"] = pcie["value"]
             out["pcie_inclusive"] = pcie
         if args.host_positions:
-            out["note_host_positions"] = "positions of every bead re-uploaded from host memory inside every timed step (PCIe-inclusive rate, not the headline)"
+            out["note_host_positions"] = "positions of every bead handed over in host memory inside every timed step (PCIe-inclusive rate, not the headline)"
     # which device every rank drove (proof that RCCL saw N ranks on N devices): gathered from all ranks
     my_info = {"rank": rank, "local_rank": local_rank, "device": dev, "device_name": torch.cuda.get_device_name(local_rank), "pid": os.getpid(),
                "beads": mine, "comm_n_ranks": (comm.n_ranks if comm is not None else None)}

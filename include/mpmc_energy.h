@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MPMC_ABI_VERSION 3
+#define MPMC_ABI_VERSION 4
 
 /* ---- status codes -------------------------------------------------------------------------------------- */
 #define MPMC_OK 0
@@ -232,8 +232,13 @@ int mpmc_update_com(mpmc_ctx *ctx, double *com, double *wrapped_com, double *wra
  * sums4.  per_bead (may be NULL) receives n_local mpmc_result.  The cross-rank combine (4 fp64 all-reduce over
  * RCCL / MPI_Allgather in the reference, :763-766) is the caller's; mpmc_pi_finish divides by P. */
 int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sums4[4], mpmc_result *per_bead, int *any_iterator_failed);
-/* systems that shared each launch of the dipole iterations in this context's last evaluation (mpmc_pi_potential_local runs the
- * Jacobi iterations of compatible beads in lockstep, one launch per iteration for the whole group); 1 = on its own */
+/* The same, with every bead's coordinates handed over in HOST memory (pos[b]: n x 3 doubles in the caller's atom order -- what the
+ * reference's bead loop holds, PathIntegral.cpp:759-775): bead b's upload is followed at once by its enqueue, so the uploads overlap
+ * the evaluations of the beads in front of them instead of standing in front of the whole step. */
+int mpmc_pi_potential_local_host(mpmc_ctx **beads, int n_local, const double *const *pos, double sums4[4], mpmc_result *per_bead,
+                                 int *any_iterator_failed);
+/* systems that shared each launch of the dipole iterations in this context's last evaluation: always 1 since ABI 4 (every bead runs
+ * on its own streams; the lockstep form of rounds 1-2 was measured slower and removed).  Kept so that ABI 3 callers still link. */
 int mpmc_last_batch_size(mpmc_ctx *ctx);
 /* obs = sums / P ; returns V = rd + coulombic + vdw + polarization (:786-804) */
 double mpmc_pi_finish(const double sums4_global[4], int P, double obs4[4]);

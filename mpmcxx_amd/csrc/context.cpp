@@ -91,35 +91,28 @@ static double bisect_threshold(double rc, Pred pred) {
 	return out;
 }
 
-// per-device result of the lane-rotation self-test (0 unknown, 1 dpp ok, 2 dpp wrong -> ds_bpermute)
-static int g_rot_mode[64] = {0};
+// per-device result of the lane-rotation self-test (0 unknown, 1 ok): every symmetric kernel rotates its j-side accumulators with
+// v_mov_b32_dpp wave_rol:1; a device on which that does not deliver lane (l + 1) & 63 cannot run this library
+static int g_rot_ok[64] = {0};
 static int rot_selftest(mpmc_ctx *c) {
-	if (c->device < 64 && g_rot_mode[c->device]) {
-		c->use_dpp = (g_rot_mode[c->device] == 1);
-		return MPMC_OK;
-	}
-	int *d = nullptr, h[128];
-	HIP_TRY(c, hipMalloc((void **)&d, 128 * sizeof(int)));
-	launch_rot_selftest(c->stream, d, d + 64);
+	if (c->device < 64 && g_rot_ok[c->device]) return MPMC_OK;
+	int *d = nullptr, h[64];
+	HIP_TRY(c, hipMalloc((void **)&d, 64 * sizeof(int)));
+	launch_rot_selftest(c->stream, d);
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	(void)hipFree(d);
-	bool dpp_ok = true, perm_ok = true;
-	for (int l = 0; l < 64; l++) {
-		if (h[l] != ((l + 1) & 63)) dpp_ok = false;
-		if (h[64 + l] != ((l + 1) & 63)) perm_ok = false;
-	}
-	if (!perm_ok) {
-		c->err = "lane-rotation self-test failed (ds_bpermute)";
-		return MPMC_ERR_INTERNAL;
-	}
-	c->use_dpp = dpp_ok;
-	if (c->device < 64) g_rot_mode[c->device] = dpp_ok ? 1 : 2;
+	for (int l = 0; l < 64; l++)
+		if (h[l] != ((l + 1) & 63)) {
+			c->err = "lane-rotation self-test failed (v_mov_b32_dpp wave_rol:1): not a gfx950 device?";
+			return MPMC_ERR_INTERNAL;
+		}
+	if (c->device < 64) g_rot_ok[c->device] = 1;
 	return MPMC_OK;
 }
 
-static int g_default_pair_kernel = 0; // (mpmc_debug_configure with a null context)
+static mpmc_tuning g_tuning_default; // what contexts created from now on start from (mpmc_debug_configure with a null context)
 
 // ---- lifetime --------------------------------------------------------------------------------------------
 extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
@@ -147,16 +140,8 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 		delete c;
 		return fail(nullptr, MPMC_ERR_HIP, "mpmc_ctx_create: hipStreamCreate failed");
 	}
-	c->pair_kernel = g_default_pair_kernel;
-	if (const char *e = std::getenv("MPMC_ONE_STREAM")) c->stream_mode = (e[0] == '1') ? 0 : 1;
-	c->two_streams = (c->stream_mode != 0);
-	if (const char *e = std::getenv("MPMC_JACOBI")) c->jacobi_hybrid = (e[0] != 's');
-	if (const char *e = std::getenv("MPMC_NO_UNI")) c->no_uniform = (e[0] == '1');
-	if (const char *e = std::getenv("MPMC_THOLE_FAR_X")) c->thole_far_x = std::max(20.0, std::atof(e));
-	if (const char *e = std::getenv("MPMC_NO_SINGLE_LAUNCH")) c->single_launch = !(e[0] == '1');
-	if (const char *e = std::getenv("MPMC_NO_PANELS")) c->use_panels = !(e[0] == '1');
-	if (const char *e = std::getenv("MPMC_PAIR_WAVES")) c->pair_waves = (std::atoi(e) == 4) ? 4 : (std::atoi(e) == 1 ? 1 : 0);
-	if (const char *e = std::getenv("MPMC_NO_RECIP_TAB")) c->no_recip_tab = (e[0] == '1');
+	c->tune = g_tuning_default;
+	c->two_streams = (c->tune.stream_mode != 0);
 	const size_t P = (size_t)c->max_pad;
 	A(dev_alloc(c, &c->d_atoms_blob, P * kAtomRecordBytes)); // every per-atom array, one block (layout: atom_block_layout)
 	if (rc == MPMC_OK)
@@ -179,7 +164,10 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	}
 	static_assert(sizeof(long long) == sizeof(double), "scalars and counts share one buffer");
 	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_scal, (S_COUNT + C_COUNT + 1) * sizeof(double)) != hipSuccess) rc = MPMC_ERR_HIP;
-	if (rc == MPMC_OK) c->h_cnt = reinterpret_cast<long long *>(c->h_scal + S_COUNT);
+	if (rc == MPMC_OK) {
+		c->h_cnt = reinterpret_cast<long long *>(c->h_scal + S_COUNT);
+		std::memset(c->h_scal, 0, (S_COUNT + C_COUNT + 1) * sizeof(double)); // (the launch-number slot the waits poll starts at 0: a recycled pinned block may hold an old context's 1.0)
+	}
 	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_flag, 4 * sizeof(int)) != hipSuccess) rc = MPMC_ERR_HIP;
 	if (rc == MPMC_OK) rc = rot_selftest(c);
 	if (rc != MPMC_OK) {
@@ -187,11 +175,6 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 		mpmc_ctx_destroy(c);
 		return rc;
 	}
-	if (const char *e = std::getenv("MPMC_NO_CLASSES")) c->no_classes = (e[0] == '1');
-	if (const char *e = std::getenv("MPMC_NO_DPP")) if (e[0] == '1') c->use_dpp = false;
-	// the Jacobi kernels rotate their j-side accumulators the way the pair sweep does: decided AFTER the self-test and the override
-	c->jacc = c->use_dpp ? 0 : 1;
-	if (const char *e = std::getenv("MPMC_JACC")) c->jacc = std::atoi(e);
 	*out = c;
 	return MPMC_OK;
 }
@@ -201,7 +184,6 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	(void)hipSetDevice(c->device);
 	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	if (c->ev_phase) (void)hipEventDestroy(c->ev_phase);
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -209,7 +191,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_atoms_blob, c->d_atom_part, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal,
 	                c->d_flag, c->d_counter, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_solve_args, c->d_tile_bounds, c->d_lists, c->d_panels, c->d_seg, c->d_gpart, c->d_trace, c->d_mv_blob, c->d_moved_idx,
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_tile_bounds, c->d_panels, c->d_seg, c->d_gpart, c->d_trace, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out, c->d_e_real, c->d_e_real_trial, c->d_dk_part, c->d_erf_tab, c->d_sweep_blocks, c->d_generic_list};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -322,7 +304,7 @@ static void compute_spatial_order(mpmc_ctx *c) {
 	for (int i = 0; i < n; i++) c->perm[i] = i;
 	bool enable = c->box_set && n > 2 * kTile;
 	if (c->opts_set && c->opts.polar_gs && c->opts.polarization && !c->opts.rd_only) enable = false; // the sweep order IS the atom order (:3569)
-	if (const char *e = std::getenv("MPMC_NO_SORT")) if (e[0] == '1') enable = false;
+	if (c->tune.no_sort) enable = false;
 	if (enable) {
 		// fractional coordinates counted from the smallest one in each dimension: with all atoms inside one period (the usual case) the
 		// periodic wrap is cut at the edge of the occupied range, so tiles are compact in the RAW coordinates too -- which is what lets
@@ -399,8 +381,9 @@ static bool carry_spatial_order(mpmc_ctx *c, const double *new_pos, int n_new) {
 }
 
 int mpmc::upload_atoms(mpmc_ctx *c) {
-	static const bool no_carry = [] { const char *e = std::getenv("MPMC_NO_ORDER_CARRY"); return e && e[0] == '1'; }();
-	if (!c->order_carried || no_carry || (int)c->perm.size() != c->n) {
+	// (atoms_dirty_order: somebody asked for a NEW order since the list was carried -- a set_options that switches Gauss-Seidel sweeps on
+	// needs the identity order of System.Energy.cpp:3569, not the carried spatial one)
+	if (!c->order_carried || c->atoms_dirty_order || c->tune.no_order_carry || (int)c->perm.size() != c->n) {
 		compute_spatial_order(c);
 		c->n_uploads_sorted++;
 	} else {
@@ -565,7 +548,7 @@ static int grow_capacity(mpmc_ctx *c, int n) {
 	}
 	f->prof = c->prof;
 	f->tim = c->tim;
-	f->pair_kernel = c->pair_kernel;
+	f->tune = c->tune;
 	f->n_uploads_carried = c->n_uploads_carried; // (diagnostics survive the growth; the order itself does not: the new context sorts)
 	f->n_uploads_sorted = c->n_uploads_sorted;
 	std::swap(*c, *f);
@@ -639,14 +622,12 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 		dev_free(c, &c->d_block_cnt, 4 * c->cap_tile_pairs);
 		dev_free(c, &c->d_cls, c->cap_tile_pairs);
 		dev_free(c, &c->d_tp_shift, c->cap_tile_pairs);
-		dev_free(c, &c->d_lists, 2 * c->cap_tile_pairs + 2);
 		c->cap_tile_pairs = 0;
 		if ((rc = dev_alloc(c, &c->d_tile_pairs, ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_block_part, 2 * ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_block_cnt, 4 * ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_cls, ntp)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_tp_shift, ntp)) != MPMC_OK) return rc;
-		if ((rc = dev_alloc(c, &c->d_lists, 2 * ntp + 2)) != MPMC_OK) return rc;
 		c->cap_tile_pairs = ntp;
 	}
 	std::vector<int2> tp;
@@ -809,20 +790,83 @@ extern "C" int mpmc_get_tile_stats(mpmc_ctx *c, int64_t out4[4]) {
 	return MPMC_OK;
 }
 
-// Measurement / A-B switches.  With a context: that context, from its next evaluation on; with a null context: the default that contexts
-// created afterwards in this process start from.  Nothing here changes a result beyond the last bits.
-//   pair_kernel   0 the fast sweep (kernels_pair.hip) where it applies and the table is large, 1 never (k_pair_fused), 2 wherever it applies
+// measurement (bench.py's roofline): exact ATOM-pair counts behind the tile-pair classes of the last evaluation.  out[12] =
+//   0 all pairs N(N-1)/2      1 pairs of the tile pairs whose tensors are stored      2 ... of the far-field tile pairs      3 ... of the
+//   tile pairs beyond the cutoff      4 / 5  sum over the stored / far tile pairs of pairs x (dimensions WITHOUT a tile-pair-wide image)
+//   6 pairs the pair sweep walks (not beyond the cutoff, or stored)      7 the same sum of pairs x non-uniform dimensions over those
+//   8 tile pairs      9 stored      10 far      11 beyond the cutoff
+extern "C" int mpmc_debug_pair_stats(mpmc_ctx *c, int64_t out[12]) {
+	if (!c || !out) return MPMC_ERR_ARG;
+	if (!c->atoms_set || !c->d_cls) return fail(c, MPMC_ERR_ARG, "mpmc_debug_pair_stats: no evaluation has run");
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	std::vector<int> cls((size_t)c->n_tile_pairs);
+	HIP_TRY(c, hipMemcpyAsync(cls.data(), c->d_cls, cls.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	for (int k = 0; k < 12; k++) out[k] = 0;
+	const int nt = c->n_tiles;
+	const bool uni = !(c->tune.no_uniform || c->tune.no_classes) && c->box.ortho;
+	auto real = [&](int T) { return (int64_t)std::max(0, std::min(kTile, c->n - T * kTile)); };
+	size_t t = 0;
+	for (int I = 0; I < nt; I++)
+		for (int J = I; J < nt; J++, t++) {
+			const int v = cls[t];
+			const int64_t pairs = (I == J) ? real(I) * (real(I) - 1) / 2 : real(I) * real(J);
+			const int um = uni ? ((v / CLS_UNIFORM_X) & 7) : 0;
+			const int64_t nu = 3 - ((um & 1) + ((um >> 1) & 1) + ((um >> 2) & 1));
+			const bool far = (v & CLS_THOLE_FAR) != 0, beyond = (v & CLS_BEYOND_CUTOFF) != 0;
+			out[0] += pairs;
+			out[far ? 2 : 1] += pairs;
+			out[far ? 5 : 4] += pairs * nu;
+			if (beyond) out[3] += pairs;
+			if (!beyond || !far) {
+				out[6] += pairs;
+				out[7] += pairs * nu;
+			}
+			out[8]++;
+			out[far ? 10 : 9]++;
+			if (beyond) out[11]++;
+		}
+	return MPMC_OK;
+}
+
+// Measurement / A-B switches (struct mpmc_tuning, context.h).  With a context: that context, from its next evaluation on; with a null
+// context: the default that contexts created afterwards in this process start from.  The library reads no environment variable for
+// any of this.  Keys (value 1 = on, 0 = off unless said otherwise):
+//   side_stream -1 | 0 | 1     pair_kernel 0 | 1 | 2     pair_waves 0 | 1 | 4     panels     uniform_images     tile_classes
+//   single_launch     recip_table     spatial_sort     order_carry     polar_delta     inline_move     trace_panel     tensor_budget_mb N
 extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) {
 	if (!key) return MPMC_ERR_ARG;
+	mpmc_tuning &t = c ? c->tune : g_tuning_default;
 	const std::string k(key);
-	if (k == "pair_kernel") {
-		const int v = (int)value;
+	const int v = (int)value;
+	const bool on = (value != 0.0);
+	if (k == "side_stream") {
+		if (v < -1 || v > 1) return MPMC_ERR_ARG;
+		t.stream_mode = v;
+	} else if (k == "pair_kernel") {
 		if (v < 0 || v > 2) return MPMC_ERR_ARG;
-		if (c) c->pair_kernel = v;
-		else g_default_pair_kernel = v;
-		return MPMC_OK;
-	}
-	return MPMC_ERR_ARG;
+		t.pair_kernel = v;
+	} else if (k == "pair_waves") {
+		if (v != 0 && v != 1 && v != 4) return MPMC_ERR_ARG;
+		t.pair_waves = v;
+	} else if (k == "panels") t.use_panels = on;
+	else if (k == "uniform_images") t.no_uniform = !on;
+	else if (k == "tile_classes") t.no_classes = !on;
+	else if (k == "single_launch") t.single_launch = on;
+	else if (k == "recip_table") t.no_recip_tab = !on;
+	else if (k == "spatial_sort") {
+		t.no_sort = !on;
+		if (c) c->atoms_dirty = c->atoms_dirty_order = true; // (the order changes with the next upload)
+	} else if (k == "order_carry") t.no_order_carry = !on;
+	else if (k == "polar_delta") t.no_polar_delta = !on;
+	else if (k == "inline_move") t.no_inline_move = !on;
+	else if (k == "trace_panel") t.trace_panel = on;
+	else if (k == "tensor_budget_mb") {
+		if (value < 0) return MPMC_ERR_ARG;
+		t.tensor_budget_mb = (long long)value;
+	} else return MPMC_ERR_ARG;
+	return MPMC_OK;
 }
 // which kernel ran the pair pass of the last evaluation: 1 the fast sweep, 0 k_pair_fused
 extern "C" int mpmc_debug_last_pair_kernel(mpmc_ctx *c) { return c ? (c->last_pair_was_sweep ? 1 : 0) : -1; }

@@ -26,7 +26,27 @@ struct EvPair {
 	int cls;
 };
 
+// Measurement / A-B switches (mpmc_debug_configure; the library reads no environment variable for any of them).  The defaults are the
+// production path; none of them changes a result beyond the last bits (tests/test_gpu_tuning.py holds every one to the reference).
+struct mpmc_tuning {
+	int stream_mode = -1;   // "side_stream": -1 by table size (kOneStreamMaxPairs), 0 never fork the side stream, 1 always
+	int pair_kernel = 0;    // "pair_kernel": 0 the fast sweep (kernels_pair.hip) where it applies and the table is large, 1 never, 2 wherever it applies
+	int pair_waves = 0;     // "pair_waves": waves per tile pair of k_pair_fused, 0 by table size (kPairSplitMax), 1 | 4
+	bool use_panels = true; // "panels": panel form of the Jacobi contraction (orthorhombic cells, stored tensors); 0: one tile pair per workgroup
+	bool no_uniform = false;   // "uniform_images" = 0: no tile-pair-wide periodic images
+	bool no_classes = false;   // "tile_classes" = 0: every tile pair is "near" (nothing skipped, every tensor stored)
+	bool single_launch = true; // "single_launch": small LJ-only boxes in one launch
+	bool no_recip_tab = false; // "recip_table" = 0: one sincos per (k, atom) instead of the factorised phases
+	bool no_sort = false;      // "spatial_sort" = 0: atoms stay in the caller's order
+	bool no_order_carry = false; // "order_carry" = 0: every upload of the atom list sorts
+	bool no_polar_delta = false; // "polar_delta" = 0: trial moves of polarizable boxes run a full evaluation
+	bool no_inline_move = false; // "inline_move" = 0: trial moves always travel through the staging block
+	bool trace_panel = false;    // "trace_panel" = 1: per-workgroup time stamps of the panel kernel (tools/panel_trace.py)
+	long long tensor_budget_mb = 4096; // "tensor_budget_mb": AUTO solver: largest tensor store it will allocate
+};
+
 struct mpmc_ctx {
+	mpmc_tuning tune;
 	int device = 0;
 	hipStream_t stream = nullptr;
 	// second stream for work that is independent of the main chain inside ONE evaluation (reciprocal space next to the
@@ -34,9 +54,6 @@ struct mpmc_ctx {
 	hipStream_t stream2 = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	bool two_streams = true; // the side stream is forked in THIS evaluation (set per evaluation from stream_mode and the table size)
-	int stream_mode = -1;    // -1: by table size (kOneStreamMaxPairs); MPMC_ONE_STREAM=1 -> 0 never fork, =0 -> 1 always fork
-	int jacc = 0; // hybrid Jacobi kernel variant (MPMC_JACC): 0 DPP lane rotation, 1 ds_bpermute (when the DPP self-test fails)
-	bool jacobi_hybrid = true; // one launch per Jacobi iteration over all tile pairs; MPMC_JACOBI=split: two kernels (stream / far)
 	int max_atoms = 0, max_pad = 0;
 	int n = 0, n_pad = 0, n_tiles = 0, n_tile_pairs = 0, n_split = 1;
 	int n_molecules = 0;
@@ -68,17 +85,14 @@ struct mpmc_ctx {
 	double *d_block_part = nullptr; // [ntp][2]
 	int *d_block_cnt = nullptr;     // [ntp][4] (2 used by the pair kernel, 4 by the static-count kernel)
 	int *d_cls = nullptr;           // tile-pair classes (CLS_*), recomputed every evaluation
-	int *d_lists = nullptr;         // [2 ntp] work lists of the two Jacobi kernels + [2] their lengths (at the end)
 	double *d_tile_bounds = nullptr; // [n_tiles][12]: wrapped fractional lo/hi, raw Cartesian lo/hi
 	double4 *d_tp_shift = nullptr;   // [n_tile_pairs] lattice vector components of the common image index (CLS_UNIFORM_X/Y/Z)
 	int4 *d_panels = nullptr;        // work table of the panel form of the Jacobi contraction (k_build_panels), rebuilt every evaluation
 	int *d_seg = nullptr;            // [n_tiles + 1] first entry of every j-tile's segment of that table
 	double *d_gpart = nullptr;       // [entries][64][3] j-side partial sums, one slot per entry of the table
 	size_t cap_panels = 0, cap_seg = 0;
-	int pair_waves = 0;              // 0: by table size (kPairSplitMax); MPMC_PAIR_WAVES=1|4 forces (measurement)
-	long long *d_trace = nullptr;    // measurement only (MPMC_TRACE_PANEL=1): [entries][4] start / end ticks, HW_ID, XCC_ID of every workgroup of the LAST panel launch
+	long long *d_trace = nullptr;    // measurement only (tune.trace_panel): [entries][4] start / end ticks, HW_ID, XCC_ID of every workgroup of the LAST panel launch
 	int n_panel_entries = 0, seg_tiles = -1; // entries of the table / the tile count its layout was made for
-	bool use_panels = true;          // MPMC_NO_PANELS=1: every tile pair through the single-tile-pair kernel (A/B comparisons)
 	bool panels_built = false;       // this evaluation's classes carry CLS_GROUPED bits and d_panels is valid
 	// the fast pair sweep (kernels_pair.hip): its erfc table, its work table { J, I0 } (depends on the tile count only) and the list of
 	// tile pairs it leaves to k_pair_fused (a tile with a frozen / chargeless / sigma- or epsilon-less atom: rebuilt with every upload)
@@ -90,8 +104,9 @@ struct mpmc_ctx {
 	size_t cap_generic = 0;
 	int n_generic = 0;
 	std::vector<int> h_generic;
-	int pair_kernel = 0;             // 0: the sweep where it applies and the table is large (> kPairSplitMax tile pairs); 1: never; 2: wherever it applies (mpmc_debug_configure)
 	bool last_pair_was_sweep = false; // (diagnostics: which kernel the last evaluation's pair pass ran)
+	FusedParams last_fp{};            // the pair pass's parameters in the last evaluation (mpmc_debug_time_pair replays it)
+	bool last_fp_valid = false;
 	double4 *h_xyzq = nullptr;       // PINNED host mirror of d_xyzq (slot order, max_pad entries): position updates copy from it asynchronously;
 	hipEvent_t ev_xyzq = nullptr;    // marks the last copy out of it done -- whoever is about to write the mirror waits for that copy only
 	bool xyzq_in_flight = false;     // (mirror_guard), not for the evaluations queued behind it
@@ -105,17 +120,7 @@ struct mpmc_ctx {
 	long long n_uploads_carried = 0, n_uploads_sorted = 0; // (diagnostics: mpmc_debug_upload_counts)
 	int edits_since_sort = 0;   // atoms inserted + removed since the last real sort
 	double sort_origin_f[3] = {0, 0, 0}; // fractional coordinate at which the spatial sort cuts the periodic wrap
-	bool no_uniform = false;         // MPMC_NO_UNI=1
-	double thole_far_x = kTholeFarX; // lambda r beyond which a tile pair's tensors are not stored (MPMC_THOLE_FAR_X)
-	// lockstep solve of several systems (mpmc_pi_potential_local): enqueue() stops before the dipole iterations when asked to and
-	// possible; the batch driver then runs the iterations of all deferred systems in shared launches on one stream
-	bool defer_solve = false, solve_deferred = false, reduce_pending_join = false;
-	hipEvent_t ev_phase = nullptr;      // "everything before the solve is enqueued" marker on this context's stream
 	hipStream_t sync_stream = nullptr;  // stream that carries this context's final copies (null: its own)
-	SolveBead *d_solve_args = nullptr;  // device array of per-system pointers (owned by the first system of a batch)
-	std::vector<SolveBead> h_solve_args; // its host image (must outlive the asynchronous copy)
-	int cap_solve_args = 0;
-	int last_batch = 1;                 // systems per launch in the last evaluation's solve
 	size_t cap_tile_pairs = 0;
 	std::vector<double> molmass_tmp; // (scratch of upload_atoms)
 	long long *static_cnt = nullptr; // pinned [4]: n_intra, n_rd_excluded, n_es_excluded, n_frozen (position independent; copied back behind every upload of the atoms)
@@ -138,7 +143,6 @@ struct mpmc_ctx {
 	bool static_dirty = true;
 	double h_static[3] = {0, 0, 0}; // lrc_pair, lrc_self, es_self
 	int *d_counter = nullptr;       // ticket counter of the single-launch small-system kernels (zero between launches)
-	bool single_launch = true;      // MPMC_NO_SINGLE_LAUNCH=1: small systems take the general multi-kernel path
 	bool scal_clean = false;        // d_scal is all zeros (the post kernel of the last evaluation left it so): no clear needed in front of this one
 	bool spin_on_post = false;      // the pending evaluation ends in k_post_results and is short: wait_and_fill polls the launch number first
 	bool last_was_single = false;   // the pending evaluation wrote h_scal from the device: nothing to copy back
@@ -159,7 +163,6 @@ struct mpmc_ctx {
 	int4 *d_lvec = nullptr;       // integer l-vectors of the k table
 	double4 *d_sf_part = nullptr; // [n_tiles][K] per-tile structure-factor partials (factorised phases)
 	size_t cap_sf_part = 0;
-	bool no_recip_tab = false;    // MPMC_NO_RECIP_TAB=1: one sincos per (k, atom)
 	double *d_w_en = nullptr;
 
 	// polarization work
@@ -176,8 +179,6 @@ struct mpmc_ctx {
 	double2 *d_ab = nullptr;
 	size_t cap_ab = 0; // in double2 elements
 	int solver_used = MPMC_SOLVER_MATRIX_FREE;
-	bool use_dpp = true;   // lane rotation by v_mov_b32_dpp wave_rol:1 (verified at create), else ds_bpermute
-	bool no_classes = false; // MPMC_NO_CLASSES=1: treat every tile pair as near (A/B comparisons only)
 
 	Box box{};
 	double box_in[20] = {0}; // what mpmc_set_box was last called with (basis, reciprocal, volume, cutoff): an identical call is a no-op

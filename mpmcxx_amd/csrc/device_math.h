@@ -20,17 +20,12 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 	return v;
 }
 
-// lane l receives the value held by lane (l+1) & 63
-template <bool DPP>
-__device__ __forceinline__ double rot_from_next(double v, int src_lane_x4) {
+// lane l receives the value held by lane (l+1) & 63: two v_mov_b32_dpp wave_rol:1 (verified once per device at context creation,
+// launch_rot_selftest)
+__device__ __forceinline__ double rot_from_next(double v) {
 	int lo = __double2loint(v), hi = __double2hiint(v);
-	if (DPP) {
-		lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
-		hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
-	} else {
-		lo = __builtin_amdgcn_ds_bpermute(src_lane_x4, lo);
-		hi = __builtin_amdgcn_ds_bpermute(src_lane_x4, hi);
-	}
+	lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+	hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
 	return __hiloint2double(hi, lo);
 }
 

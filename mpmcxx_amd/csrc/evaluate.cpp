@@ -129,8 +129,7 @@ static int resolve_solver(mpmc_ctx *c) {
 	int want = c->opts.solver;
 	if (c->opts.polar_gs) want = MPMC_SOLVER_MATRIX_FREE; // Gauss-Seidel sweeps rebuild the tensors row block by row block (kernels_gs.hip)
 	if (want == MPMC_SOLVER_AUTO) {
-		size_t budget_mb = 4096;
-		if (const char *e = std::getenv("MPMC_TENSOR_BUDGET_MB")) budget_mb = (size_t)std::strtoull(e, nullptr, 10);
+		const size_t budget_mb = (size_t)c->tune.tensor_budget_mb;
 		want = (need * sizeof(double2) <= budget_mb * (size_t)1048576) ? MPMC_SOLVER_COMPACT : MPMC_SOLVER_MATRIX_FREE;
 		// building the store costs about as much as three iterations save (0.10 ms against 0.03 ms per iteration at 10 000 atoms)
 		if (c->opts.polar_precision == 0.0 && c->opts.polar_max_iter <= 3) want = MPMC_SOLVER_MATRIX_FREE;
@@ -215,7 +214,7 @@ RecipDev mpmc::recip_view(const mpmc_ctx *c) {
 	r.kvec = c->d_kvec;
 	r.w_en = c->d_w_en;
 	r.kw = c->d_kw;
-	r.lvec = c->no_recip_tab ? nullptr : c->d_lvec;
+	r.lvec = c->tune.no_recip_tab ? nullptr : c->d_lvec;
 	r.sf = c->d_sf;
 	r.K = c->K;
 	return r;
@@ -224,12 +223,10 @@ RecipDev mpmc::recip_view(const mpmc_ctx *c) {
 // which pieces of energy() to run
 
 int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
-	// stale position-independent terms ride along with this evaluation (an insertion / removal makes them stale every time) -- unless
-	// the solve is deferred to the lockstep driver of pi.cpp, which reads the scalar block back itself
-	const bool may_ride = !c->defer_solve;
-	int rc = prepare(c, may_ride);
+	// stale position-independent terms ride along with this evaluation (an insertion / removal makes them stale every time)
+	int rc = prepare(c, true);
 	if (rc != MPMC_OK) return rc;
-	const bool static_ride = c->static_dirty; // (only possible with may_ride)
+	const bool static_ride = c->static_dirty;
 	c->static_ride_gen = 0;
 	const AtomsDev at = atoms_view(c);
 	const RecipDev rcp = recip_view(c);
@@ -242,13 +239,13 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 
 	c->last_was_single = false;
 	c->spin_on_post = false;
-	if (c->single_launch && mask == (RUN_PAIR | RUN_ATOMTERMS) && !o.feynman_hibbs && c->n_tiles <= kSingleLaunchTiles && !c->prof && !static_ride) {
+	if (c->tune.single_launch && mask == (RUN_PAIR | RUN_ATOMTERMS) && !o.feynman_hibbs && c->n_tiles <= kSingleLaunchTiles && !c->prof && !static_ride) {
 		// small LJ box (BASELINE configs[1]): the whole evaluation is one launch -- pair sweep without classes, the block that finishes last
 		// folds the partials into the pinned result vector; the LRC terms are the cached position-independent ones
 		FusedParams fp{};
 		fp.rd_lrc = o.rd_lrc;
 		c->single_seq += 1.0;
-		launch_pair_lj_single(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_counter, c->h_scal,
+		launch_pair_lj_single(st, at, c->box, fp, c->d_tile_pairs, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_counter, c->h_scal,
 		                      c->single_seq);
 		HIP_TRY(c, hipGetLastError());
 		c->last_was_single = true;
@@ -279,7 +276,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	const bool side_work = need_sf || need_intra;
 	// a fork/join costs ~20 us of dispatch latency: worth it next to reciprocal-space work, not for the O(N) atom terms alone -- and not
 	// for small tables at all (kOneStreamMaxPairs).  Decided here, once per evaluation: nothing is forked at this point.
-	c->two_streams = (c->stream_mode == 1) || (c->stream_mode < 0 && c->n_tile_pairs > kOneStreamMaxPairs);
+	c->two_streams = (c->tune.stream_mode == 1) || (c->tune.stream_mode < 0 && c->n_tile_pairs > kOneStreamMaxPairs);
 	const bool side_fork = c->two_streams && (need_sf || need_intra);
 	bool panel_side = false; // the panel table of the Jacobi contraction is being built on the side stream
 	if (side_work) {
@@ -313,9 +310,9 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		// tile-pair classes from this configuration's tile bounding boxes (orthorhombic cells; all "near" otherwise)
 		{
 			ProfScope pc(c, MPMC_K_CLASSES);
-			if (c->no_classes) HIP_TRY(c, hipMemsetAsync(c->d_cls, 0, (size_t)c->n_tile_pairs * sizeof(int), st));
+			if (c->tune.no_classes) HIP_TRY(c, hipMemsetAsync(c->d_cls, 0, (size_t)c->n_tile_pairs * sizeof(int), st));
 			else launch_tile_classes(st, at, c->box, c->d_tile_pairs, c->n_tile_pairs, (o.polarization && !o.rd_only) ? o.polar_damp : 0.0,
-			                         c->d_tile_bounds, c->d_cls, c->no_uniform ? nullptr : c->d_tp_shift, c->sort_origin_f, c->thole_far_x);
+			                         c->d_tile_bounds, c->d_cls, c->tune.no_uniform ? nullptr : c->d_tp_shift, c->sort_origin_f, kTholeFarX);
 		}
 		FusedParams fp;
 		fp.ewald_alpha = c->ewald_alpha;
@@ -335,17 +332,15 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		}
 		fp.wolf_erfa_over_r = std::erf(c->ewald_alpha * c->box.cutoff) / c->box.cutoff;
 		fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
-		fp.thole_far_x = c->thole_far_x;
-		fp.pair_waves = c->pair_waves ? c->pair_waves : (c->n_tile_pairs <= kPairSplitMax ? 4 : 1);
+		fp.thole_far_x = kTholeFarX;
+		fp.pair_waves = c->tune.pair_waves ? c->tune.pair_waves : (c->n_tile_pairs <= kPairSplitMax ? 4 : 1);
 		fp.store_only = ((mask & RUN_STORE) && !(mask & (RUN_PAIR | RUN_FIELD))) ? 1 : 0;
 		fp.touch_n = fp.store_only ? c->touch_n : -1;
 		for (int k = 0; k < 8; k++) fp.touch[k] = c->touch[k];
 		if (!fp.store_only && compact) c->store_dirty_tiles.clear(); // a full sweep rebuilds every stored tile pair
-		if (compact && !c->jacobi_hybrid) // work lists of the two-kernel Jacobi form only
-			launch_build_lists(st, c->d_cls, c->n_tile_pairs, c->d_lists, c->d_lists + 2 * (size_t)c->n_tile_pairs);
 		// panels of the Jacobi contraction: two tile pairs of equal class behind one j-tile per wave (orthorhombic cells, stored tensors)
 		c->panels_built = false;
-		if (compact && c->jacobi_hybrid && c->use_panels && c->box.ortho && !c->no_classes && !c->no_uniform && !c->defer_solve && c->n_tiles >= 3) {
+		if (compact && c->tune.use_panels && c->box.ortho && !c->tune.no_classes && !c->tune.no_uniform && c->n_tiles >= 3) {
 			if (c->seg_tiles != c->n_tiles) { // the table's layout depends on the tile count only
 				std::vector<int> seg((size_t)c->n_tiles + 1, 0);
 				for (int J = 0; J < c->n_tiles; J++) seg[J + 1] = seg[J] + panel_segment_entries(J);
@@ -368,8 +363,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				if ((rc = dev_alloc(c, &c->d_panels, need)) != MPMC_OK) return rc;
 				if ((rc = dev_alloc(c, &c->d_gpart, need * kTile * 3)) != MPMC_OK) return rc;
 				c->cap_panels = need;
-				static const bool want_trace = [] { const char *e = std::getenv("MPMC_TRACE_PANEL"); return e && e[0] == '1'; }();
-				if (want_trace) {
+				if (c->tune.trace_panel) {
 					if (c->d_trace) (void)hipFree(c->d_trace);
 					c->d_trace = nullptr;
 					if ((rc = dev_alloc(c, &c->d_trace, need * 4)) != MPMC_OK) return rc;
@@ -384,22 +378,24 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			}
 			c->panels_built = true;
 		}
+		c->last_fp = fp;
+		c->last_fp_valid = !fp.store_only;
 		ProfScope p(c, MPMC_K_PAIR);
 		// the fast sweep (kernels_pair.hip) where it applies -- orthorhombic cell, Ewald electrostatics, alpha r_c inside its erfc table --
 		// and, by default, where the table is large (small tables: four waves per tile pair in k_pair_fused, a latency matter); the tile
 		// pairs with a special atom, which it skips, go through k_pair_fused on their list
-		const bool sweep = c->pair_kernel != 1 && c->use_dpp && c->d_sweep_blocks && (c->pair_kernel == 2 || fp.pair_waves == 1) &&
+		const bool sweep = c->tune.pair_kernel != 1 && c->d_sweep_blocks && (c->tune.pair_kernel == 2 || fp.pair_waves == 1) &&
 		                   pair_sweep_covers(c->box, fp, c->ewald_alpha);
 		c->last_pair_was_sweep = sweep;
 		if (sweep) {
 			launch_pair_sweep(st, at, c->box, fp, c->n_molecules != c->n, c->d_sweep_blocks, c->n_sweep_blocks, c->d_cls,
-			                  (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->d_erf_tab, c->d_block_part, c->d_block_cnt, c->d_part,
+			                  (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->d_erf_tab, c->d_block_part, c->d_block_cnt, c->d_part,
 			                  compact ? c->d_ab : nullptr);
 			if (c->n_generic > 0)
-				launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_generic, c->d_block_part, c->d_block_cnt, c->d_part,
+				launch_pair_fused(st, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_generic, c->d_block_part, c->d_block_cnt, c->d_part,
 				                  compact ? c->d_ab : nullptr, c->d_generic_list);
 		} else if (!(fp.store_only && !compact)) // (a store-only pass without a store to fill has nothing to do beyond the classes)
-			launch_pair_fused(st, c->use_dpp, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
+			launch_pair_fused(st, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
 			                  compact ? c->d_ab : nullptr);
 	}
 	if ((side_work && side_fork) || panel_side) join_side(c);
@@ -421,17 +417,6 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	}
 
 	// ---- thole_iterative, reference src/System.Energy.cpp:3450-3543 ------------------------------------------------
-	c->solve_deferred = false;
-	c->last_batch = 1;
-	if ((mask & RUN_SOLVE) && c->defer_solve && compact && c->jacobi_hybrid && o.polar_precision == 0.0 && !o.polar_gs) {
-		// fixed iteration count, stored-tensor single-launch Jacobi: the caller runs the iterations of several systems together
-		if (reduce_forked) join_side(c);
-		if (!c->ev_phase) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_phase, hipEventDisableTiming));
-		HIP_TRY(c, hipEventRecord(c->ev_phase, st));
-		HIP_TRY(c, hipGetLastError());
-		c->solve_deferred = true;
-		return MPMC_OK;
-	}
 	if (mask & RUN_SOLVE) {
 		const bool by_precision = (o.polar_precision != 0.0);
 		const int want_rrms = (o.polar_rrms || o.polar_precision > 0) ? 1 : 0;
@@ -488,37 +473,24 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			if (dense) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
 				launch_dense_matvec(st, c->d_adense, c->n_pad, c->d_mu[c->mu_cur], kDenseChunks, c->d_part);
-			} else if (compact && c->jacobi_hybrid) {
+			} else if (compact) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
 				if (c->panels_built) // every tile pair through the panel table: two per wave where classes allow
-					launch_dipole_iter_panel(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels,
+					launch_dipole_iter_panel(st, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels,
 					                         c->n_panel_entries, c->d_ab, c->d_part, c->d_gpart, converged, c->d_trace);
 				else
-					launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
-					                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part, o.polar_damp,
+					launch_dipole_iter_hybrid(st, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
+					                          (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part, o.polar_damp,
 					                          converged);
-			} else if (compact) {
-				const int *counts = c->d_lists + 2 * (size_t)c->n_tile_pairs;
-				hipStream_t s2 = fork_side(c); // the fp64-bound far-field kernel runs beside the HBM-bound streaming kernel
-				{
-					ProfScope p(c, MPMC_K_DIPOLE_FAR, s2);
-					launch_dipole_iter_far(s2, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_lists, counts, c->n_tile_pairs, c->d_part);
-				}
-				{
-					ProfScope p(c, MPMC_K_DIPOLE_ITER);
-					launch_dipole_iter_stream(st, c->use_dpp, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_lists, counts, c->n_tile_pairs,
-					                          c->d_ab, c->d_part);
-				}
-				join_side(c);
 			} else { // matrix-free: the same symmetric tile-pair walk with nothing stored (null store => damped tensors rebuilt)
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
-				launch_dipole_iter_hybrid(st, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
-				                          (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, nullptr, c->d_part, o.polar_damp,
+				launch_dipole_iter_hybrid(st, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
+				                          (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, nullptr, c->d_part, o.polar_damp,
 				                          converged);
 			}
 			{
 				ProfScope p(c, MPMC_K_REDUCE);
-				if (compact && c->jacobi_hybrid && c->panels_built && !dense)
+				if (compact && c->panels_built && !dense)
 					launch_dipole_update_panel(st, at, c->d_e_static, c->d_part, c->d_gpart, c->d_seg, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur],
 					                           c->d_e_induced, want_rrms, c->d_rrms, allowed, ctl, host_flag, it);
 				else
@@ -590,7 +562,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 extern "C" int mpmc_debug_time_panel(mpmc_ctx *c, int reps, double *ms_per_launch) {
 	if (!c || !ms_per_launch || reps <= 0) return MPMC_ERR_ARG;
 	if (c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_debug_time_panel: an evaluation is in flight");
-	if (!c->have_polar || !c->panels_built || !c->jacobi_hybrid || c->solver_used != MPMC_SOLVER_COMPACT)
+	if (!c->have_polar || !c->panels_built || c->solver_used != MPMC_SOLVER_COMPACT)
 		return fail(c, MPMC_ERR_ARG, "mpmc_debug_time_panel: the last evaluation did not run the panel kernel");
 	HIP_TRY(c, hipSetDevice(c->device));
 	const AtomsDev at = atoms_view(c);
@@ -598,12 +570,53 @@ extern "C" int mpmc_debug_time_panel(mpmc_ctx *c, int reps, double *ms_per_launc
 	HIP_TRY(c, hipEventCreate(&e0));
 	HIP_TRY(c, hipEventCreate(&e1));
 	for (int r = 0; r < 3; r++) // (warm)
-		launch_dipole_iter_panel(c->stream, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels, c->n_panel_entries,
+		launch_dipole_iter_panel(c->stream, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels, c->n_panel_entries,
 		                         c->d_ab, c->d_part, c->d_gpart, nullptr, nullptr);
 	HIP_TRY(c, hipEventRecord(e0, c->stream));
 	for (int r = 0; r < reps; r++)
-		launch_dipole_iter_panel(c->stream, c->jacc, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels, c->n_panel_entries,
+		launch_dipole_iter_panel(c->stream, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels, c->n_panel_entries,
 		                         c->d_ab, c->d_part, c->d_gpart, nullptr, nullptr);
+	HIP_TRY(c, hipEventRecord(e1, c->stream));
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipEventSynchronize(e1));
+	float ms = 0;
+	HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	*ms_per_launch = (double)ms / reps;
+	return MPMC_OK;
+}
+
+// the same for the pair pass of the last evaluation (fast sweep or k_pair_fused, whichever ran): `reps` launches back to back between one
+// pair of events.  Needs the classes of a complete evaluation; what it overwrites (block partials, field slots, tensor store) is rewritten
+// identically, the configuration being the same.
+extern "C" int mpmc_debug_time_pair(mpmc_ctx *c, int reps, double *ms_per_launch) {
+	if (!c || !ms_per_launch || reps <= 0) return MPMC_ERR_ARG;
+	if (c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_debug_time_pair: an evaluation is in flight");
+	if (!c->cache_valid || !c->last_fp_valid) return fail(c, MPMC_ERR_ARG, "mpmc_debug_time_pair: no complete evaluation has run");
+	HIP_TRY(c, hipSetDevice(c->device));
+	const AtomsDev at = atoms_view(c);
+	const FusedParams &fp = c->last_fp;
+	const bool compact = c->solver_used == MPMC_SOLVER_COMPACT && fp.do_thole;
+	auto launch = [&] {
+		if (c->last_pair_was_sweep) {
+			launch_pair_sweep(c->stream, at, c->box, fp, c->n_molecules != c->n, c->d_sweep_blocks, c->n_sweep_blocks, c->d_cls,
+			                  (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->d_erf_tab, c->d_block_part, c->d_block_cnt, c->d_part,
+			                  compact ? c->d_ab : nullptr);
+			if (c->n_generic > 0)
+				launch_pair_fused(c->stream, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_generic, c->d_block_part, c->d_block_cnt, c->d_part,
+				                  compact ? c->d_ab : nullptr, c->d_generic_list);
+		} else {
+			launch_pair_fused(c->stream, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
+			                  compact ? c->d_ab : nullptr);
+		}
+	};
+	hipEvent_t e0, e1;
+	HIP_TRY(c, hipEventCreate(&e0));
+	HIP_TRY(c, hipEventCreate(&e1));
+	for (int r = 0; r < 2; r++) launch();
+	HIP_TRY(c, hipEventRecord(e0, c->stream));
+	for (int r = 0; r < reps; r++) launch();
 	HIP_TRY(c, hipEventRecord(e1, c->stream));
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipEventSynchronize(e1));

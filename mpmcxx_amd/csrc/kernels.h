@@ -138,7 +138,7 @@ constexpr int kPairSplitMax = 8192;
 // every unordered pair once: energies + counts (block partials), static-field partials fpart[nt][n_pad][3],
 // Thole store ab[n_tile_pairs][64*64] (double2 = 16 B per pair)
 // tp_list (may be null): the launch covers the tile pairs tp_list[0 .. n_tile_pairs) only -- what the fast sweep below leaves to it
-void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
+void launch_pair_fused(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
                        const int *cls, int n_tile_pairs, double *block_part /*[ntp][2]*/, int *block_cnt /*[ntp][2]*/, double *fpart, double2 *ab,
                        const int *tp_list = nullptr);
 // ---- the fast pair sweep (kernels_pair.hip): orthorhombic cells, Ewald electrostatics, tile pairs of "plain" atoms ----
@@ -165,7 +165,7 @@ void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *bl
 // LJ (+ counts) of a small system in ONE launch: no tile classes, the last-arriving block folds the partials and writes the scalar
 // vector [S_COUNT doubles][C_COUNT int64][seq] into pinned host memory (seq last: a host polling that slot finds the results
 // complete); `counter` is a zeroed int the kernel leaves zeroed
-void launch_pair_lj_single(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs, int n_tile_pairs,
+void launch_pair_lj_single(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs, int n_tile_pairs,
                            double *block_part, int *block_cnt, int *counter, double *out_host, double seq);
 // S_ES_RECIP = (4 pi / V) sum_k w_k |S_k|^2 from the structure factors of this configuration
 void launch_recip_energy(hipStream_t st, const RecipDev &rc, const Box &bx, double *scal);
@@ -179,16 +179,9 @@ void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, cons
                          double *tile_bounds /*[nt][12]*/, int *cls, double4 *tp_shift /*[ntp], may be null*/,
                          const double origin_f[3] /*fractional origin of the spatial sort: where the periodic wrap is cut*/,
                          double thole_far_x = kTholeFarX /*lambda r beyond which a tile pair is CLS_THOLE_FAR*/);
-// work lists of the two Jacobi kernels from the class array: lists[0..ntp) stored tile pairs, lists[ntp..2ntp) far ones
-void launch_build_lists(hipStream_t st, const int *cls, int n_tile_pairs, int *lists /*[2 ntp]*/, int *counts /*[2]*/);
-// one Jacobi contraction = these two launches (each partial slot is written by exactly one of them): part[nt][n_pad][3]
-void launch_dipole_iter_stream(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                               const int *lists, const int *counts, int n_tile_pairs, const double2 *ab, double *part);
-void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                            const int *lists, const int *counts, int n_tile_pairs, double *part);
-// single-launch alternative (all tile pairs, class read per block)
-// jacc: 0 DPP lane rotation, 1 ds_bpermute rotation, 2 ds_add_f64 into an LDS image of the j-atoms
-void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+// one Jacobi contraction over all tile pairs (class read per block): part[nt][n_pad][3].  Triclinic cells and the matrix-free solver;
+// orthorhombic cells with a tensor store take the panel form below
+void launch_dipole_iter_hybrid(hipStream_t st, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                                const int *cls, const double4 *tp_shift /*null: no uniform-image fast path*/, int n_tile_pairs,
                                const double2 *ab /*null: matrix-free, tensors inside the damping range rebuilt from the positions*/,
                                double *part, double polar_damp, const int *converged = nullptr);
@@ -197,33 +190,14 @@ int panel_segment_entries(int J); // entries the work table reserves for j-tile 
 // the work table of the panel kernel: per j-tile its diagonal tile pair, panels of two tile pairs of equal class, odd singles
 void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg /*[n_tiles + 1]*/, int4 *panels);
 // i-side partial sums -> part[J][I atoms] (the usual slots, upper triangle + diagonal only); j-side -> gpart[entry][64][3]
-void launch_dipole_iter_panel(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+void launch_dipole_iter_panel(hipStream_t st, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                               const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart,
                               const int *converged = nullptr, long long *trace = nullptr /*measurement only (MPMC_TRACE_PANEL=1)*/);
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,
                                 const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr,
                                 int *ctl, int *host_flag, int it);
-// ---- lockstep solve of B systems (path-integral images): per-system pointers of the batched Jacobi / update / energy kernels ----
-struct SolveBead {
-	AtomsDev at;
-	const int2 *tile_pairs;
-	const int *cls;
-	const double4 *tp_shift; // null: no uniform-image fast path
-	const double2 *ab;
-	double *part;            // [nt][n_pad][3]
-	double *mu[2];           // double-buffered dipoles
-	const double *e_static;
-	double *e_induced;
-	double *rrms;
-	double *scal;
-};
-void launch_dipole_iter_hybrid_batched(hipStream_t st, int jacc, const SolveBead *sb, int n_beads, const Box &bx, int cur, int n_tile_pairs);
-// mu[1-cur] = alpha (E0 + sum of slots) for every system (tail of contract_dipoles, calc_dipole_rrms)
-void launch_dipole_update_batched(hipStream_t st, const SolveBead *sb, int n_beads, int n_pad, int n_slots, int cur, int want_rrms);
-void launch_polar_energy_batched(hipStream_t st, const SolveBead *sb, int n_beads, int cur, int want_rrms);
-
 // lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
-void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm);
+void launch_rot_selftest(hipStream_t st, int *out);
 
 // ---- dense solver (kernels_dense.hip): the reference's 3N x 3N layout, contraction on the fp64 matrix cores ------------------------
 // a: (3 n_pad)^2 doubles, slot order, diagonal 3x3 blocks and padded slots zero

@@ -590,10 +590,6 @@ __global__ __launch_bounds__(512) void k_dipole_update(AtomsDev at, const double
                                                        double allowed_sqerr, int *__restrict__ ctl, int *__restrict__ host_flag, int it) {
 	dipole_update_block(at, e_static, part, n_split, mu_old, mu_new, e_induced, want_rrms, rrms_atom, allowed_sqerr, ctl, host_flag, it);
 }
-__global__ __launch_bounds__(512) void k_dipole_update_b(const SolveBead *__restrict__ sb, int n_split, int cur, int want_rrms) {
-	const SolveBead b = sb[blockIdx.y];
-	dipole_update_block(b.at, b.e_static, b.part, n_split, b.mu[cur], b.mu[1 - cur], b.e_induced, want_rrms, b.rrms, 0.0, nullptr, nullptr, 0);
-}
 
 __global__ __launch_bounds__(256) void k_dipole_reset(AtomsDev at, const double *__restrict__ e_static, double *__restrict__ mu) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
@@ -626,21 +622,11 @@ __global__ __launch_bounds__(256) void k_polar_energy(AtomsDev at, const double 
                                                       const double *__restrict__ rrms_atom, double *__restrict__ scal) {
 	polar_energy_block(at, mu, e_static, rrms_atom, scal);
 }
-__global__ __launch_bounds__(256) void k_polar_energy_b(const SolveBead *__restrict__ sb, int cur, int want_rrms) {
-	const SolveBead b = sb[blockIdx.x];
-	polar_energy_block(b.at, b.mu[cur], b.e_static, want_rrms ? b.rrms : nullptr, b.scal);
-}
 
 void launch_dipole_update(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, int n_split, const double *mu_old,
                           double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr, int *ctl, int *host_flag, int it) {
 	hipLaunchKernelGGL(k_dipole_update, dim3(at.n_pad / kTile), dim3(kTile * kSlotGroups), 0, st, at, e_static, part, n_split, mu_old, mu_new,
 	                   e_induced, want_rrms, rrms_atom, allowed_sqerr, ctl, host_flag, it);
-}
-void launch_dipole_update_batched(hipStream_t st, const SolveBead *sb, int n_beads, int n_pad, int n_slots, int cur, int want_rrms) {
-	hipLaunchKernelGGL(k_dipole_update_b, dim3(n_pad / kTile, n_beads), dim3(kTile * kSlotGroups), 0, st, sb, n_slots, cur, want_rrms);
-}
-void launch_polar_energy_batched(hipStream_t st, const SolveBead *sb, int n_beads, int cur, int want_rrms) {
-	hipLaunchKernelGGL(k_polar_energy_b, dim3(n_beads), dim3(256), 0, st, sb, cur, want_rrms);
 }
 void launch_dipole_reset(hipStream_t st, const AtomsDev &at, const double *e_static, double *mu) {
 	hipLaunchKernelGGL(k_dipole_reset, dim3((at.n_pad + 255) / 256), dim3(256), 0, st, at, e_static, mu);

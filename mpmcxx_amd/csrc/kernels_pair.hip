@@ -146,16 +146,15 @@ __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, con
                                         double2 *__restrict__ ab_tile, SweepAcc &A, int &n_lj, int &n_es) {
 	// diagonal tile pair: s = 1..32, the last one with lanes 0..31 only (each pair once); off-diagonal: s = 0..63
 	const int s0 = diag ? 1 : 0, n = diag ? 32 : 64;
-	const int src4 = ((lane + 1) & 63) * 4;
 	for (int k = 0; k < n; ++k) {
 		const int s = s0 + k;
 		const bool last = (k == n - 1);
 		sweep_step<UM, FIELD, INTRA, PAD>(s_xy, s_zq, s_se, s_mol, s_tab, lane + s, lane, I, shx, shy, shz, bx, pp, diag && last, i_real, store,
 		                                  ab_tile + s * kTile, A, n_lj, n_es);
 		if (FIELD && !last) {
-			A.gx = rot_from_next<true>(A.gx, src4);
-			A.gy = rot_from_next<true>(A.gy, src4);
-			A.gz = rot_from_next<true>(A.gz, src4);
+			A.gx = rot_from_next(A.gx);
+			A.gy = rot_from_next(A.gy);
+			A.gz = rot_from_next(A.gz);
 		}
 	}
 }

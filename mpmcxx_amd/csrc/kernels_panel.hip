@@ -116,7 +116,7 @@ struct PanAcc {
 };
 
 // one step of the walk: every member against j = (lane + s) & 63 (LDS slot jl = lane + s, no wrap: the image holds every value twice)
-template <int JACC, bool FAR, int NU, int NI, bool ROT, bool PAD>
+template <bool FAR, int NU, int NI, bool ROT, bool PAD>
 __device__ __forceinline__ void pan_step(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zm, const double2 *__restrict__ s_mm,
                                          const double *__restrict__ s_valid, const int jl, const int src4, const double (&L)[3],
                                          const double (&iL)[3], const double (&q)[NI][3], const double (&m)[NI][3], const double2 (&t)[NI],
@@ -153,14 +153,14 @@ __device__ __forceinline__ void pan_step(const double2 *__restrict__ s_xy, const
 		A.g[2] = fma(-ta, m[k][2], fma(di, oz, A.g[2]));
 	}
 	if (ROT) {
-		A.g[0] = rot_from_next<JACC == 0>(A.g[0], src4);
-		A.g[1] = rot_from_next<JACC == 0>(A.g[1], src4);
-		A.g[2] = rot_from_next<JACC == 0>(A.g[2], src4);
+		A.g[0] = rot_from_next(A.g[0]);
+		A.g[1] = rot_from_next(A.g[1]);
+		A.g[2] = rot_from_next(A.g[2]);
 	}
 }
 
 // the walk: n_steps steps from s_first on (64 from 0 for an off-diagonal tile pair, 32 from 1 for a diagonal one); n_steps is a multiple of PIPE
-template <int JACC, bool FAR, int NU, int NI, int PIPE>
+template <bool FAR, int NU, int NI, int PIPE>
 __device__ __forceinline__ void pan_walk(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zm, const double2 *__restrict__ s_mm,
                                          const double *__restrict__ s_valid, const bool pad, const int lane, const int src4,
                                          const double (&L)[3], const double (&iL)[3], const double (&q)[NI][3], const double (&m)[NI][3],
@@ -172,10 +172,10 @@ __device__ __forceinline__ void pan_walk(const double2 *__restrict__ s_xy, const
 #define MPMC_FAR_LOOP(P)                                                                                                               \
 	for (int kc = 0; kc < n_steps - 4; kc += 4, jb += 4) {                                                                             \
 		_Pragma("unroll") for (int u = 0; u < 4; ++u)                                                                                  \
-		    pan_step<JACC, true, NU, NI, true, P>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, none, A);                      \
+		    pan_step<true, NU, NI, true, P>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, none, A);                      \
 	}                                                                                                                                  \
-	_Pragma("unroll") for (int u = 0; u < 3; ++u) pan_step<JACC, true, NU, NI, true, P>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, none, A); \
-	pan_step<JACC, true, NU, NI, false, P>(s_xy, s_zm, s_mm, s_valid, jb + 3, src4, L, iL, q, m, none, A);
+	_Pragma("unroll") for (int u = 0; u < 3; ++u) pan_step<true, NU, NI, true, P>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, none, A); \
+	pan_step<true, NU, NI, false, P>(s_xy, s_zm, s_mm, s_valid, jb + 3, src4, L, iL, q, m, none, A);
 		if (pad) { // wave-uniform: only the panels whose j-tile is the padded last tile
 			MPMC_FAR_LOOP(true)
 		} else {
@@ -202,7 +202,7 @@ __device__ __forceinline__ void pan_walk(const double2 *__restrict__ s_xy, const
 			double2 t[NI];
 #pragma unroll
 			for (int k = 0; k < NI; ++k) t[k] = buf[k][u];
-			pan_step<JACC, false, NU, NI, true, false>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
+			pan_step<false, NU, NI, true, false>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
 #pragma unroll
 			for (int k = 0; k < NI; ++k) buf[k][u] = ld_stream<true>(ab + ab_tile[k] + voff + u * kTile); // refill in place
 			__builtin_amdgcn_sched_barrier(0);
@@ -213,13 +213,13 @@ __device__ __forceinline__ void pan_walk(const double2 *__restrict__ s_xy, const
 		double2 t[NI];
 #pragma unroll
 		for (int k = 0; k < NI; ++k) t[k] = buf[k][u];
-		if (u != PIPE - 1) pan_step<JACC, false, NU, NI, true, false>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
-		else pan_step<JACC, false, NU, NI, false, false>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
+		if (u != PIPE - 1) pan_step<false, NU, NI, true, false>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
+		else pan_step<false, NU, NI, false, false>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
 		__builtin_amdgcn_sched_barrier(0);
 	}
 }
 
-template <int JACC, int PIPE, int NI>
+template <int PIPE, int NI>
 __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
                                             const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab, double *__restrict__ part,
                                             double *__restrict__ gslot, const int tpA, const int tpB, const int flags, const int J,
@@ -284,7 +284,7 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	// the four waves split the walk: 16 steps each of the 64 of an off-diagonal tile pair (s = 0..63), 8 each of the 32 of a diagonal one (s = 1..32)
 	const int n_steps = (diag ? 32 : 64) / kPanelWaves, s_first = (diag ? 1 : 0) + w * n_steps;
 	PanAcc<NI> A = {};
-#define MPMC_PWALK(F, N) pan_walk<JACC, F, N, NI, PIPE>(s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
+#define MPMC_PWALK(F, N) pan_walk<F, N, NI, PIPE>(s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
 	if (far) {
 		switch (nu) {
 		case 0: MPMC_PWALK(true, 0); break;
@@ -342,7 +342,7 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	gslot[3 * lane + p2] = g[2];
 }
 
-template <int JACC, int PIPE>
+template <int PIPE>
 __global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev at, Box bx, const double *__restrict__ mu,
                                                                         const int2 *__restrict__ tile_pairs, const double4 *__restrict__ tp_shift,
                                                                         const int4 *__restrict__ panels, const double2 *__restrict__ ab,
@@ -366,8 +366,8 @@ __global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev
 		if (trace && threadIdx.x == 0) trace[4 * (size_t)blockIdx.x + 1] = 0; // no work: the reader drops entries whose end stamp is 0
 		return;
 	}
-	if (tpB >= 0) panel_block<JACC, PIPE, 2>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
-	else panel_block<JACC, PIPE, 1>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
+	if (tpB >= 0) panel_block<PIPE, 2>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
+	else panel_block<PIPE, 1>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
 	if (trace && threadIdx.x == 0) { // (wave 0 is the last one to leave a workgroup: it folds the partial sums)
 		long long *o = trace + 4 * (size_t)blockIdx.x;
 		o[0] = t_start;
@@ -469,15 +469,12 @@ void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int 
 	hipLaunchKernelGGL(k_build_panels, dim3(n_tiles), dim3(64), 0, st, cls, n_tiles, seg, panels);
 }
 
-void launch_dipole_iter_panel(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+void launch_dipole_iter_panel(hipStream_t st, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                               const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart,
                               const int *converged, long long *trace) {
 	if (n_entries <= 0) return;
 	dim3 grid(n_entries), block(kTile * kPanelWaves);
-	if (jacc == 1)
-		hipLaunchKernelGGL((k_dipole_iter_panel<1, 4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace);
-	else
-		hipLaunchKernelGGL((k_dipole_iter_panel<0, 4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace);
+	hipLaunchKernelGGL((k_dipole_iter_panel<4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace);
 }
 
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,

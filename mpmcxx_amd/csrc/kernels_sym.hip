@@ -27,15 +27,11 @@ namespace mpmc {
 __device__ __forceinline__ int stagger_start(int block) { return ((block * 5) & 15) * 4; }
 
 // self-test of the rotation primitive: out[l] = lane id received by lane l (expected (l+1)&63)
-__global__ void k_rot_selftest(int *out_dpp, int *out_perm) {
+__global__ void k_rot_selftest(int *out) {
 	const int lane = threadIdx.x;
-	const int src4 = ((lane + 1) & 63) * 4;
-	out_dpp[lane] = (int)rot_from_next<true>((double)lane, src4);
-	out_perm[lane] = (int)rot_from_next<false>((double)lane, src4);
+	out[lane] = (int)rot_from_next((double)lane);
 }
-void launch_rot_selftest(hipStream_t st, int *out_dpp, int *out_perm) {
-	hipLaunchKernelGGL(k_rot_selftest, dim3(1), dim3(64), 0, st, out_dpp, out_perm);
-}
+void launch_rot_selftest(hipStream_t st, int *out) { hipLaunchKernelGGL(k_rot_selftest, dim3(1), dim3(64), 0, st, out); }
 
 // ------------------------------------------------------------------------------------------------------
 // fused symmetric pair kernel
@@ -58,7 +54,7 @@ struct PairTail {
 //   WAVES : waves per tile pair (1 or 4).  A lone wave's 64 dependent steps take 16 us with LJ alone and 65 us with Ewald + field +
 //           Thole store; a table of a few hundred tile pairs leaves most SIMDs empty, so small systems split the steps over four
 //           waves whose sums meet in LDS in wave order (reproducible).  Large tables keep one wave per tile pair (one prologue).
-template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool DPP, bool EXT = false, bool ALPHA2 = false, bool TAIL = false, int WAVES = (TAIL ? 4 : 1)>
+template <bool ORTHO, bool ES, int FIELD, bool THOLE, bool EXT = false, bool ALPHA2 = false, bool TAIL = false, int WAVES = (TAIL ? 4 : 1)>
 __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, FusedParams fp, const int2 *__restrict__ tile_pairs,
                                                    const int *__restrict__ cls, double *__restrict__ block_part, int *__restrict__ block_cnt,
                                                    double *__restrict__ fpart /*[nt][n_pad][3]*/, double2 *__restrict__ ab, PairTail tail = PairTail{},
@@ -81,7 +77,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, 
 	const bool diag = (IJ.x == IJ.y);
 	const int i = IJ.x * kTile + lane;
 	const int j0 = IJ.y * kTile;
-	const int src4 = ((lane + 1) & 63) * 4;
 	// tile-pair class (wave-uniform): whole tile pair beyond the cutoff / beyond the Thole damping range
 	const int cl = TAIL ? 0 : cls[tp]; // (the single-launch form of small systems carries no classes: every tile pair is "near")
 	const bool beyond = (cl & CLS_BEYOND_CUTOFF) != 0;
@@ -287,9 +282,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, 
 		}
 		if (store_thole) ab_tile[s * kTile + lane] = make_double2(ta, tb);
 		if (FIELD != 0 && !last) {
-			gx = rot_from_next<DPP>(gx, src4);
-			gy = rot_from_next<DPP>(gy, src4);
-			gz = rot_from_next<DPP>(gz, src4);
+			gx = rot_from_next(gx);
+			gy = rot_from_next(gy);
+			gz = rot_from_next(gz);
 		}
 	}
 
@@ -420,76 +415,52 @@ __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, 
 }
 
 template <bool ORTHO, bool ES, int FIELD, bool THOLE>
-static void launch_fused_t(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, const int *cls,
-                           int ntp, double *bpart, int *bcnt, double *fpart, double2 *ab, const int *tp_list) {
-	if (FIELD == 1 && fp.polar_ewald_alpha != fp.ewald_alpha) { // two different Ewald alphas: every extension compiled in, ds_bpermute or DPP
-		if (dpp)
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
-		else
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
-		return;
-	}
-	if ((ES && fp.wolf) || fp.fh_order) { // extended variant (Wolf / Feynman-Hibbs): DPP rotation only when the self-test allows it
-		if (dpp)
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
-		else
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
-		return;
-	}
-	if (fp.pair_waves == 4) { // small table: four waves per tile pair
-		if (dpp)
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true, false, false, false, 4>), dim3(ntp), dim3(4 * kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
-		else
-			hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false, false, false, false, 4>), dim3(ntp), dim3(4 * kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
-		return;
-	}
-	if (dpp)
-		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, true>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
-	else
-		hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, false>), dim3(ntp), dim3(kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list);
+static void launch_fused_t(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, const int *cls, int ntp,
+                           double *bpart, int *bcnt, double *fpart, double2 *ab, const int *tp_list) {
+#define MPMC_PF(EXT, A2, W) \
+	hipLaunchKernelGGL((k_pair_fused<ORTHO, ES, FIELD, THOLE, EXT, A2, false, W>), dim3(ntp), dim3(W * kTile), 0, st, at, bx, fp, tp, cls, bpart, bcnt, fpart, ab, PairTail{}, tp_list)
+	if (FIELD == 1 && fp.polar_ewald_alpha != fp.ewald_alpha) MPMC_PF(true, true, 1); // two different Ewald alphas: every extension compiled in
+	else if ((ES && fp.wolf) || fp.fh_order) MPMC_PF(true, false, 1);                 // Wolf / Feynman-Hibbs
+	else if (fp.pair_waves == 4) MPMC_PF(false, false, 4);                            // small table: four waves per tile pair
+	else MPMC_PF(false, false, 1);
+#undef MPMC_PF
 }
 
 template <bool ORTHO>
-static void launch_fused_o(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, const int *cls,
+static void launch_fused_o(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tp, const int *cls,
                            int ntp, double *bpart, int *bcnt, double *fpart, double2 *ab, const int *tp_list) {
 	const bool thole = fp.do_thole && ab;
 	if (!fp.do_es && thole) // (store-only sweeps of polarizable trial moves)
-		launch_fused_t<ORTHO, false, 0, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
+		launch_fused_t<ORTHO, false, 0, true>(st, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
 	else if (!fp.do_es)
-		launch_fused_t<ORTHO, false, 0, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
+		launch_fused_t<ORTHO, false, 0, false>(st, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
 	else if (fp.do_field == 0)
-		launch_fused_t<ORTHO, true, 0, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
+		launch_fused_t<ORTHO, true, 0, false>(st, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
 	else if (fp.do_field == 1) {
-		if (thole) launch_fused_t<ORTHO, true, 1, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
-		else launch_fused_t<ORTHO, true, 1, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
+		if (thole) launch_fused_t<ORTHO, true, 1, true>(st, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
+		else launch_fused_t<ORTHO, true, 1, false>(st, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
 	} else {
-		if (thole) launch_fused_t<ORTHO, true, 2, true>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
-		else launch_fused_t<ORTHO, true, 2, false>(st, dpp, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
+		if (thole) launch_fused_t<ORTHO, true, 2, true>(st, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
+		else launch_fused_t<ORTHO, true, 2, false>(st, at, bx, fp, tp, cls, ntp, bpart, bcnt, fpart, ab, tp_list);
 	}
 }
 
 // small systems, LJ (+ LRC) only: one launch, results land in `out_host` (pinned, device-visible) when the stream has drained
-void launch_pair_lj_single(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs, int n_tile_pairs,
+void launch_pair_lj_single(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs, int n_tile_pairs,
                            double *block_part, int *block_cnt, int *counter, double *out_host, double seq) {
 	const PairTail tail{counter, out_host, seq};
 	dim3 grid(n_tile_pairs), block(4 * kTile);
-#define MPMC_LJ1(O, D) \
-	hipLaunchKernelGGL((k_pair_fused<O, false, 0, false, D, false, false, true>), grid, block, 0, st, at, bx, fp, tile_pairs, nullptr, block_part, block_cnt, nullptr, nullptr, tail)
-	if (bx.ortho) {
-		if (dpp) MPMC_LJ1(true, true);
-		else MPMC_LJ1(true, false);
-	} else {
-		if (dpp) MPMC_LJ1(false, true);
-		else MPMC_LJ1(false, false);
-	}
-#undef MPMC_LJ1
+	if (bx.ortho)
+		hipLaunchKernelGGL((k_pair_fused<true, false, 0, false, false, false, true>), grid, block, 0, st, at, bx, fp, tile_pairs, nullptr, block_part, block_cnt, nullptr, nullptr, tail);
+	else
+		hipLaunchKernelGGL((k_pair_fused<false, false, 0, false, false, false, true>), grid, block, 0, st, at, bx, fp, tile_pairs, nullptr, block_part, block_cnt, nullptr, nullptr, tail);
 }
 
-void launch_pair_fused(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
+void launch_pair_fused(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
                        const int *cls, int n_tile_pairs, double *block_part, int *block_cnt, double *fpart, double2 *ab, const int *tp_list) {
 	if (n_tile_pairs <= 0) return;
-	if (bx.ortho) launch_fused_o<true>(st, dpp, at, bx, fp, tile_pairs, cls, n_tile_pairs, block_part, block_cnt, fpart, ab, tp_list);
-	else launch_fused_o<false>(st, dpp, at, bx, fp, tile_pairs, cls, n_tile_pairs, block_part, block_cnt, fpart, ab, tp_list);
+	if (bx.ortho) launch_fused_o<true>(st, at, bx, fp, tile_pairs, cls, n_tile_pairs, block_part, block_cnt, fpart, ab, tp_list);
+	else launch_fused_o<false>(st, at, bx, fp, tile_pairs, cls, n_tile_pairs, block_part, block_cnt, fpart, ab, tp_list);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -622,57 +593,8 @@ void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, cons
 }
 
 // ------------------------------------------------------------------------------------------------------
-// tile-pair work lists of the two Jacobi kernels: stable compaction of the class array (single block, fixed order,
-// so the block -> tile pair map is the same in every launch)
-//   lists[0 .. ntp)        tile pairs whose tensors are stored (inside the damping range, diagonal tiles included)
-//   lists[ntp .. 2 ntp)    tile pairs beyond the damping range
-//   counts[0], counts[1]   their lengths
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_build_lists(const int *__restrict__ cls, int ntp, int *__restrict__ lists, int *__restrict__ counts) {
-	__shared__ int s_near[1024], s_far[1024];
-	const int t = threadIdx.x;
-	const int per = (ntp + 1023) / 1024;
-	const int b0 = t * per, b1 = min(ntp, b0 + per);
-	int nn = 0, nf = 0;
-	for (int k = b0; k < b1; ++k) {
-		if (cls[k] & CLS_THOLE_FAR) nf++;
-		else nn++;
-	}
-	s_near[t] = nn;
-	s_far[t] = nf;
-	__syncthreads();
-	for (int off = 1; off < 1024; off <<= 1) { // inclusive Hillis-Steele scan
-		const int vn = (t >= off) ? s_near[t - off] : 0, vf = (t >= off) ? s_far[t - off] : 0;
-		__syncthreads();
-		s_near[t] += vn;
-		s_far[t] += vf;
-		__syncthreads();
-	}
-	int on = s_near[t] - nn, of = s_far[t] - nf;
-	for (int k = b0; k < b1; ++k) {
-		if (cls[k] & CLS_THOLE_FAR) lists[ntp + of++] = k;
-		else lists[on++] = k;
-	}
-	if (t == 1023) {
-		counts[0] = s_near[1023];
-		counts[1] = s_far[1023];
-	}
-}
-void launch_build_lists(hipStream_t st, const int *cls, int n_tile_pairs, int *lists, int *counts) {
-	hipLaunchKernelGGL(k_build_lists, dim3(1), dim3(1024), 0, st, cls, n_tile_pairs, lists, counts);
-}
-
-// ------------------------------------------------------------------------------------------------------
 // One Jacobi contraction (reference contract_dipoles :3564-3598 over the A matrix of thole_amatrix :2661-2770).
 // For the pair (i,j):   F_i -= a mu_j - b d (d.mu_j),   F_j -= a mu_i - b d (d.mu_i),   T = a I - b d(x)d.
-//
-//   k_dipole_iter_stream  tile pairs inside the damping range: (a,b) streamed from the compact store, 16 B per
-//                         unordered pair, each block 64 KiB contiguous.  HBM-bound by construction: 33 flop per 16 B.
-//                         Masked pairs were stored as (0,0): the loop carries no predicates.
-//   k_dipole_iter_far     tile pairs beyond lambda r = kTholeFarX (damping dropped, kernels.h): a = 1/r^3, b = 3/r^5 recomputed from the
-//                         positions (v_rsq_f64 + 1 Newton step).  fp64-bound, no HBM traffic beyond the atom tiles.
-// Both write the partial slots [source tile][atom] of the same buffer; every slot is written exactly once per
-// iteration by exactly one of the two kernels.
 // ------------------------------------------------------------------------------------------------------
 template <bool ORTHO>
 __device__ __forceinline__ void image_vec(const Box &bx, double dx, double dy, double dz, double &ox, double &oy, double &oz) {
@@ -686,196 +608,11 @@ __device__ __forceinline__ void image_vec(const Box &bx, double dx, double dy, d
 	}
 }
 
-template <bool ORTHO, bool DPP>
-__global__ __launch_bounds__(64) void k_dipole_iter_stream(AtomsDev at, Box bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
-                                                           const int *__restrict__ list, const int *__restrict__ count,
-                                                           const double2 *__restrict__ ab, double *__restrict__ part /*[nt][n_pad][3]*/) {
-	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_mx[kTile], s_my[kTile], s_mz[kTile];
-	__shared__ double s_g[3 * kTile];
-	if ((int)blockIdx.x >= count[0]) return;
-	const int lane = threadIdx.x;
-	const int tp = list[blockIdx.x];
-	const int2 IJ = tile_pairs[tp];
-	const bool diag = (IJ.x == IJ.y);
-	const int i = IJ.x * kTile + lane;
-	const int j0 = IJ.y * kTile;
-	const int src4 = ((lane + 1) & 63) * 4;
-
-	const double4 pi = at.xyzq[i];
-	const double mix = mu[3 * (size_t)i], miy = mu[3 * (size_t)i + 1], miz = mu[3 * (size_t)i + 2];
-	{
-		const double4 pj = at.xyzq[j0 + lane];
-		s_x[lane] = pj.x;
-		s_y[lane] = pj.y;
-		s_z[lane] = pj.z;
-		s_mx[lane] = mu[3 * (size_t)(j0 + lane)];
-		s_my[lane] = mu[3 * (size_t)(j0 + lane) + 1];
-		s_mz[lane] = mu[3 * (size_t)(j0 + lane) + 2];
-	}
-	__syncthreads();
-
-	const double2 *__restrict__ abt = ab + (size_t)tp * (kTile * kTile) + lane;
-	double fx = 0, fy = 0, fz = 0, gx = 0, gy = 0, gz = 0;
-	// 64 steps (off-diagonal, staggered start) or 32 steps (diagonal, s = 1..32): always whole chunks of 4
-	const int s_first = diag ? 1 : stagger_start(tp), n_steps = diag ? 32 : 64;
-	// software pipeline: the (a,b) of the NEXT 4 steps are in flight while the current 4 are applied
-	double2 cur[4], nxt[4];
-#pragma unroll
-	for (int u = 0; u < 4; ++u) cur[u] = ld_stream<true>(abt + (diag ? (s_first + u) : ((s_first + u) & 63)) * kTile);
-	for (int kc = 0; kc < n_steps; kc += 4) {
-		const bool more = (kc + 4 < n_steps);
-		if (more) {
-#pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const int sn = diag ? (s_first + kc + 4 + u) : ((s_first + kc + 4 + u) & 63);
-				nxt[u] = ld_stream<true>(abt + sn * kTile);
-			}
-		}
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const int s = diag ? (s_first + kc + u) : ((s_first + kc + u) & 63);
-			const int jl = (lane + s) & 63;
-			const double2 t = cur[u];
-			double ox, oy, oz;
-			image_vec<ORTHO>(bx, pi.x - s_x[jl], pi.y - s_y[jl], pi.z - s_z[jl], ox, oy, oz);
-			const double mjx = s_mx[jl], mjy = s_my[jl], mjz = s_mz[jl];
-			const double dj = t.y * fma(oz, mjz, fma(oy, mjy, ox * mjx));
-			const double di = t.y * fma(oz, miz, fma(oy, miy, ox * mix));
-			fx = fma(-t.x, mjx, fma(dj, ox, fx));
-			fy = fma(-t.x, mjy, fma(dj, oy, fy));
-			fz = fma(-t.x, mjz, fma(dj, oz, fz));
-			gx = fma(-t.x, mix, fma(di, ox, gx));
-			gy = fma(-t.x, miy, fma(di, oy, gy));
-			gz = fma(-t.x, miz, fma(di, oz, gz));
-			if (kc + u != n_steps - 1) {
-				gx = rot_from_next<DPP>(gx, src4);
-				gy = rot_from_next<DPP>(gy, src4);
-				gz = rot_from_next<DPP>(gz, src4);
-			}
-		}
-		if (more) {
-#pragma unroll
-			for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
-		}
-	}
-	const int jl_last = (lane + s_first + n_steps - 1) & 63;
-	const int nt_pad3 = at.n_pad * 3;
-	if (diag) {
-		s_g[3 * jl_last + 0] = gx;
-		s_g[3 * jl_last + 1] = gy;
-		s_g[3 * jl_last + 2] = gz;
-		__syncthreads();
-		double *o = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)i;
-		o[0] = fx + s_g[3 * lane + 0];
-		o[1] = fy + s_g[3 * lane + 1];
-		o[2] = fz + s_g[3 * lane + 2];
-	} else {
-		double *oi = part + (size_t)IJ.y * nt_pad3 + 3 * (size_t)i;
-		oi[0] = fx;
-		oi[1] = fy;
-		oi[2] = fz;
-		double *oj = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + jl_last);
-		oj[0] = gx;
-		oj[1] = gy;
-		oj[2] = gz;
-	}
-}
-
-template <bool ORTHO, bool DPP>
-__global__ __launch_bounds__(64) void k_dipole_iter_far(AtomsDev at, Box bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
-                                                        const int *__restrict__ list, const int *__restrict__ count,
-                                                        double *__restrict__ part /*[nt][n_pad][3]*/) {
-	__shared__ double s_x[kTile], s_y[kTile], s_z[kTile], s_mx[kTile], s_my[kTile], s_mz[kTile], s_v[kTile];
-	if ((int)blockIdx.x >= count[1]) return;
-	const int lane = threadIdx.x;
-	const int tp = list[blockIdx.x];
-	const int2 IJ = tile_pairs[tp]; // never a diagonal tile (distance 0 is not "far")
-	const int i = IJ.x * kTile + lane;
-	const int j0 = IJ.y * kTile;
-	const int src4 = ((lane + 1) & 63) * 4;
-
-	const double4 pi = at.xyzq[i];
-	const double vi = (at.mf[i].y & AF_PAD) ? 0.0 : 1.0;
-	const double mix = mu[3 * (size_t)i], miy = mu[3 * (size_t)i + 1], miz = mu[3 * (size_t)i + 2];
-	{
-		const double4 pj = at.xyzq[j0 + lane];
-		s_x[lane] = pj.x;
-		s_y[lane] = pj.y;
-		s_z[lane] = pj.z;
-		s_mx[lane] = mu[3 * (size_t)(j0 + lane)];
-		s_my[lane] = mu[3 * (size_t)(j0 + lane) + 1];
-		s_mz[lane] = mu[3 * (size_t)(j0 + lane) + 2];
-		s_v[lane] = (at.mf[j0 + lane].y & AF_PAD) ? 0.0 : 1.0;
-	}
-	__syncthreads();
-
-	double fx = 0, fy = 0, fz = 0, gx = 0, gy = 0, gz = 0;
-#pragma unroll 4
-	for (int s = 0; s < kTile; ++s) {
-		const int jl = (lane + s) & 63;
-		double ox, oy, oz;
-		image_vec<ORTHO>(bx, pi.x - s_x[jl], pi.y - s_y[jl], pi.z - s_z[jl], ox, oy, oz);
-		// undamped dipole tensor: a = 1/r^3, b = 3/r^5 (beyond lambda r = kTholeFarX the damping is dropped, kernels.h)
-		const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
-		const double ir = fast_rsqrt_1(r2);
-		const double ir2 = ir * ir;
-		const double ta = (vi * s_v[jl]) * (ir2 * ir);
-		const double tb = 3.0 * ta * ir2;
-		const double mjx = s_mx[jl], mjy = s_my[jl], mjz = s_mz[jl];
-		const double dj = tb * fma(oz, mjz, fma(oy, mjy, ox * mjx));
-		const double di = tb * fma(oz, miz, fma(oy, miy, ox * mix));
-		fx = fma(-ta, mjx, fma(dj, ox, fx));
-		fy = fma(-ta, mjy, fma(dj, oy, fy));
-		fz = fma(-ta, mjz, fma(dj, oz, fz));
-		gx = fma(-ta, mix, fma(di, ox, gx));
-		gy = fma(-ta, miy, fma(di, oy, gy));
-		gz = fma(-ta, miz, fma(di, oz, gz));
-		if (s != kTile - 1) {
-			gx = rot_from_next<DPP>(gx, src4);
-			gy = rot_from_next<DPP>(gy, src4);
-			gz = rot_from_next<DPP>(gz, src4);
-		}
-	}
-	const int jl_last = (lane + kTile - 1) & 63;
-	const int nt_pad3 = at.n_pad * 3;
-	double *oi = part + (size_t)IJ.y * nt_pad3 + 3 * (size_t)i;
-	oi[0] = fx;
-	oi[1] = fy;
-	oi[2] = fz;
-	double *oj = part + (size_t)IJ.x * nt_pad3 + 3 * (size_t)(j0 + jl_last);
-	oj[0] = gx;
-	oj[1] = gy;
-	oj[2] = gz;
-}
-
-void launch_dipole_iter_stream(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                               const int *lists, const int *counts, int n_tile_pairs, const double2 *ab, double *part) {
-	dim3 grid(n_tile_pairs), block(kTile); // blocks beyond the list length exit at once (the length lives on the device)
-	if (bx.ortho) {
-		if (dpp) hipLaunchKernelGGL((k_dipole_iter_stream<true, true>), grid, block, 0, st, at, bx, mu, tile_pairs, lists, counts, ab, part);
-		else hipLaunchKernelGGL((k_dipole_iter_stream<true, false>), grid, block, 0, st, at, bx, mu, tile_pairs, lists, counts, ab, part);
-	} else {
-		if (dpp) hipLaunchKernelGGL((k_dipole_iter_stream<false, true>), grid, block, 0, st, at, bx, mu, tile_pairs, lists, counts, ab, part);
-		else hipLaunchKernelGGL((k_dipole_iter_stream<false, false>), grid, block, 0, st, at, bx, mu, tile_pairs, lists, counts, ab, part);
-	}
-}
-
-void launch_dipole_iter_far(hipStream_t st, bool dpp, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
-                            const int *lists, const int *counts, int n_tile_pairs, double *part) {
-	if (!bx.ortho) return; // only orthorhombic cells are classified: the far list is empty
-	dim3 grid(n_tile_pairs), block(kTile);
-	const int *far_list = lists + n_tile_pairs;
-	if (dpp) hipLaunchKernelGGL((k_dipole_iter_far<true, true>), grid, block, 0, st, at, bx, mu, tile_pairs, far_list, counts, part);
-	else hipLaunchKernelGGL((k_dipole_iter_far<true, false>), grid, block, 0, st, at, bx, mu, tile_pairs, far_list, counts, part);
-}
-
 // ------------------------------------------------------------------------------------------------------
 // Single-launch form of the same contraction (the default): one kernel walks ALL tile pairs, streaming the stored ones
 // and recomputing the far ones (wave-uniform branch), so HBM-bound and fp64-bound waves share the CUs.
-//   JACC selects how the j-side accumulators meet their atoms:
-//     0  registers rotated by one lane per step with v_mov_b32_dpp wave_rol:1 (6 VALU issues per step)
-//     1  the same through ds_bpermute_b32 (fallback when the DPP self-test fails)
-//   (ds_add_f64 into an LDS image of the j-atoms was measured too: 0.113 ms against 0.105 ms per launch, dropped.)
+//   The j-side accumulators meet their atoms in registers, rotated by one lane per step with v_mov_b32_dpp wave_rol:1 (6 VALU issues
+//   per step; ds_bpermute_b32 and ds_add_f64 into an LDS image of the j-atoms were measured and dropped: 0.113 against 0.105 ms).
 // ------------------------------------------------------------------------------------------------------
 // FAR and the uniform-image mask UM (3 bits, one per dimension) are wave-uniform properties of the tile pair: the walk is instantiated
 // for each combination so that the inner loop carries no branch.  A set UM bit: in that dimension the periodic image index is the same
@@ -896,7 +633,7 @@ struct HybAcc {
 // RECOMP (with !FAR): nothing is stored at all (solver MATRIX_FREE, the store does not fit its budget): the damped tensor of a tile pair
 // inside the damping range is rebuilt from the positions with the arithmetic of the pair sweep (thole_amatrix :2731-2757); t.x then
 // carries the pair's 0/1 mask (padded slots, the half-counted step 32 of diagonal tiles) and t.y the damping constant lambda.
-template <bool ORTHO, int JACC, bool FAR, int UM, bool ROT, bool RECOMP = false>
+template <bool ORTHO, bool FAR, int UM, bool ROT, bool RECOMP = false>
 __device__ __forceinline__ void hyb_step(const Box &bx, const HybLds &L, const int jl, const int src4, const double pix, const double piy,
                                          const double piz, const double mix, const double miy, const double miz, double2 t, const double padi,
                                          HybAcc &A) {
@@ -943,13 +680,13 @@ __device__ __forceinline__ void hyb_step(const Box &bx, const HybLds &L, const i
 	A.gy = fma(-t.x, miy, fma(di, oy, A.gy));
 	A.gz = fma(-t.x, miz, fma(di, oz, A.gz));
 	if (ROT) {
-		A.gx = rot_from_next<JACC == 0>(A.gx, src4);
-		A.gy = rot_from_next<JACC == 0>(A.gy, src4);
-		A.gz = rot_from_next<JACC == 0>(A.gz, src4);
+		A.gx = rot_from_next(A.gx);
+		A.gy = rot_from_next(A.gy);
+		A.gz = rot_from_next(A.gz);
 	}
 }
 
-template <bool ORTHO, int JACC, int PIPE, bool FAR, int UM>
+template <bool ORTHO, int PIPE, bool FAR, int UM>
 __device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const double pix, const double piy, const double piz, const double mix,
                                          const double miy, const double miz, const double2 *__restrict__ abt, const int s_first,
                                          const int n_steps, const int lane, const int src4, const double padi, HybAcc &A, const double lambda = 0.0,
@@ -959,19 +696,19 @@ __device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const d
 		for (int k = 0; k < n_steps; ++k) {
 			const int s = s_first + k;
 			const double mask = (diag && s == 32 && lane >= 32) ? 0.0 : vi;
-			if (k != n_steps - 1) hyb_step<ORTHO, JACC, false, UM, true, true>(bx, L, jb + k, src4, pix, piy, piz, mix, miy, miz, make_double2(mask, lambda), padi, A);
-			else hyb_step<ORTHO, JACC, false, UM, false, true>(bx, L, jb + k, src4, pix, piy, piz, mix, miy, miz, make_double2(mask, lambda), padi, A);
+			if (k != n_steps - 1) hyb_step<ORTHO, false, UM, true, true>(bx, L, jb + k, src4, pix, piy, piz, mix, miy, miz, make_double2(mask, lambda), padi, A);
+			else hyb_step<ORTHO, false, UM, false, true>(bx, L, jb + k, src4, pix, piy, piz, mix, miy, miz, make_double2(mask, lambda), padi, A);
 		}
 		return;
 	}
 	if (FAR) {
 		for (int kc = 0; kc < n_steps - 4; kc += 4, jb += 4) {
 #pragma unroll
-			for (int u = 0; u < 4; ++u) hyb_step<ORTHO, JACC, true, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
+			for (int u = 0; u < 4; ++u) hyb_step<ORTHO, true, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
 		}
 #pragma unroll
-		for (int u = 0; u < 3; ++u) hyb_step<ORTHO, JACC, true, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
-		hyb_step<ORTHO, JACC, true, UM, false>(bx, L, jb + 3, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
+		for (int u = 0; u < 3; ++u) hyb_step<ORTHO, true, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
+		hyb_step<ORTHO, true, UM, false>(bx, L, jb + 3, src4, pix, piy, piz, mix, miy, miz, make_double2(0, 0), padi, A);
 		return;
 	}
 	// rolling prefetch ring: the (a,b) of step k + PIPE is requested as soon as the registers of step k are consumed, so PIPE
@@ -986,15 +723,15 @@ __device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const d
 		pn += PIPE * kTile;
 #pragma unroll
 		for (int u = 0; u < PIPE; ++u) {
-			hyb_step<ORTHO, JACC, false, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
+			hyb_step<ORTHO, false, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
 			buf[u] = ld_stream<true>(pn + u * kTile); // refill the slot just consumed: in place, no register copies
 			__builtin_amdgcn_sched_barrier(0); // keep the steps in program order (no hoisting of all LDS reads to the top)
 		}
 	}
 #pragma unroll
 	for (int u = 0; u < PIPE; ++u) {
-		if (u != PIPE - 1) hyb_step<ORTHO, JACC, false, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
-		else hyb_step<ORTHO, JACC, false, UM, false>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
+		if (u != PIPE - 1) hyb_step<ORTHO, false, UM, true>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
+		else hyb_step<ORTHO, false, UM, false>(bx, L, jb + u, src4, pix, piy, piz, mix, miy, miz, buf[u], padi, A);
 		__builtin_amdgcn_sched_barrier(0);
 	}
 }
@@ -1002,7 +739,7 @@ __device__ __forceinline__ void hyb_walk(const Box &bx, const HybLds &L, const d
 // W waves share one tile pair: wave w walks the steps [w n/W, (w+1) n/W) of the same 64 i-atoms, so a tile pair is W short
 // waves on W SIMDs instead of one long one (12 403 long waves on 1024 SIMDs left a quarter of the CU-time idle in the
 // tail of the launch).  The W partial sums of every atom meet in LDS and are added in wave order (fixed => reproducible).
-template <bool ORTHO, int JACC, int PIPE, int W>
+template <bool ORTHO, int PIPE, int W>
 __device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
                                           const int *__restrict__ cls, const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab,
                                           double *__restrict__ part /*[nt][n_pad][3]*/, const int tp, const double lambda = 0.0) {
@@ -1040,7 +777,7 @@ __device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, con
 	// 64 steps (off-diagonal, s = 0..63) or 32 steps (diagonal, s = 1..32), W equal shares of whole PIPE rounds
 	const int n_steps = (diag ? 32 : 64) / W;
 	const int s_first = (diag ? 1 : 0) + w * n_steps;
-#define MPMC_WALK(F, U) hyb_walk<ORTHO, JACC, PIPE, F, U>(bx, L, qx, qy, qz, mix, miy, miz, abt, s_first, n_steps, lane, src4, padi, A, lambda, vi, diag)
+#define MPMC_WALK(F, U) hyb_walk<ORTHO, PIPE, F, U>(bx, L, qx, qy, qz, mix, miy, miz, abt, s_first, n_steps, lane, src4, padi, A, lambda, vi, diag)
 #define MPMC_WALK_UM(F)                                                       \
 	switch (um) {                                                             \
 	case 1: MPMC_WALK(F, 1); break;                                           \
@@ -1108,51 +845,21 @@ __device__ __forceinline__ void hyb_block(const AtomsDev &at, const Box &bx, con
 	}
 }
 
-template <bool ORTHO, int JACC, int PIPE = 8, int W = 1>
+template <bool ORTHO, int PIPE = 8, int W = 1>
 __global__ __launch_bounds__(64 * W) void k_dipole_iter_hybrid(AtomsDev at, Box bx, const double *__restrict__ mu,
                                                                 const int2 *__restrict__ tile_pairs, const int *__restrict__ cls,
                                                                 const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab,
                                                                 double *__restrict__ part, double lambda, const int *__restrict__ converged) {
 	if (converged && *converged != 0) return; // an iteration enqueued ahead of the verdict of a precision-terminated solve
-	hyb_block<ORTHO, JACC, PIPE, W>(at, bx, mu, tile_pairs, cls, tp_shift, ab, part, blockIdx.x, lambda);
+	hyb_block<ORTHO, PIPE, W>(at, bx, mu, tile_pairs, cls, tp_shift, ab, part, blockIdx.x, lambda);
 }
 
-// the same contraction for B systems in ONE launch (blockIdx.y = system): the images of a path-integral ensemble run their Jacobi
-// iterations in lockstep, so one launch carries B x 12 403 waves instead of 12 403 -- the launch tail (a quarter of the CU-time of a
-// single-system launch) and the per-launch gaps shrink by B.  `cur` selects the dipole buffer every system reads.
-template <bool ORTHO, int JACC, int PIPE = 8>
-__global__ __launch_bounds__(64) void k_dipole_iter_hybrid_b(const SolveBead *__restrict__ sb, Box bx, int cur) {
-	// the members one by one (scalar loads): a by-value copy of the 160-byte record went through 152 B of scratch
-	const SolveBead *__restrict__ b = sb + blockIdx.y;
-	const AtomsDev at = b->at;
-	hyb_block<ORTHO, JACC, PIPE, 1>(at, bx, b->mu[cur], b->tile_pairs, b->cls, b->tp_shift, b->ab, b->part, blockIdx.x);
-}
-
-void launch_dipole_iter_hybrid_batched(hipStream_t st, int jacc, const SolveBead *sb, int n_beads, const Box &bx, int cur, int n_tile_pairs) {
-	dim3 grid(n_tile_pairs, n_beads), block(kTile);
-	if (bx.ortho) {
-		if (jacc == 1) hipLaunchKernelGGL((k_dipole_iter_hybrid_b<true, 1>), grid, block, 0, st, sb, bx, cur);
-		else hipLaunchKernelGGL((k_dipole_iter_hybrid_b<true, 0>), grid, block, 0, st, sb, bx, cur);
-	} else {
-		if (jacc == 1) hipLaunchKernelGGL((k_dipole_iter_hybrid_b<false, 1>), grid, block, 0, st, sb, bx, cur);
-		else hipLaunchKernelGGL((k_dipole_iter_hybrid_b<false, 0>), grid, block, 0, st, sb, bx, cur);
-	}
-}
-
-void launch_dipole_iter_hybrid(hipStream_t st, int jacc, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
+void launch_dipole_iter_hybrid(hipStream_t st, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                                const int *cls, const double4 *tp_shift, int n_tile_pairs, const double2 *ab, double *part, double polar_damp,
                                const int *converged) {
 	dim3 grid(n_tile_pairs);
-#define MPMC_LAUNCH_HYB(O, J, P, W) \
-	hipLaunchKernelGGL((k_dipole_iter_hybrid<O, J, P, W>), grid, dim3(kTile * W), 0, st, at, bx, mu, tile_pairs, cls, tp_shift, ab, part, polar_damp, converged)
-	if (bx.ortho) {
-		if (jacc == 1) MPMC_LAUNCH_HYB(true, 1, 8, 1);
-		else MPMC_LAUNCH_HYB(true, 0, 8, 1);
-	} else {
-		if (jacc == 1) MPMC_LAUNCH_HYB(false, 1, 8, 1);
-		else MPMC_LAUNCH_HYB(false, 0, 8, 1);
-	}
-#undef MPMC_LAUNCH_HYB
+	if (bx.ortho) hipLaunchKernelGGL((k_dipole_iter_hybrid<true>), grid, dim3(kTile), 0, st, at, bx, mu, tile_pairs, cls, tp_shift, ab, part, polar_damp, converged);
+	else hipLaunchKernelGGL((k_dipole_iter_hybrid<false>), grid, dim3(kTile), 0, st, at, bx, mu, tile_pairs, cls, tp_shift, ab, part, polar_damp, converged);
 }
 
 } // namespace mpmc

@@ -6,113 +6,11 @@
 using namespace mpmc;
 
 // ---- path integral ---------------------------------------------------------------------------------------
-// Enqueue one full evaluation of every system.  Systems whose solve can be deferred (same device, same box and options, fixed
-// iteration count, stored-tensor single-launch Jacobi) run everything up to the static field on their own streams -- the pair
-// sweeps of different systems overlap -- and then their dipole iterations together: one launch per iteration for the whole group
-// (SolveBead array, blockIdx.y = system) on the first system's stream, which also carries the final copies of every member.
-static bool same_solve_shape(const mpmc_ctx *a, const mpmc_ctx *b) {
-	return a->device == b->device && a->n == b->n && a->n_pad == b->n_pad && a->n_tile_pairs == b->n_tile_pairs &&
-	       std::memcmp(&a->opts, &b->opts, sizeof(mpmc_options)) == 0 && std::memcmp(a->box.b, b->box.b, sizeof(a->box.b)) == 0 &&
-	       a->jacc == b->jacc && a->no_uniform == b->no_uniform && a->no_classes == b->no_classes;
-}
-static int pi_enqueue_all(mpmc_ctx **beads, int n_local) {
-	// Opt-in (MPMC_PI_LOCKSTEP=1).  Measured on MI355X, 32 beads of the 10 000-atom box: the lockstep launches run each bead's
-	// contraction exactly as fast as a launch of its own (0.107 ms per bead: the kernel is issue-bound, not tail-bound), while
-	// independent streams let one bead's pair sweep fill the stalls of another bead's iterations -- 650 evaluations/s in lockstep
-	// against 737 on independent streams.  The lockstep form stays for its clean per-launch timings.
-	const char *e = std::getenv("MPMC_PI_LOCKSTEP");
-	const bool lockstep = e && e[0] == '1';
-	for (int b = 0; b < n_local; b++) {
-		mpmc_ctx *c = beads[b];
-		if (!c) return MPMC_ERR_ARG;
-		c->defer_solve = lockstep && n_local > 1;
-		int rc = enqueue(c, full_mask(c));
-		c->defer_solve = false;
-		if (rc != MPMC_OK) return rc;
-	}
-	std::vector<char> done(n_local, 0);
-	for (int lead = 0; lead < n_local; lead++) {
-		if (done[lead] || !beads[lead]->solve_deferred) continue;
-		std::vector<mpmc_ctx *> grp;
-		for (int b = lead; b < n_local; b++)
-			if (!done[b] && beads[b]->solve_deferred && same_solve_shape(beads[lead], beads[b])) {
-				grp.push_back(beads[b]);
-				done[b] = 1;
-			}
-		mpmc_ctx *L = grp[0];
-		const int nb = (int)grp.size();
-		const mpmc_options &o = L->opts;
-		HIP_TRY(L, hipSetDevice(L->device));
-		hipStream_t st = L->stream;
-		if (nb > L->cap_solve_args) {
-			dev_free(L, &L->d_solve_args, (size_t)L->cap_solve_args);
-			L->cap_solve_args = 0;
-			int rc = dev_alloc(L, &L->d_solve_args, (size_t)nb);
-			if (rc != MPMC_OK) return rc;
-			L->cap_solve_args = nb;
-		}
-		std::vector<SolveBead> &args = L->h_solve_args;
-		args.resize(nb);
-		for (int k = 0; k < nb; k++) {
-			mpmc_ctx *c = grp[k];
-			SolveBead &a = args[k];
-			a.at = atoms_view(c);
-			a.tile_pairs = c->d_tile_pairs;
-			a.cls = c->d_cls;
-			a.tp_shift = (c->no_uniform || c->no_classes) ? nullptr : c->d_tp_shift;
-			a.ab = c->d_ab;
-			a.part = c->d_part;
-			a.mu[0] = c->d_mu[0];
-			a.mu[1] = c->d_mu[1];
-			a.e_static = c->d_e_static;
-			a.e_induced = c->d_e_induced;
-			a.rrms = c->d_rrms;
-			a.scal = c->d_scal;
-			if (k > 0) HIP_TRY(L, hipStreamWaitEvent(st, c->ev_phase, 0)); // the member's pre-solve work (its own stream) is done
-		}
-		HIP_TRY(L, hipMemcpyAsync(L->d_solve_args, args.data(), (size_t)nb * sizeof(SolveBead), hipMemcpyHostToDevice, st));
-		const int want_rrms = o.polar_rrms ? 1 : 0;
-		int cur = 0; // field_finalize wrote mu[0]
-		for (int it = 1; it <= o.polar_max_iter; it++) {
-			{
-				ProfScope p(L, MPMC_K_DIPOLE_ITER);
-				launch_dipole_iter_hybrid_batched(st, L->jacc, L->d_solve_args, nb, L->box, cur, L->n_tile_pairs);
-			}
-			{
-				ProfScope p(L, MPMC_K_REDUCE);
-				launch_dipole_update_batched(st, L->d_solve_args, nb, L->n_pad, L->n_tiles, cur, want_rrms);
-			}
-			cur = 1 - cur;
-		}
-		{
-			ProfScope p(L, MPMC_K_REDUCE);
-			launch_polar_energy_batched(st, L->d_solve_args, nb, cur, want_rrms);
-		}
-		HIP_TRY(L, hipGetLastError());
-		for (int k = 0; k < nb; k++) {
-			mpmc_ctx *c = grp[k];
-			c->mu_cur = cur;
-			c->iters = o.polar_max_iter;
-			c->have_polar = true;
-			c->last_batch = nb;
-			HIP_TRY(L, hipMemcpyAsync(c->h_scal, c->d_scal, (S_COUNT + C_COUNT) * sizeof(double), hipMemcpyDeviceToHost, st));
-			c->sync_stream = st;
-			c->pending = true;
-			c->solve_deferred = false;
-		}
-	}
-	return MPMC_OK;
-}
-
-// systems per launch in the dipole iterations of this context's last evaluation (1: it ran on its own)
-extern "C" int mpmc_last_batch_size(mpmc_ctx *c) { return c ? c->last_batch : 0; }
-
-extern "C" int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sums4[4], mpmc_result *per_bead, int *any_failed) {
-	if (!beads || n_local < 0 || !sums4) return MPMC_ERR_ARG;
-	{ // every bead enqueued before the first wait; the dipole iterations of compatible beads run in lockstep, in shared launches
-		int rc = pi_enqueue_all(beads, n_local);
-		if (rc != MPMC_OK) return rc;
-	}
+// PI_calculate_potential (src/SimulationControl.PathIntegral.cpp:752-805) over the beads of this process: every bead is a complete,
+// independent evaluation on its own context and streams; all of them are enqueued before the first wait, so one bead's pair sweep
+// fills the launch ramps and tails of another bead's dipole iterations (a lockstep form that shared launches between the beads was
+// measured in round 1 -- 650 against 737 evaluations/s -- and removed in round 3).
+static int pi_wait_all(mpmc_ctx **beads, int n_local, double sums4[4], mpmc_result *per_bead, int *any_failed) {
 	sums4[0] = sums4[1] = sums4[2] = sums4[3] = 0;
 	int failed = 0;
 	for (int b = 0; b < n_local; b++) {
@@ -128,6 +26,36 @@ extern "C" int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sum
 	}
 	if (any_failed) *any_failed = failed;
 	return MPMC_OK;
+}
+
+// systems per launch in the dipole iterations of this context's last evaluation: always 1 (kept for ABI stability)
+extern "C" int mpmc_last_batch_size(mpmc_ctx *c) { return c ? 1 : 0; }
+
+extern "C" int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sums4[4], mpmc_result *per_bead, int *any_failed) {
+	if (!beads || n_local < 0 || !sums4) return MPMC_ERR_ARG;
+	for (int b = 0; b < n_local; b++) {
+		if (!beads[b]) return MPMC_ERR_ARG;
+		int rc = enqueue(beads[b], full_mask(beads[b]));
+		if (rc != MPMC_OK) return rc;
+	}
+	return pi_wait_all(beads, n_local, sums4, per_bead, any_failed);
+}
+
+// The same step with every bead's positions handed over in HOST memory (pos[b]: n x 3 doubles, original atom order) -- the boundary as
+// a host program with its own copy of the coordinates uses it.  Bead b's upload (host pass over its 3 n doubles, one asynchronous
+// 32 n-byte copy from the context's pinned mirror on the bead's own stream) is followed at once by bead b's enqueue, so the device
+// works on bead b while the host prepares bead b + 1: the uploads hide behind the evaluations instead of standing in front of them.
+extern "C" int mpmc_pi_potential_local_host(mpmc_ctx **beads, int n_local, const double *const *pos, double sums4[4], mpmc_result *per_bead,
+                                            int *any_failed) {
+	if (!beads || n_local < 0 || !sums4 || !pos) return MPMC_ERR_ARG;
+	for (int b = 0; b < n_local; b++) {
+		mpmc_ctx *c = beads[b];
+		if (!c || !pos[b]) return MPMC_ERR_ARG;
+		int rc = mpmc_update_positions(c, 0, c->n, pos[b]);
+		if (rc != MPMC_OK) return rc;
+		if ((rc = enqueue(c, full_mask(c))) != MPMC_OK) return rc;
+	}
+	return pi_wait_all(beads, n_local, sums4, per_bead, any_failed);
 }
 
 extern "C" double mpmc_pi_finish(const double s[4], int P, double obs4[4]) {

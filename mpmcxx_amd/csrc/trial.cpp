@@ -70,7 +70,7 @@ extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
 	const bool polar = o.polarization && !o.rd_only;
 	const int m = c->trial_count;
 	c->trial_polar_delta = false;
-	static const bool no_polar_delta = [] { const char *e = std::getenv("MPMC_NO_POLAR_DELTA"); return e && e[0] == '1'; }();
+	const bool no_polar_delta = c->tune.no_polar_delta;
 	const bool polar_delta = polar && c->e_real_valid && !no_polar_delta && m <= MPMC_TRIAL_MAX_ATOMS && !o.wolf && !o.feynman_hibbs;
 	if ((polar && !polar_delta) || m > MPMC_TRIAL_MAX_ATOMS || o.wolf || o.feynman_hibbs) { // (the delta kernels carry the base LJ + Ewald terms only)
 		// the dipole solve couples every atom: evaluate the trial configuration in full (still on the device)
@@ -88,7 +88,7 @@ extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
 	hipStream_t st = c->stream;
 	// short moves of non-polarizable boxes travel in the kernel arguments: no staging copy (a trial is launch-bound on the host: every
 	// call saved is ~5 us of a ~25 us move).  The polarizable path keeps the device lists (its field / store kernels read them).
-	static const bool no_inline = [] { const char *e = std::getenv("MPMC_NO_INLINE_MOVE"); return e && e[0] == '1'; }();
+	const bool no_inline = c->tune.no_inline_move;
 	c->trial_inline = !polar_delta && m <= kMvInline && !no_inline;
 	if (c->trial_inline) {
 		for (int t = 0; t < m; t++) {

@@ -112,6 +112,7 @@ def lib():
     L.mpmc_get_dipoles.argtypes = [vp, dp, dp, dp]
     L.mpmc_update_com.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_int)]
     L.mpmc_pi_potential_local.argtypes = [C.POINTER(vp), C.c_int, dp, C.POINTER(Result), C.POINTER(C.c_int)]
+    L.mpmc_pi_potential_local_host.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(dp), dp, C.POINTER(Result), C.POINTER(C.c_int)]
     L.mpmc_pi_finish.argtypes = [dp, C.c_int, dp]
     L.mpmc_last_batch_size.argtypes = [vp]
     L.mpmc_pi_chain_mass_length2.argtypes = [C.c_int, C.c_int, dp, dp, ip]
@@ -144,6 +145,9 @@ def lib():
     L.mpmc_debug_configure.argtypes = [vp, C.c_char_p, C.c_double]
     L.mpmc_debug_last_pair_kernel.argtypes = [vp]
     L.mpmc_debug_erfc_table.argtypes = [C.c_double, dp, dp]
+    L.mpmc_debug_pair_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.mpmc_debug_time_panel.argtypes = [vp, C.c_int, dp]
+    L.mpmc_debug_time_pair.argtypes = [vp, C.c_int, dp]
     _lib = L
     return L
 
@@ -378,6 +382,22 @@ class System:
         self._check(self._L.mpmc_get_tile_stats(self._h, a))
         return {"tile_pairs": a[0], "thole_stored": a[1], "thole_far": a[2], "beyond_cutoff": a[3]}
 
+    def pair_stats(self) -> Dict[str, int]:
+        """exact atom-pair counts behind the tile-pair classes of the last evaluation (mpmc_debug_pair_stats)."""
+        a = (C.c_int64 * 12)()
+        self._check(self._L.mpmc_debug_pair_stats(self._h, a))
+        keys = ["pairs", "pairs_stored", "pairs_far", "pairs_beyond_cutoff", "nonuniform_dims_x_pairs_stored", "nonuniform_dims_x_pairs_far",
+                "pairs_swept", "nonuniform_dims_x_pairs_swept", "tile_pairs", "tile_pairs_stored", "tile_pairs_far", "tile_pairs_beyond_cutoff"]
+        return {k: int(a[i]) for i, k in enumerate(keys)}
+
+    def time_kernel(self, which: str, reps: int = 100) -> float:
+        """ms per launch of the dominant kernels of the LAST evaluation, `reps` launches back to back between one pair of HIP events on the
+        context's stream: which = "panel" (Jacobi contraction) | "pair" (pair sweep)."""
+        v = C.c_double(0.0)
+        fn = self._L.mpmc_debug_time_panel if which == "panel" else self._L.mpmc_debug_time_pair
+        self._check(fn(self._h, int(reps), C.byref(v)))
+        return v.value
+
     def last_batch_size(self) -> int:
         """systems that shared each launch of the dipole iterations in the last evaluation (pi_potential_local batches compatible beads)."""
         return int(self._L.mpmc_last_batch_size(self._h))
@@ -388,16 +408,25 @@ class System:
         return a.value, b.value
 
 
-def pi_potential_local(beads: Sequence[System]):
+def pi_potential_local(beads: Sequence[System], host_positions: Optional[Sequence[np.ndarray]] = None):
     """local leg of SimulationControl::PI_calculate_potential (reference PathIntegral.cpp:752-805):
-    returns (sums4 = ordered sums of {rd, coulombic, polarization, vdw} over this rank's beads, per-bead results, failed)."""
+    returns (sums4 = ordered sums of {rd, coulombic, polarization, vdw} over this rank's beads, per-bead results, failed).
+    host_positions: one C-contiguous (n, 3) float64 array per bead -- the coordinates travel inside the call
+    (mpmc_pi_potential_local_host: bead b's upload overlaps the evaluation of the beads in front of it)."""
     L = lib()
     n = len(beads)
     arr = (C.c_void_p * max(n, 1))(*[b.handle for b in beads])
     sums = np.zeros(4)
     res = (Result * max(n, 1))()
     failed = C.c_int(0)
-    rc = L.mpmc_pi_potential_local(arr, n, _dp(sums), res, C.byref(failed))
+    if host_positions is not None:
+        if len(host_positions) != n:
+            raise ValueError("host_positions: one array per bead")
+        keep = [np.ascontiguousarray(p, dtype=np.float64) for p in host_positions]
+        ptrs = (C.POINTER(C.c_double) * max(n, 1))(*[_dp(p) for p in keep])
+        rc = L.mpmc_pi_potential_local_host(arr, n, ptrs, _dp(sums), res, C.byref(failed))
+    else:
+        rc = L.mpmc_pi_potential_local(arr, n, _dp(sums), res, C.byref(failed))
     if rc != MPMC_OK:
         msg = b""
         for b in beads:

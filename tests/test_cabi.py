@@ -26,13 +26,13 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(syms) >= 30
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, missing
-    assert L.mpmc_abi_version() == 3
+    assert L.mpmc_abi_version() == 4
 
 
 def test_code_object_is_gfx950():
     data = open(mbuild.build_library(), "rb").read()
     assert b"gfx950" in data
-    for kern in (b"k_pair_fused", b"k_recip_sf", b"k_dipole_iter_stream", b"k_dipole_iter_far", b"k_dipole_iter_hybrid", b"k_dipole_iter_panel", b"k_build_panels", b"k_delta_field", b"k_dense_matvec", b"k_gs_tile", b"k_classify", b"k_atom_terms"):
+    for kern in (b"k_pair_fused", b"k_pair_sweep", b"k_recip_sf", b"k_dipole_iter_hybrid", b"k_dipole_iter_panel", b"k_build_panels", b"k_delta_field", b"k_dense_matvec", b"k_gs_tile", b"k_classify", b"k_atom_terms"):
         assert kern in data, kern
 
 
@@ -93,3 +93,16 @@ def test_library_keeps_its_internals_out_of_the_global_namespace():
     head, leg = src.split("def cpu_baseline(", 1)
     leg_body, rest = leg.split("\ndef main(", 1)
     assert "from oracle import" not in head and "from oracle import" not in rest and "import oracle" not in rest
+
+
+def test_library_reads_one_environment_variable_only():
+    """measurement switches travel through mpmc_debug_configure (csrc/context.cpp), not through getenv: the one variable the library
+    reads is MPMC_RCCL_LIB, the path of the RCCL it should dlopen (csrc/comm.cpp)."""
+    import re
+
+    hits = []
+    for dirpath, _, files in os.walk(os.path.join(util.ROOT, "mpmcxx_amd", "csrc")):
+        for f in files:
+            for m in re.finditer(r'getenv\("([A-Z_0-9]+)"\)', open(os.path.join(dirpath, f)).read()):
+                hits.append((f, m.group(1)))
+    assert hits == [("comm.cpp", "MPMC_RCCL_LIB")], hits

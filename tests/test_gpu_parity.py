@@ -225,12 +225,9 @@ def test_pi_local_loop_matches_per_bead_energies():
         b.close()
 
 
-@pytest.mark.parametrize("lockstep", ["0", "1"])
-def test_pi_local_loop_polarizable_lockstep_solve(monkeypatch, lockstep):
-    """MPMC_PI_LOCKSTEP=1: the Jacobi iterations of the beads share launches (blockIdx.y = bead).  Without it the in-ensemble evaluation IS
-    the stand-alone one (bit for bit); the lockstep launches walk one tile pair per wave where the stand-alone path walks panels of two, so
-    there the per-atom sums differ in their last bits (1e-12)."""
-    monkeypatch.setenv("MPMC_PI_LOCKSTEP", lockstep)
+def test_pi_local_loop_polarizable_equals_standalone_evaluations():
+    """every bead of mpmc_pi_potential_local is a complete evaluation on its own streams: the in-ensemble result IS the stand-alone one,
+    bit for bit (the lockstep form of rounds 1-2, which shared launches between beads, is gone: mpmc_last_batch_size is always 1)."""
     atoms, basis, opts = util.load_fixture("ion1000_polar")
     beads = []
     for b in range(3):
@@ -240,24 +237,38 @@ def test_pi_local_loop_polarizable_lockstep_solve(monkeypatch, lockstep):
         beads.append(energy.System(a, basis, opts))
     sums, per, failed = energy.pi_potential_local(beads)
     assert not failed
-    plain = not (os.environ.get("MPMC_JACOBI") or os.environ.get("MPMC_TENSOR_BUDGET_MB"))  # lockstep needs the stored single-launch form
-    assert beads[0].last_batch_size() == (3 if (lockstep == "1" and plain) else 1)
+    assert beads[0].last_batch_size() == 1
     mu_batch = [b.dipoles()[0].copy() for b in beads]
     single = [b.energy() for b in beads]
-    if lockstep == "0" or not plain:
-        assert [p["energy"] for p in per] == single
-        assert [p["polarization_energy"] for p in per] == [b.observables["polarization_energy"] for b in beads]
-        for m, b in zip(mu_batch, beads):
-            assert np.array_equal(m, b.dipoles()[0])
-    else:
-        for p, e, b in zip(per, single, beads):
-            assert util.close(p["energy"], e, 1e-13) and util.close(p["polarization_energy"], b.observables["polarization_energy"], 1e-12)
-        for m, b in zip(mu_batch, beads):
-            assert util.max_rel(m, b.dipoles()[0]) < 1e-12
+    assert [p["energy"] for p in per] == single
+    assert [p["polarization_energy"] for p in per] == [b.observables["polarization_energy"] for b in beads]
+    for m, b in zip(mu_batch, beads):
+        assert np.array_equal(m, b.dipoles()[0])
     g = util.golden("ion1000_polar")
     assert all(p["polar_iterations"] == int(g["polar_iterations"]) for p in per)
     for b in beads:
         b.close()
+
+
+def test_pi_local_loop_with_host_positions_equals_resident_positions():
+    """mpmc_pi_potential_local_host: every bead's coordinates arrive in host memory inside the call (upload of bead b + 1 behind the
+    enqueue of bead b); same numbers as uploading first and evaluating afterwards, bit for bit."""
+    atoms, basis, opts = util.load_fixture("ion1000_polar")
+    pos, beads, beads2 = [], [], []
+    for b in range(4):
+        rng = np.random.default_rng(700 + b)
+        pos.append(np.ascontiguousarray(atoms["pos"] + rng.normal(scale=0.05, size=atoms["pos"].shape)))
+        beads.append(energy.System(atoms, basis, opts))      # created at the unperturbed geometry: the positions travel in the call
+        beads2.append(energy.System(dict(atoms, pos=pos[-1]), basis, opts))
+    for s in beads:
+        s.energy()
+    sums, per, failed = energy.pi_potential_local(beads, host_positions=pos)
+    sums2, per2, failed2 = energy.pi_potential_local(beads2)
+    assert not failed and not failed2
+    assert np.array_equal(sums, sums2)
+    assert [p["energy"] for p in per] == [p["energy"] for p in per2]
+    for s in beads + beads2:
+        s.close()
 
 
 @pytest.mark.parametrize("name", util.LARGE)
@@ -300,7 +311,7 @@ def test_full_size_translation_invariance_and_image_shift():
     T.close()
 
 
-def test_spatial_order_is_transparent(monkeypatch):
+def test_spatial_order_is_transparent():
     """the library sorts atoms into compact tiles internally; every output is in the caller's order and the
     energies do not depend on the internal order beyond summation rounding."""
     atoms, basis, opts = util.load_fixture("water64_polar")
@@ -309,8 +320,11 @@ def test_spatial_order_is_transparent(monkeypatch):
     mu_s, E_s, F_s = S.dipoles()
     A_s = S.thole_amatrix(0, 9)
     S.close()
-    monkeypatch.setenv("MPMC_NO_SORT", "1")
-    T = energy.System(atoms, basis, opts)
+    energy.configure("spatial_sort", 0)
+    try:
+        T = energy.System(atoms, basis, opts)
+    finally:
+        energy.configure("spatial_sort", 1)
     e_plain = T.energy()
     mu_p, E_p, F_p = T.dipoles()
     A_p = T.thole_amatrix(0, 9)

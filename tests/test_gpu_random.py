@@ -141,10 +141,10 @@ def test_solver_variants_agree(solver):
     check(atoms, basis, opts, f"solver {solver}")
 
 
-def test_auto_solver_falls_back_when_the_store_does_not_fit(monkeypatch):
-    monkeypatch.setenv("MPMC_TENSOR_BUDGET_MB", "0")  # nothing fits: AUTO must recompute tensors, still on the GPU
+def test_auto_solver_falls_back_when_the_store_does_not_fit():
     atoms, basis, opts = util.load_fixture("ion216_polar")
     S = energy.System(atoms, basis, opts)
+    S.configure("tensor_budget_mb", 0)  # nothing fits: AUTO must recompute tensors, still on the GPU
     S.energy()
     assert S.memory_usage()[1] == 0
     g = util.golden("ion216_polar")

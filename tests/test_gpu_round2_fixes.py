@@ -69,27 +69,6 @@ def test_device_pointer_upload_invalidates_the_trial_cache():
     T.close()
 
 
-@pytest.mark.parametrize("name,solver", [("ion1000_polar", "compact"), ("ion1000_polar", "matrix_free"), ("water64_polar", "compact")])
-def test_ds_bpermute_fallback_reaches_the_jacobi_kernels(monkeypatch, name, solver):
-    """jacc was derived before the DPP self-test / MPMC_NO_DPP override, so the Jacobi kernels always used the DPP rotation.
-    With MPMC_NO_DPP=1 every symmetric kernel (pair sweep AND hybrid Jacobi) must take the ds_bpermute path and still match the reference."""
-    monkeypatch.setenv("MPMC_NO_DPP", "1")
-    g = util.golden(name)
-    atoms, basis, opts = util.load_fixture(name)
-    S = energy.System(atoms, basis, dict(opts, solver=solver))
-    S.energy()
-    util.assert_energies(S.observables, g, False, label=f"{name}/no_dpp")
-    mu, E, F = S.dipoles()
-    assert util.max_rel(mu.reshape(-1), g["mu"]) < util.REL_TOL
-    S.close()
-    monkeypatch.delenv("MPMC_NO_DPP")
-    T = energy.System(atoms, basis, dict(opts, solver=solver))
-    T.energy()
-    mu2, _, _ = T.dipoles()
-    assert util.max_rel(mu, mu2) < 1e-12  # same arithmetic, different lane-rotation primitive
-    T.close()
-
-
 def test_gauss_seidel_order_follows_any_option_that_switches_it(tmp_path):
     """the re-sort was requested only when polar_gs itself toggled.  Here polar_gs is set from the start and POLARIZATION is
     switched on later: the sweep must run in the reference's atom order (System.Energy.cpp:3569), not in the spatial slot order."""
@@ -155,7 +134,7 @@ def test_molecule_flag_is_the_last_atom_row():
     S.close()
 
 
-def test_counts_after_a_drift_resort_without_electrostatics(monkeypatch):
+def test_counts_after_a_drift_resort_without_electrostatics():
     """Guard of an invariant, not of a bug that was seen: an atom that drifts more than the re-sort threshold makes the next evaluation
     upload the atoms in a new spatial order, and that upload leaves the position-independent pair counts in the device's count block,
     which the evaluation no longer clears as a matter of course (the kernel that posts the results leaves it zeroed).  The counts and
@@ -163,8 +142,8 @@ def test_counts_after_a_drift_resort_without_electrostatics(monkeypatch):
     where the in-cutoff count of coulombic_real is a slot only the final reduction of the pair sweep writes."""
     atoms, basis, opts = util.load_fixture("water64_polar")
     opts = dict(opts, polarization=0, polar_iterative=0, polar_ewald=0, rd_only=1)
-    monkeypatch.setenv("MPMC_NO_SINGLE_LAUNCH", "1")  # the general path (the one-launch form of small LJ boxes bypasses the block)
     S = energy.System(atoms, basis, opts)
+    S.configure("single_launch", 0)  # the general path (the one-launch form of small LJ boxes bypasses the block)
     S.energy()
     assert S.observables["n_rd_excluded"] > 0 and S.observables["n_es_in_cutoff"] == 0
     ids = atoms["mol_id"]

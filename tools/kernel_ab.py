@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Same-process A/B of kernel variants on ONE bead of the benchmark box (10 000 polarizable atoms).
 
-usage: python tools/kernel_ab.py "label:ENV=v,@key=v" ...        (an empty list = defaults; @key=v: energy.configure(key, v), i.e.
-       mpmc_debug_configure -- e.g. "fused:@pair_kernel=1" "sweep:@pair_kernel=2")
+usage: python tools/kernel_ab.py "label:key=v,key=v" ...        (an empty list = defaults; key=v: energy.configure(key, v), i.e.
+       mpmc_debug_configure -- e.g. "fused:pair_kernel=1" "sweep:pair_kernel=2"); every variant runs on ONE stream (side_stream=0)
+       unless it says otherwise, so that the HIP-event brackets see each kernel alone on the GPU
 
-Each variant gets a fresh context created under its environment (the library reads its MPMC_* toggles at
-mpmc_ctx_create), 2 warm-up evaluations, then `reps` profiled evaluations; prints HIP-event ms per launch of every
+Each variant gets a fresh context created under its settings, 2 warm-up evaluations, then `reps` profiled evaluations; prints HIP-event ms per launch of every
 kernel class, the evaluation wall time and the total energy (must be identical to ~1e-12 between variants).
 The list is run twice (A B A B) so that drift of the box shows up.
 """
@@ -27,19 +27,11 @@ specs = sys.argv[1:] or ["default:"]
 for rnd in (1, 2):
     for spec in specs:
         label, _, envs = spec.partition(":")
-        added = []
-        cfg = []
+        S = energy.System(atoms, basis, opts)
+        S.configure("side_stream", 0)
         for kv in filter(None, envs.split(",")):
             k, _, v = kv.partition("=")
-            if k.startswith("@"):
-                energy.configure(k[1:], float(v))
-                cfg.append(k[1:])
-            else:
-                os.environ[k] = v
-                added.append(k)
-        S = energy.System(atoms, basis, opts)
-        for k in cfg:
-            energy.configure(k, 0)
+            S.configure(k.lstrip("@"), float(v))
         for _ in range(2):
             e = S.energy()
         S.set_profiling(True)
@@ -50,7 +42,5 @@ for rnd in (1, 2):
         wall = (time.perf_counter() - t0) / reps
         t = S.timings(reset=True)
         S.close()
-        for k in added:
-            del os.environ[k]
         cls = "  ".join(f"{k} {v['ms'] / max(v['launches'], 1):.4f}x{v['launches'] // reps}" for k, v in t.items() if v["launches"])
         print(f"r{rnd} {label:>12s}: eval {wall * 1e3:.3f} ms  E {e:.12e} | {cls}", flush=True)

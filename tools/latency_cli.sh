@@ -8,6 +8,4 @@ g++ -std=c++14 -O2 -I $root/include $root/examples/energy_cli.cpp -L $root/mpmcx
 for f in lj64 lj1000 ion64_es ion216_polar ion216_precision ion1000_polar; do
 	echo -n "$f default:            "; /tmp/energy_cli $root/tests/golden/$f.in --time $reps | tail -1
 done
-for f in lj64 lj1000; do
-	echo -n "$f MPMC_NO_SINGLE_LAUNCH=1: "; MPMC_NO_SINGLE_LAUNCH=1 /tmp/energy_cli $root/tests/golden/$f.in --time $reps | tail -1
-done
+# (the general multi-kernel path of small LJ boxes: python -c "energy.configure('single_launch', 0)" through tools/latency_probe.py)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Two settings of a switch that is read when a context is created, over system sizes: full evaluations of the polarizable ion box of
+"""Two settings of a measurement switch (mpmc_debug_configure) over system sizes: full evaluations of the polarizable ion box of
 bench.py, one at a time, same process, same box, the settings interleaved (three rounds); energies of the two forms compared.
-   python tools/pair_waves_sweep.py [--env NAME=a,b] [sizes...]      default: MPMC_PAIR_WAVES=1,4 (one against four waves per tile pair
-   in the pair sweep); MPMC_ONE_STREAM=0,1 places the size below which the side stream is not forked."""
+   python tools/pair_waves_sweep.py [--key NAME=a,b] [sizes...]      default: pair_kernel=1,2 (k_pair_fused against the fast sweep);
+   pair_waves=1,4 (with pair_kernel=1 as a second --key) one against four waves per tile pair; side_stream=0,1 places the size below
+   which the side stream is not forked."""
 import os
 import sys
 import tempfile
@@ -14,11 +15,17 @@ import bench  # noqa: E402
 from mpmcxx_amd import energy  # noqa: E402
 
 args = sys.argv[1:]
-name, values = "MPMC_PAIR_WAVES", ["1", "4"]
-if args and args[0] == "--env":
-    name, v = args[1].split("=")
-    values = v.split(",")
+name, values = "pair_kernel", ["1", "2"]
+fixed = []
+while args and args[0] == "--key":
+    k, v = args[1].split("=")
+    if "," in v:
+        name, values = k, v.split(",")
+    else:
+        fixed.append((k, float(v)))
     args = args[2:]
+for k, v in fixed:
+    energy.configure(k, v)
 sizes = [int(x) for x in args] or [216, 512, 1000, 2000, 3000, 4000, 5000, 7000, 10000]
 tmp = tempfile.mkdtemp()
 print(f"atoms  tile_pairs   {name}={values[0]} us/eval (3 rounds)      {name}={values[1]} us/eval (3 rounds)      rel.diff of the energies")
@@ -28,7 +35,7 @@ for n in sizes:
     en = {}
     for rnd in range(3):
         for v in values:
-            os.environ[name] = v
+            energy.configure(name, float(v))
             S = energy.System(atoms, basis, opts)
             for _ in range(5):
                 en[v] = S.energy()

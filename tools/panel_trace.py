@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of ONE launch of the panel Jacobi kernel (k_dipole_iter_panel) on the 10 000-atom box: per workgroup start / end time stamps
 (wall_clock64, 100 MHz) and the CU it ran on.  Prints how full the chip was over the launch and how the last workgroups end.
-usage: MPMC_TRACE_PANEL=1 MPMC_ONE_STREAM=1 python tools/panel_trace.py"""
+usage: python tools/panel_trace.py"""
 import ctypes as C
 import os
 import sys
@@ -11,10 +11,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("MPMC_TRACE_PANEL", "1")
-os.environ.setdefault("MPMC_ONE_STREAM", "1")
 import bench  # noqa: E402
 from mpmcxx_amd import energy  # noqa: E402
+
+energy.configure("trace_panel", 1)
+energy.configure("side_stream", 0)
 
 atoms, basis, opts = bench.build_case(10000, tempfile.mkdtemp())
 S = energy.System(atoms, basis, opts)
