@@ -7,9 +7,10 @@
 // Here the two boxes are two device contexts; `place_on_devices()` puts box 0 on device 0 and box 1 on device 1 when the node
 // shows two (north_star: "Gibbs dual-box energies shard naturally across the GPUs"), `energy()` enqueues both evaluations before
 // it waits for either.  The acceptance factor is the library's restatement of boltzmann_factor_NVT_Gibbs, pinned by the reference's
-// own function (tests/golden/gibbs_bf.json).  The move generators of Gibbs_mc (make_move_Gibbs, volume_change_Gibbs) are outside the
-// path (MC drivers) and the reference's own loop cannot run in this image, so no trajectory exists to reproduce; what the
-// moves DO to a live context -- set_box, set_atoms with a new N, update_positions, restore -- is exercised by tests/test_gpu_box_moves.py.
+// own function (tests/golden/gibbs_bf.json).  GibbsNVT below restates the loop of Gibbs_mc with its move generators (make_move_Gibbs,
+// volume_change_Gibbs) and reproduces trajectories made by the reference's own functions (oracle/ref_gibbs_traj.cpp ->
+// tests/golden/gibbs_*; tests/test_gibbs_driver.py); what the moves DO to a live context -- set_box, set_atoms with a new N,
+// update_positions, restore -- is also exercised directly by tests/test_gpu_box_moves.py.
 #pragma once
 #include <array>
 #include <cmath>
@@ -179,9 +180,9 @@ public:
 			systems[i]->countN();
 		}
 		if (cfg.volume_probability == 0.0) cfg.volume_probability = 1.0 / (double)(systems[0]->observables->N + systems[1]->observables->N);
+		evaluate_both(initial_energy);
 		for (int i = 0; i < 2; i++) {
 			systems[i]->observables->volume = systems[i]->pbc.volume;
-			initial_energy[i] = evaluate(i);
 			if (!std::isfinite(initial_energy[i])) initial_energy[i] = systems[i]->observables->energy = kGibbsMaxValue; // mc_initial_energy :161-175
 			ckpt_obs[i] = *systems[i]->observables;
 		}
@@ -198,8 +199,7 @@ public:
 		r.movetype[0] = movetype[0];
 		r.movetype[1] = movetype[1];
 		make_move_Gibbs();
-		fin[0] = evaluate(0);
-		fin[1] = evaluate(1);
+		evaluate_both(fin);
 		double bf[2] = {stored_bf[0], stored_bf[1]}, en[2] = {systems[0]->observables->energy, systems[1]->observables->energy};
 		mpmc_gibbs_move m{};
 		for (int i = 0; i < 2; i++) {
@@ -306,13 +306,17 @@ private:
 		c[1] /= mass;
 		c[2] /= mass;
 	}
-	// systems[i]->energy(): the reference's pairs() refreshes every Molecule::com on the way (update_com, src/System.cpp:1347-1378)
-	double evaluate(int i) {
-		energy_calls++;
-		const double e = systems[i]->energy();
-		com[i].resize(n_molecules(i));
-		for (int m = 0; m < n_molecules(i); m++) update_COM(i, m, com[i][m]);
-		return e;
+	// systems[0]->energy(), systems[1]->energy() (Gibbs.cpp:179-180): both boxes -- usually on two devices -- are enqueued before either is
+	// waited for, results taken in box order.  The reference's pairs() refreshes every Molecule::com on the way (update_com, src/System.cpp:1347-1378).
+	void evaluate_both(double e[2]) {
+		energy_calls += 2;
+		systems[0]->energy_async();
+		systems[1]->energy_async();
+		for (int i = 0; i < 2; i++) {
+			e[i] = systems[i]->energy_wait();
+			com[i].resize(n_molecules(i));
+			for (int m = 0; m < n_molecules(i); m++) update_COM(i, m, com[i][m]);
+		}
 	}
 
 	struct Quat { // reference src/Quaternion.cpp
