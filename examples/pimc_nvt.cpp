@@ -70,7 +70,15 @@ int main(int argc, char **argv) {
 			mpmc::write_pqr(base + name, *beads[b]);
 		}
 		const mpmc::observables_t &o = mc.pi.sys_observables;
-		std::printf("{\"P\": %d, \"natoms\": %d, \"steps\": %u, \"AR\": %.5f, \"AR_displace\": %.5f, \"AR_bead\": %.5f, \"energy\": %.17g, \"kinetic\": %.17g, "
+		long long waits[4] = {0, 0, 0, 0}; // how the host waits of all images ended (polls seen / timed out, stream syncs, yields)
+		for (int b = 0; b < P; b++) {
+			long long w[4] = {0, 0, 0, 0};
+			if (mpmc_debug_wait_counters(beads[b]->context(), w) == 0)
+				for (int k = 0; k < 4; k++) waits[k] += w[k];
+		}
+		std::printf("{\"wait_polls_seen\": %lld, \"wait_polls_timed_out\": %lld, \"wait_stream_syncs\": %lld, \"wait_poll_yields\": %lld, ", waits[0], waits[1],
+		            waits[2], waits[3]);
+		std::printf("\"P\": %d, \"natoms\": %d, \"steps\": %u, \"AR\": %.5f, \"AR_displace\": %.5f, \"AR_bead\": %.5f, \"energy\": %.17g, \"kinetic\": %.17g, "
 		            "\"seconds\": %.3f, \"steps_per_s\": %.2f, \"energy_evals_per_s\": %.1f, \"devices\": %d, \"trial_moves\": %d}\n",
 		            P, (int)beads[0]->atoms.size(), mc.step, mc.acceptance_rate(),
 		            (mc.accept_displace + mc.reject_displace) ? (double)mc.accept_displace / (double)(mc.accept_displace + mc.reject_displace) : 0.0,

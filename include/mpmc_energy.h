@@ -319,6 +319,16 @@ int mpmc_memory_usage(mpmc_ctx *ctx, int64_t *total_bytes, int64_t *tensor_store
  * streamed (64 KiB each), pairs beyond the damping range (bare dipole tensor recomputed), pairs wholly beyond the cutoff } */
 int mpmc_get_tile_stats(mpmc_ctx *ctx, int64_t out4[4]);
 
+/* ---- diagnostics (no effect on results) -------------------------------------------------------------------
+ * How this context's host-side waits ended since it was created: out4 = { polls of the pinned result block that saw the device's post,
+ * polls that ran out of their budget (the wait then synchronised the stream), stream synchronisations, yields taken inside long polls }.
+ * Short evaluations and trial moves are polled for (a few microseconds earlier than the driver's completion path); a host with fewer
+ * free cores than polling threads shows up here as timeouts and yields. */
+int mpmc_debug_wait_counters(mpmc_ctx *ctx, long long out4[4]);
+/* Measurement / A-B switch, key = value (keys: csrc/context.cpp, struct mpmc_tuning).  ctx == NULL: the default of contexts created
+ * afterwards in this process.  The library reads no environment variable for any of these. */
+int mpmc_debug_configure(mpmc_ctx *ctx, const char *key, double value);
+
 #ifdef __cplusplus
 }
 #endif

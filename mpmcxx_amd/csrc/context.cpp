@@ -549,6 +549,7 @@ static int grow_capacity(mpmc_ctx *c, int n) {
 	f->prof = c->prof;
 	f->tim = c->tim;
 	f->tune = c->tune;
+	f->n_poll_hits = c->n_poll_hits, f->n_poll_timeouts = c->n_poll_timeouts, f->n_stream_syncs = c->n_stream_syncs, f->n_poll_yields = c->n_poll_yields;
 	f->n_uploads_carried = c->n_uploads_carried; // (diagnostics survive the growth; the order itself does not: the new context sorts)
 	f->n_uploads_sorted = c->n_uploads_sorted;
 	std::swap(*c, *f);
@@ -870,6 +871,17 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 }
 // which kernel ran the pair pass of the last evaluation: 1 the fast sweep, 0 k_pair_fused
 extern "C" int mpmc_debug_last_pair_kernel(mpmc_ctx *c) { return c ? (c->last_pair_was_sweep ? 1 : 0) : -1; }
+
+// how this context's host waits ended since it was created: out[4] = polls that saw the device's post, polls that ran out of their
+// budget (the wait then synchronised the stream), stream synchronisations, yields taken inside long polls (poll_posted, context.h)
+extern "C" int mpmc_debug_wait_counters(mpmc_ctx *c, long long *out4) {
+	if (!c || !out4) return -1;
+	out4[0] = c->n_poll_hits;
+	out4[1] = c->n_poll_timeouts;
+	out4[2] = c->n_stream_syncs;
+	out4[3] = c->n_poll_yields;
+	return 0;
+}
 
 // diagnostics only (tests assert that the order was really carried): uploads of the atom list that kept the order / that sorted
 extern "C" int mpmc_debug_upload_counts(mpmc_ctx *c, long long *out2) {

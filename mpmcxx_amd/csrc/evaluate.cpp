@@ -1,8 +1,5 @@
 // evaluate.cpp -- one energy evaluation: k tables, work buffers, the enqueue of every kernel of double System::energy(), result assembly, component entry points
 // (part of libmpmc_energy.so; shared state and helpers: context.h.  There is no CPU fallback anywhere in this library.)
-#include <atomic>
-#include <chrono>
-
 #include "context.h"
 
 
@@ -504,19 +501,11 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 					// spin on the pinned flag until iteration `it` is closed (or an earlier one converged); a stream synchronisation costs
 					// ~15 us, this ~2.  Past a generous budget fall back to the blocking read (correct either way).
 					volatile const int *hf = host_flag;
-					const auto t0 = std::chrono::steady_clock::now();
-					bool seen = false;
-					for (int spins = 0;; ++spins) {
-						if (hf[0] >= it || hf[1] != 0) {
-							std::atomic_thread_fence(std::memory_order_acquire);
-							seen = true;
-							break;
-						}
-						if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
-					}
+					const bool seen = poll_posted(c, [&] { return hf[0] >= it || hf[1] != 0; }, std::chrono::microseconds(50000));
 					if (seen) {
 						done_at = hf[1];
 					} else {
+						c->n_stream_syncs++;
 						HIP_TRY(c, hipMemcpyAsync(c->h_flag, ctl + 1, sizeof(int), hipMemcpyDeviceToHost, st));
 						HIP_TRY(c, hipStreamSynchronize(st));
 						done_at = *c->h_flag;
@@ -636,18 +625,13 @@ int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 		// the kernel posts its launch number behind the results (system-scope release): a short spin on the pinned slot returns a few
 		// microseconds before the driver's own completion path would; past the budget, or if anything is off, fall back to the sync
 		volatile const double *flag = c->h_scal + S_COUNT + C_COUNT;
-		const auto budget = std::chrono::microseconds(c->last_was_single ? 200 : 1000);
-		const auto t0 = std::chrono::steady_clock::now();
-		for (int spins = 0;; ++spins) {
-			if (*flag == c->single_seq) {
-				std::atomic_thread_fence(std::memory_order_acquire);
-				seen = true;
-				break;
-			}
-			if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) break;
-		}
+		const double want = c->single_seq;
+		seen = poll_posted(c, [&] { return *flag == want; }, std::chrono::microseconds(c->last_was_single ? 200 : 1000));
 	}
-	if (!seen) HIP_TRY(c, hipStreamSynchronize(c->sync_stream ? c->sync_stream : c->stream));
+	if (!seen) {
+		c->n_stream_syncs++;
+		HIP_TRY(c, hipStreamSynchronize(c->sync_stream ? c->sync_stream : c->stream));
+	}
 	c->sync_stream = nullptr;
 	c->pending = false;
 	prof_harvest(c);

@@ -205,17 +205,13 @@ extern "C" int mpmc_trial_energy_wait(mpmc_ctx *c, mpmc_result *out) {
 		bool seen = false;
 		if (c->ev_used.empty()) {
 			volatile const double *flag = c->h_delta_out + 8;
-			const auto t0 = std::chrono::steady_clock::now();
-			for (int spins = 0;; ++spins) {
-				if (*flag == c->trial_seq) {
-					std::atomic_thread_fence(std::memory_order_acquire);
-					seen = true;
-					break;
-				}
-				if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) break;
-			}
+			const double want = c->trial_seq;
+			seen = poll_posted(c, [&] { return *flag == want; }, std::chrono::microseconds(1000));
 		}
-		if (!seen) HIP_TRY(c, hipStreamSynchronize(c->stream));
+		if (!seen) {
+			c->n_stream_syncs++;
+			HIP_TRY(c, hipStreamSynchronize(c->stream));
+		}
 		prof_harvest(c);
 	}
 	const int do_es = c->opts.rd_only ? 0 : 1;

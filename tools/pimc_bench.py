@@ -69,5 +69,7 @@ for a, b in zip(res["full"]["rows"], res["trial"]["rows"]):
 for mode in ("full", "trial"):
     r = res[mode]
     print(f"{mode:5s}: {natoms} atoms x {P} images, {r['steps']} steps in {r['seconds']:.2f} s = {r['steps_per_s']:.1f} MC steps/s "
-          f"({r['energy_evals_per_s']:.0f} image evaluations/s), AR {r['AR']:.3f}")
+          f"({r['energy_evals_per_s']:.0f} image evaluations/s), AR {r['AR']:.3f}; host waits: {r.get('wait_polls_seen')} polls seen, "
+          f"{r.get('wait_polls_timed_out')} timed out, {r.get('wait_stream_syncs')} stream syncs, {r.get('wait_poll_yields')} yields; "
+          f"{len(os.sched_getaffinity(0))} cores available, OpenMP {'on' if OMP else 'off'}")
 print(f"largest relative difference between the two energy.dat files: {worst:.2e}; speed-up {res['trial']['steps_per_s'] / res['full']['steps_per_s']:.1f}x")
