@@ -265,8 +265,13 @@ def test_pi_local_loop_with_host_positions_equals_resident_positions():
     sums, per, failed = energy.pi_potential_local(beads, host_positions=pos)
     sums2, per2, failed2 = energy.pi_potential_local(beads2)
     assert not failed and not failed2
-    assert np.array_equal(sums, sums2)
-    assert [p["energy"] for p in per] == [p["energy"] for p in per2]
+    assert np.allclose(sums, sums2, rtol=1e-12, atol=0.0)
+    for p, q in zip(per, per2):
+        assert util.close(p["energy"], q["energy"], 1e-12) and p["n_lj_in_cutoff"] == q["n_lj_in_cutoff"]
+    for s, hp in zip(beads, pos):  # the two-call form on the same contexts: identical arithmetic
+        s.update_positions(0, hp)
+    sums3, per3, _ = energy.pi_potential_local(beads)
+    assert np.array_equal(sums, sums3) and [p["energy"] for p in per] == [p["energy"] for p in per3]
     for s in beads + beads2:
         s.close()
 
