@@ -869,6 +869,8 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 	} else return MPMC_ERR_ARG;
 	return MPMC_OK;
 }
+// the last evaluated trial move: 1 = a full evaluation of the trial configuration, 0 = per-move delta energies, -1 = none
+extern "C" int mpmc_debug_last_trial_was_full(mpmc_ctx *c) { return (c && c->trial_last_kind >= 0) ? c->trial_last_kind : -1; }
 // which kernel ran the pair pass of the last evaluation: 1 the fast sweep, 0 k_pair_fused
 extern "C" int mpmc_debug_last_pair_kernel(mpmc_ctx *c) { return c ? (c->last_pair_was_sweep ? 1 : 0) : -1; }
 

@@ -200,6 +200,7 @@ struct mpmc_ctx {
 	bool cache_valid = false;   // last_full = totals of the accepted configuration, d_sf = its structure factors
 	mpmc_result last_full{};
 	mpmc_result trial_res{};
+	int trial_last_kind = -1; // (diagnostics) the last enqueued trial: 1 full evaluation, 0 delta energies
 	bool trial_open = false, trial_evaluated = false, trial_was_full = false, trial_enqueued = false, trial_noop = false;
 	mpmc_result trial_keep{}; // accepted totals while a full-evaluation trial is in flight
 	int trial_first = 0, trial_count = 0;
@@ -385,6 +386,7 @@ int prepare(mpmc_ctx *c, bool defer_static = false); // uploads what is dirty, (
 int enqueue(mpmc_ctx *c, unsigned mask);         // one evaluation (the pieces in `mask`) on the context's streams (evaluate.cpp)
 int wait_and_fill(mpmc_ctx *c, mpmc_result *out); // waits for it and assembles the result (evaluate.cpp)
 unsigned full_mask(const mpmc_ctx *c);           // what double System::energy() runs under the current options
+void ext_params(const mpmc_ctx *c, FusedParams &fp, bool wolf_on); // Wolf / Feynman-Hibbs fields of the pair parameters (evaluate.cpp)
 AtomsDev atoms_view(const mpmc_ctx *c);
 RecipDev recip_view(const mpmc_ctx *c);
 int upload_atoms(mpmc_ctx *c);                   // spatial order + device atom arrays (context.cpp)

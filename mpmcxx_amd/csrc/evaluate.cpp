@@ -217,6 +217,21 @@ RecipDev mpmc::recip_view(const mpmc_ctx *c) {
 	return r;
 }
 
+// the Wolf / Feynman-Hibbs fields of the pair parameters (pair sweep and per-move delta kernels)
+void mpmc::ext_params(const mpmc_ctx *c, FusedParams &fp, bool wolf_on) {
+	const mpmc_options &o = c->opts;
+	fp.wolf = wolf_on ? 1 : 0;
+	fp.fh_order = o.feynman_hibbs ? ((o.feynman_hibbs_order == 4) ? 4 : 2) : 0;
+	fp.fh_c2 = fp.fh_c4 = 0.0;
+	if (fp.fh_order) { // reference constants.h:15-33: M2A2 hBar2 / (24 kB T) and M2A4 hBar4 / (1152 kB2 T^2), reduced mass in kg
+		const double hBar2 = 1.11211999e-68, hBar4 = 1.23681087e-136, kB = 1.3806503e-23, kB2 = 1.90619525e-46, amu = 1.66053873e-27;
+		fp.fh_c2 = 1.0e20 * (hBar2 / (24.0 * kB * o.temperature)) / amu;
+		fp.fh_c4 = 1.0e40 * (hBar4 / (1152.0 * kB2 * o.temperature * o.temperature)) / (amu * amu);
+	}
+	fp.wolf_erfa_over_r = std::erf(c->ewald_alpha * c->box.cutoff) / c->box.cutoff;
+	fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
+}
+
 // which pieces of energy() to run
 
 int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
@@ -319,16 +334,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		fp.do_es = ((mask & RUN_PAIR_ES) || (mask & RUN_FIELD)) ? 1 : 0;
 		fp.do_field = (mask & RUN_FIELD) ? (o.polar_ewald ? 1 : 2) : 0;
 		fp.do_thole = compact ? 1 : 0;
-		fp.wolf = (o.wolf && (mask & RUN_WOLF)) ? 1 : 0;
-		fp.fh_order = o.feynman_hibbs ? ((o.feynman_hibbs_order == 4) ? 4 : 2) : 0;
-		fp.fh_c2 = fp.fh_c4 = 0.0;
-		if (fp.fh_order) { // reference constants.h:15-33: M2A2 hBar2 / (24 kB T) and M2A4 hBar4 / (1152 kB2 T^2), reduced mass in kg
-			const double hBar2 = 1.11211999e-68, hBar4 = 1.23681087e-136, kB = 1.3806503e-23, kB2 = 1.90619525e-46, amu = 1.66053873e-27;
-			fp.fh_c2 = 1.0e20 * (hBar2 / (24.0 * kB * o.temperature)) / amu;
-			fp.fh_c4 = 1.0e40 * (hBar4 / (1152.0 * kB2 * o.temperature * o.temperature)) / (amu * amu);
-		}
-		fp.wolf_erfa_over_r = std::erf(c->ewald_alpha * c->box.cutoff) / c->box.cutoff;
-		fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
+		ext_params(c, fp, (o.wolf && (mask & RUN_WOLF)) != 0);
 		fp.thole_far_x = kTholeFarX;
 		fp.pair_waves = c->tune.pair_waves ? c->tune.pair_waves : (c->n_tile_pairs <= kPairSplitMax ? 4 : 1);
 		fp.store_only = ((mask & RUN_STORE) && !(mask & (RUN_PAIR | RUN_FIELD))) ? 1 : 0;

@@ -221,7 +221,8 @@ struct MvInline {
 	int slot[kMvInline], orig[kMvInline];
 };
 void launch_commit_positions_inline(hipStream_t st, double4 *xyzq, const MvInline &inl, int m);
-void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc, double alpha, int do_es,
+void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc,
+                  const FusedParams &fp /*ewald_alpha and the Wolf / Feynman-Hibbs fields*/, int do_es,
                   const int *mv_slot, const int *orig_of_mv, const double4 *mv_new, int m, int *moved_idx, double4 *sf_trial,
                   double *block_part, int *block_cnt, double *out4, long long *dcnt2,
                   double *host_out /*pinned [9]: the result and, last, the launch number `seq`*/, double seq,

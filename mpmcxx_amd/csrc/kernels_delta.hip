@@ -12,10 +12,12 @@
 
 namespace mpmc {
 
-// u(i,j) of lj() and coulombic_real() (erfc part) for one geometry; adds to e_lj/e_re and the in-cutoff counts with sign sg
-template <bool ORTHO>
-__device__ __forceinline__ void pair_terms(const Box &bx, double alpha, int do_es, const double4 &pi, const double4 &pj, double sig, double eps,
-                                           const PairFlags &f, double sg, double &e_lj, double &e_re, int &n_lj, int &n_es) {
+// u(i,j) of lj() and coulombic_real() (erfc part) for one geometry; adds to e_lj/e_re and the in-cutoff counts with sign sg.
+// EXT: the adjacent physics of the pair sweep's extended variant -- coulombic_wolf (:1420-1462) instead of the erfc term, Feynman-Hibbs
+// corrections of both terms (:1100-1148, :1521-1557) -- with the same per-pair arithmetic (pair_math.h); imu = 1/M_i + 1/M_j.
+template <bool ORTHO, bool EXT>
+__device__ __forceinline__ void pair_terms(const Box &bx, const FusedParams &fp, int do_es, const double4 &pi, const double4 &pj, double sig,
+                                           double eps, const PairFlags &f, double imu, double sg, double &e_lj, double &e_re, int &n_lj, int &n_es) {
 	double ox, oy, oz;
 	const double ri2 = min_image_sq<ORTHO>(bx, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, ox, oy, oz);
 	const double ir = fast_rsqrt(ri2);
@@ -26,12 +28,23 @@ __device__ __forceinline__ void pair_terms(const Box &bx, double alpha, int do_e
 		const double t12 = f.attractive_only ? 0.0 : s6 * s6;
 		e_lj = fma(sg * 4.0 * eps, t12 - s6, e_lj);
 		n_lj += (sg > 0) ? 1 : -1;
+		if (EXT && fp.fh_order) e_lj = fma(sg, fh_lj_corr(fp.fh_order, fp.fh_c2, fp.fh_c4, imu, eps, t12, s6, ir), e_lj);
 	}
-	if (do_es && (ri2 <= bx.t_es) && !f.es_excluded) {
+	if (!do_es || f.es_excluded) return;
+	if (EXT && fp.wolf) {
+		if (ri2 <= bx.t_wolf) { // r < R
+			e_re = fma(sg * (pi.w * pj.w), ir - fp.wolf_erfa_over_r - fp.wolf_inv_r2 * (bx.cutoff - ri2 * ir), e_re);
+			n_es += (sg > 0) ? 1 : -1;
+		}
+		return;
+	}
+	if (ri2 <= bx.t_es) {
 		double g;
-		const double ec = erfc_and_gauss(alpha * (ri2 * ir), g);
+		const double r = ri2 * ir;
+		const double ec = erfc_and_gauss(fp.ewald_alpha * r, g);
 		e_re = fma(sg * (pi.w * pj.w) * ec, ir, e_re);
 		n_es += (sg > 0) ? 1 : -1;
+		if (EXT && fp.fh_order) e_re = fma(sg, fh_es_corr(fp.fh_order, fp.fh_c2, fp.fh_c4, imu, fp.ewald_alpha, ec, g, ri2, r, ir), e_re);
 	}
 }
 
@@ -69,8 +82,8 @@ struct MvArg { // every element is read with a STATIC index (scalar loads from t
 
 // thread = atom slot j of tile `tile`; loops over the m moved atoms.
 // mv.slot(k): slot of moved atom k; mv.nw(k): its trial position (+ charge); moved_idx[slot]: k or -1.
-template <bool ORTHO, class MV>
-__device__ __forceinline__ void delta_pairs_tile(const AtomsDev &at, const Box &bx, double alpha, int do_es, const MV &mv, int m,
+template <bool ORTHO, bool EXT, class MV>
+__device__ __forceinline__ void delta_pairs_tile(const AtomsDev &at, const Box &bx, const FusedParams &fp, int do_es, const MV &mv, int m,
                                                  const int *__restrict__ moved_idx, double *__restrict__ block_part, int *__restrict__ block_cnt,
                                                  int tile) {
 	const int j = tile * kTile + threadIdx.x;
@@ -85,6 +98,8 @@ __device__ __forceinline__ void delta_pairs_tile(const AtomsDev &at, const Box &
 	const double4 pj_new = (kj >= 0) ? mv.nw(kj) : pj_old;
 	double e_lj = 0, e_re = 0;
 	int n_lj = 0, n_es = 0;
+	double imm_j = 0.0;
+	if (EXT && fp.fh_order) imm_j = at.inv_molmass[j];
 	if (!(mj.y & AF_PAD)) {
 		for (int k = 0; k < m; ++k) {
 			if (kj >= 0 && kj <= k) continue; // moved-moved pairs once (k < kj), never the atom with itself
@@ -95,8 +110,10 @@ __device__ __forceinline__ void delta_pairs_tile(const AtomsDev &at, const Box &
 			const double2 li = at.lj[si];
 			double sig, eps;
 			lj_mix(mi.y, mj.y, li.x, li.y, lj.x, lj.y, sig, eps);
-			pair_terms<ORTHO>(bx, alpha, do_es, mv.nw(k), pj_new, sig, eps, f, 1.0, e_lj, e_re, n_lj, n_es);
-			pair_terms<ORTHO>(bx, alpha, do_es, at.xyzq[si], pj_old, sig, eps, f, -1.0, e_lj, e_re, n_lj, n_es);
+			double imu = 0.0;
+			if (EXT && fp.fh_order) imu = at.inv_molmass[si] + imm_j;
+			pair_terms<ORTHO, EXT>(bx, fp, do_es, mv.nw(k), pj_new, sig, eps, f, imu, 1.0, e_lj, e_re, n_lj, n_es);
+			pair_terms<ORTHO, EXT>(bx, fp, do_es, at.xyzq[si], pj_old, sig, eps, f, imu, -1.0, e_lj, e_re, n_lj, n_es);
 		}
 	}
 	e_lj = wave_sum(e_lj);
@@ -185,15 +202,16 @@ __device__ __forceinline__ void delta_recip_k(const AtomsDev &at, const RecipDev
 }
 
 // ONE launch for the three parts of a trial that do not depend on one another (they were three): blocks [0, nt) the pair terms of one
-// tile each, block nt the intramolecular term, blocks (nt, nt + 1 + K) one k-vector each.  Without electrostatics the grid is nt.
-template <bool ORTHO, class MV>
-__global__ __launch_bounds__(64) void k_delta_all(AtomsDev at, Box bx, RecipDev rc, const int *__restrict__ slot_of, double alpha, int do_es, MV mv, int m,
+// tile each, block nt the intramolecular term, blocks (nt, nt + 1 + K) one k-vector each.  Without Ewald electrostatics (none at all, or
+// Wolf: no intramolecular and no reciprocal term, coulombic() :1404-1413) the grid is nt.
+template <bool ORTHO, bool EXT, class MV>
+__global__ __launch_bounds__(64) void k_delta_all(AtomsDev at, Box bx, RecipDev rc, const int *__restrict__ slot_of, FusedParams fp, int do_es, MV mv, int m,
                                                   const int *__restrict__ moved_idx, double4 *__restrict__ sf_trial, double *__restrict__ block_part,
                                                   int *__restrict__ block_cnt, double *__restrict__ out_intra) {
 	const int nt = at.n_pad / kTile;
 	const int b = blockIdx.x; // (block-uniform roles)
-	if (b < nt) delta_pairs_tile<ORTHO>(at, bx, alpha, do_es, mv, m, moved_idx, block_part, block_cnt, b);
-	else if (b == nt) delta_intra_block(at, slot_of, alpha, mv, m, moved_idx, out_intra);
+	if (b < nt) delta_pairs_tile<ORTHO, EXT>(at, bx, fp, do_es, mv, m, moved_idx, block_part, block_cnt, b);
+	else if (b == nt) delta_intra_block(at, slot_of, fp.ewald_alpha, mv, m, moved_idx, out_intra);
 	else delta_recip_k(at, rc, mv, m, sf_trial, b - nt - 1);
 }
 
@@ -396,34 +414,39 @@ __global__ void k_commit_positions(double4 *__restrict__ xyzq, const int *__rest
 	const int k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k < m) xyzq[mv_slot[k]] = mv_new[k];
 }
-void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc, double alpha, int do_es,
+void launch_delta(hipStream_t st, const AtomsDev &at, const int *slot_of, const Box &bx, const RecipDev &rc, const FusedParams &fp, int do_es,
                   const int *mv_slot, const int *orig_of_mv, const double4 *mv_new, int m, int *moved_idx, double4 *sf_trial,
                   double *block_part, int *block_cnt, double *out4, long long *dcnt2, double *host_out, double seq, const MvInline *inl) {
 	const int nt = at.n_pad / kTile;
-	const int grid = do_es ? nt + 1 + rc.K : nt;
+	const bool ext = (do_es && fp.wolf) || fp.fh_order;
+	const int do_ewald = (do_es && !fp.wolf) ? 1 : 0; // intramolecular + reciprocal parts exist
+	const int grid = do_ewald ? nt + 1 + rc.K : nt;
+#define MPMC_DELTA(O, E, MVT, MVV, MAP)                                                                                                              \
+	hipLaunchKernelGGL((k_delta_all<O, E, MVT>), dim3(grid), dim3(kTile), 0, st, at, bx, rc, slot_of, fp, do_es, MVV, m, MAP, sf_trial, block_part, block_cnt, \
+	                   out4 + 2)
+#define MPMC_DELTA_OE(MVT, MVV, MAP)              \
+	if (bx.ortho) {                               \
+		if (ext) MPMC_DELTA(true, true, MVT, MVV, MAP);   \
+		else MPMC_DELTA(true, false, MVT, MVV, MAP);      \
+	} else {                                      \
+		if (ext) MPMC_DELTA(false, true, MVT, MVV, MAP);  \
+		else MPMC_DELTA(false, false, MVT, MVV, MAP);     \
+	}
 	if (inl) { // the move travels in the kernel arguments (m <= kMvInline: the lists are scanned in the kernels, no map)
 		MvArg mv;
 		mv.d = *inl;
-		if (bx.ortho)
-			hipLaunchKernelGGL((k_delta_all<true, MvArg>), dim3(grid), dim3(kTile), 0, st, at, bx, rc, slot_of, alpha, do_es, mv, m, nullptr, sf_trial,
-			                   block_part, block_cnt, out4 + 2);
-		else
-			hipLaunchKernelGGL((k_delta_all<false, MvArg>), dim3(grid), dim3(kTile), 0, st, at, bx, rc, slot_of, alpha, do_es, mv, m, nullptr, sf_trial,
-			                   block_part, block_cnt, out4 + 2);
-		hipLaunchKernelGGL(k_delta_finish, dim3(1), dim3(256), 0, st, block_part, block_cnt, nt, rc, sf_trial, bx, do_es, out4, dcnt2, host_out, seq);
+		MPMC_DELTA_OE(MvArg, mv, nullptr)
+		hipLaunchKernelGGL(k_delta_finish, dim3(1), dim3(256), 0, st, block_part, block_cnt, nt, rc, sf_trial, bx, do_ewald, out4, dcnt2, host_out, seq);
 		return;
 	}
 	const bool use_map = (m > 8); // short lists are scanned in the kernels; long ones go through the slot -> list-index map
 	if (use_map) hipLaunchKernelGGL(k_mark_moved, dim3((m + 63) / 64), dim3(64), 0, st, moved_idx, mv_slot, m, 1);
 	else moved_idx = nullptr;
 	const MvDev mv{mv_slot, orig_of_mv, mv_new};
-	if (bx.ortho)
-		hipLaunchKernelGGL((k_delta_all<true, MvDev>), dim3(grid), dim3(kTile), 0, st, at, bx, rc, slot_of, alpha, do_es, mv, m, moved_idx, sf_trial,
-		                   block_part, block_cnt, out4 + 2);
-	else
-		hipLaunchKernelGGL((k_delta_all<false, MvDev>), dim3(grid), dim3(kTile), 0, st, at, bx, rc, slot_of, alpha, do_es, mv, m, moved_idx, sf_trial,
-		                   block_part, block_cnt, out4 + 2);
-	hipLaunchKernelGGL(k_delta_finish, dim3(1), dim3(256), 0, st, block_part, block_cnt, nt, rc, sf_trial, bx, do_es, out4, dcnt2, host_out, seq);
+	MPMC_DELTA_OE(MvDev, mv, moved_idx)
+#undef MPMC_DELTA_OE
+#undef MPMC_DELTA
+	hipLaunchKernelGGL(k_delta_finish, dim3(1), dim3(256), 0, st, block_part, block_cnt, nt, rc, sf_trial, bx, do_ewald, out4, dcnt2, host_out, seq);
 	if (use_map) hipLaunchKernelGGL(k_mark_moved, dim3((m + 63) / 64), dim3(64), 0, st, moved_idx, mv_slot, m, 0);
 }
 // accept, the move in the kernel arguments

@@ -208,20 +208,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, 
 					const double t12 = f.attractive_only ? 0.0 : s6 * s6;
 					e_lj = fma(4.0 * eps, t12 - s6, e_lj);
 					n_lj++;
-					if (EXT && fp.fh_order) { // lj_fh_corr :1100-1148
-						const double imu = imm_i + s_imm[jl];
-						const double ir2 = ir * ir;
-						const double dE = -24.0 * eps * (2.0 * t12 - s6) * ir;
-						const double d2E = 24.0 * eps * (26.0 * t12 - 7.0 * s6) * ir2;
-						double corr = fp.fh_c2 * imu * (d2E + 2.0 * dE * ir);
-						if (fp.fh_order >= 4) {
-							const double ir3 = ir2 * ir;
-							const double d3E = -1344.0 * eps * (6.0 * t12 - s6) * ir3;
-							const double d4E = 12096.0 * eps * (10.0 * t12 - s6) * (ir2 * ir2);
-							corr += fp.fh_c4 * (imu * imu) * (15.0 * dE * ir3 + 4.0 * d3E * ir + d4E);
-						}
-						e_lj += corr;
-					}
+					if (EXT && fp.fh_order) // lj_fh_corr :1100-1148
+						e_lj += fh_lj_corr(fp.fh_order, fp.fh_c2, fp.fh_c4, imm_i + s_imm[jl], eps, t12, s6, ir);
 				}
 				if (ES) {
 					const double qq = pi.w * qj;
@@ -237,21 +225,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_pair_fused(AtomsDev at, Box bx, 
 					if (es_pair) {
 						e_re = fma(qq * erfc_a, ir, e_re);
 						n_es++;
-						if (EXT && fp.fh_order) { // coulombic_real_FH :1521-1557 (added WITHOUT the charge product, as the reference does :1499-1500)
-							const double al = fp.ewald_alpha, a2 = al * al, a3 = a2 * al;
-							const double imu = imm_i + s_imm[jl];
-							const double ir2 = ir * ir, ir3 = ir2 * ir, ir4 = ir2 * ir2;
-							const double isp = kOneOverSqrtPi;
-							const double du = -2.0 * al * gauss_a * ir * isp - erfc_a * ir2;
-							const double d2u = 4.0 * isp * gauss_a * (a3 + ir2) + 2.0 * erfc_a * ir3;
-							double corr = fp.fh_c2 * imu * (d2u + 2.0 * du * ir);
-							if (fp.fh_order >= 4) {
-								const double d3u = gauss_a * isp * (-8.0 * (a3 * a2) * r - 8.0 * a3 * ir - 12.0 * al * ir3) - 6.0 * erfc_a * ir4;
-								const double d4u = gauss_a * isp * (8.0 * a3 * a2 + 16.0 * a3 * (a3 * al) * ri2 + 32.0 * a3 * ir2 + 48.0 * ir4) + 24.0 * erfc_a * (ir4 * ir);
-								corr += fp.fh_c4 * (imu * imu) * (15.0 * du * ir3 + 4.0 * d3u * ir + d4u);
-							}
-							e_re += corr;
-						}
+						if (EXT && fp.fh_order) // coulombic_real_FH :1521-1557
+							e_re += fh_es_corr(fp.fh_order, fp.fh_c2, fp.fh_c4, imm_i + s_imm[jl], fp.ewald_alpha, erfc_a, gauss_a, ri2, r, ir);
 					} // (the intramolecular charge-to-screen term, :1503-1504, is summed by k_intra_terms)
 					if (FIELD == 1 && fld_pair) { // real_term :2919-2934: erfc form, or erf form (= 1 - erfc) for es_excluded pairs
 						const double ap = fp.polar_ewald_alpha;

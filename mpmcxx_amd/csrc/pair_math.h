@@ -179,6 +179,38 @@ MPMC_HD double lj_term(double sigma_abs, double epsilon, double rimg, bool attra
 	return 4.0 * epsilon * (t12 - s6);
 }
 
+// Feynman-Hibbs corrections (reference System.Energy.cpp: lj_fh_corr :1100-1148, coulombic_real_FH :1521-1557), per pair, shared by the
+// pair sweep and the per-move delta kernels.  c2 = M2A2 hbar^2 / (24 kB T amu2kg), c4 = M2A4 hbar^4 / (1152 kB^2 T^2 amu2kg^2);
+// imu = 1/M_i + 1/M_j (molecule masses, amu): the reduced mass enters as its inverse.
+MPMC_HD double fh_lj_corr(int order, double c2, double c4, double imu, double eps, double t12, double s6, double ir) {
+	const double ir2 = ir * ir;
+	const double dE = -24.0 * eps * (2.0 * t12 - s6) * ir;
+	const double d2E = 24.0 * eps * (26.0 * t12 - 7.0 * s6) * ir2;
+	double corr = c2 * imu * (d2E + 2.0 * dE * ir);
+	if (order >= 4) {
+		const double ir3 = ir2 * ir;
+		const double d3E = -1344.0 * eps * (6.0 * t12 - s6) * ir3;
+		const double d4E = 12096.0 * eps * (10.0 * t12 - s6) * (ir2 * ir2);
+		corr += c4 * (imu * imu) * (15.0 * dE * ir3 + 4.0 * d3E * ir + d4E);
+	}
+	return corr;
+}
+// (added WITHOUT the charge product, as the reference does, :1499-1500); erfc_a = erfc(alpha r), gauss_a = exp(-alpha^2 r^2)
+MPMC_HD double fh_es_corr(int order, double c2, double c4, double imu, double al, double erfc_a, double gauss_a, double ri2, double r, double ir) {
+	const double a2 = al * al, a3 = a2 * al;
+	const double ir2 = ir * ir, ir3 = ir2 * ir, ir4 = ir2 * ir2;
+	const double isp = kOneOverSqrtPi;
+	const double du = -2.0 * al * gauss_a * ir * isp - erfc_a * ir2;
+	const double d2u = 4.0 * isp * gauss_a * (a3 + ir2) + 2.0 * erfc_a * ir3;
+	double corr = c2 * imu * (d2u + 2.0 * du * ir);
+	if (order >= 4) {
+		const double d3u = gauss_a * isp * (-8.0 * (a3 * a2) * r - 8.0 * a3 * ir - 12.0 * al * ir3) - 6.0 * erfc_a * ir4;
+		const double d4u = gauss_a * isp * (8.0 * a3 * a2 + 16.0 * a3 * (a3 * al) * ri2 + 32.0 * a3 * ir2 + 48.0 * ir4) + 24.0 * erfc_a * (ir4 * ir);
+		corr += c4 * (imu * imu) * (15.0 * du * ir3 + 4.0 * d3u * ir + d4u);
+	}
+	return corr;
+}
+
 // Thole exponential damping, reference System.Energy.cpp:2731-2757:  T = a*I - b*(d (x) d),
 //   a = damp1/r^3, b = 3*damp2/r^5.  r == 0 gives the reference's MAXVALUE guard (:2704-2705).
 MPMC_HD void thole_ab(double r, double lambda, double &a, double &b) {

@@ -71,14 +71,17 @@ extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
 	const int m = c->trial_count;
 	c->trial_polar_delta = false;
 	const bool no_polar_delta = c->tune.no_polar_delta;
-	const bool polar_delta = polar && c->e_real_valid && !no_polar_delta && m <= MPMC_TRIAL_MAX_ATOMS && !o.wolf && !o.feynman_hibbs;
-	if ((polar && !polar_delta) || m > MPMC_TRIAL_MAX_ATOMS || o.wolf || o.feynman_hibbs) { // (the delta kernels carry the base LJ + Ewald terms only)
+	// (Wolf electrostatics and the Feynman-Hibbs corrections are per-pair terms like the others: the delta kernels carry them; a
+	// polarizable box under Wolf keeps the full evaluation -- its static field is the Ewald one, outside the reference's own combinations)
+	const bool polar_delta = polar && c->e_real_valid && !no_polar_delta && m <= MPMC_TRIAL_MAX_ATOMS && !o.wolf;
+	if ((polar && !polar_delta) || m > MPMC_TRIAL_MAX_ATOMS) {
 		// the dipole solve couples every atom: evaluate the trial configuration in full (still on the device)
 		c->trial_keep = c->last_full;
 		int rc = mpmc_update_positions(c, c->trial_first, m, c->trial_new.data());
 		if (rc != MPMC_OK) return rc;
 		if ((rc = mpmc_energy_async(c)) != MPMC_OK) return rc;
 		c->trial_was_full = true;
+		c->trial_last_kind = 1;
 		c->trial_enqueued = true;
 		return MPMC_OK;
 	}
@@ -116,13 +119,17 @@ extern "C" int mpmc_trial_energy_async(mpmc_ctx *c) {
 	}
 	const int do_es = o.rd_only ? 0 : 1;
 	{
+		FusedParams fp{};
+		fp.ewald_alpha = c->ewald_alpha;
+		ext_params(c, fp, o.wolf && do_es);
 		ProfScope p(c, MPMC_K_PAIR);
-		launch_delta(st, atoms_view(c), c->d_slot_of, c->box, recip_view(c), c->ewald_alpha, do_es, c->d_mv_slot, c->d_mv_orig, c->d_mv_new, m,
+		launch_delta(st, atoms_view(c), c->d_slot_of, c->box, recip_view(c), fp, do_es, c->d_mv_slot, c->d_mv_orig, c->d_mv_new, m,
 		             c->d_moved_idx, c->d_sf_trial, c->d_block_part, c->d_block_cnt, c->d_delta_out, c->d_delta_cnt, c->h_delta_out,
 		             (c->trial_seq += 1.0), c->trial_inline ? &c->mv_inline : nullptr);
 	}
 	HIP_TRY(c, hipGetLastError()); // (k_delta_finish posts the result into h_delta_out itself)
 	c->trial_was_full = false;
+	c->trial_last_kind = 0;
 	if (polar_delta) {
 		// Polarizable box: the pair energies and structure factors above are O(m N); the static field follows the same way -- real part:
 		// delta of the pairs with a moved atom; reciprocal part: recomputed from the trial structure factors (O(K N), 30 us at 10 000

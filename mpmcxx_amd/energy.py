@@ -144,6 +144,7 @@ def lib():
     L.mpmc_pi_allreduce.argtypes = [C.POINTER(vp), C.c_int, dp, C.POINTER(Result), C.POINTER(C.c_int)]
     L.mpmc_debug_configure.argtypes = [vp, C.c_char_p, C.c_double]
     L.mpmc_debug_last_pair_kernel.argtypes = [vp]
+    L.mpmc_debug_last_trial_was_full.argtypes = [vp]
     L.mpmc_debug_erfc_table.argtypes = [C.c_double, dp, dp]
     L.mpmc_debug_pair_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.mpmc_debug_time_panel.argtypes = [vp, C.c_int, dp]
@@ -246,6 +247,10 @@ class System:
     def configure(self, key: str, value: float):
         """measurement / A-B switch of THIS context (see mpmc_debug_configure in csrc/context.cpp)."""
         self._check(self._L.mpmc_debug_configure(self._h, key.encode(), float(value)))
+
+    def last_trial_was_full(self) -> bool:
+        """whether the last trial move ran a full evaluation of the trial configuration (True) or per-move delta energies (False)."""
+        return self._L.mpmc_debug_last_trial_was_full(self._h) == 1
 
     def last_pair_kernel(self) -> str:
         return "sweep" if self._L.mpmc_debug_last_pair_kernel(self._h) == 1 else "fused"

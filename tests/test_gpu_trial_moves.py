@@ -27,7 +27,8 @@ def nonpolar(opts):
 @pytest.mark.parametrize("name,polar", [("lj64", False), ("ion64_es", False), ("water64_polar", False), ("ion216_triclinic", False),
                                         ("ion216_frozen", False), ("water64_polar", True), ("ion216_wolf", False), ("water64_fh2", False),
                                         ("ion216_polar", True), ("ion216_polar_nopbc", True), ("ion216_triclinic", True), ("ion216_framework", True),
-                                        ("ion1000_polar", True), ("ion216_precision", True)])
+                                        ("ion1000_polar", True), ("ion216_precision", True), ("water64_fh4", False), ("ion216_fh4_polar", True),
+                                        ("ion216_fh4_polar", False)])
 def test_trial_moves_track_full_evaluations(name, polar):
     from oracle import OracleSystem
 
@@ -45,6 +46,9 @@ def test_trial_moves_track_full_evaluations(name, polar):
         a, b = mols[rng.integers(len(mols))]
         trial = pos[a:b] + rng.normal(scale=0.4, size=(b - a, 3))
         e_trial = S.trial_energy(a, trial)
+        # per-move delta energies, not a full evaluation in disguise -- Wolf and Feynman-Hibbs included (round 3); the one combination
+        # that keeps the full evaluation is a polarizable box under Wolf, which no fixture holds
+        assert not S.last_trial_was_full(), name
         full_pos = pos.copy()
         full_pos[a:b] = trial
         at2 = dict(atoms)
