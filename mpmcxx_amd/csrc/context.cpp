@@ -806,7 +806,7 @@ extern "C" int mpmc_debug_pair_stats(mpmc_ctx *c, int64_t out[12]) {
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	for (int k = 0; k < 12; k++) out[k] = 0;
 	const int nt = c->n_tiles;
-	const bool uni = !(c->tune.no_uniform || c->tune.no_classes) && c->box.ortho;
+	const bool uni = !(c->tune.no_uniform || c->tune.no_classes);
 	auto real = [&](int T) { return (int64_t)std::max(0, std::min(kTile, c->n - T * kTile)); };
 	size_t t = 0;
 	for (int I = 0; I < nt; I++)

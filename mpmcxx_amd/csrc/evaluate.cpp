@@ -319,7 +319,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 
 	// ---- pairwise pass: one symmetric sweep (energies + counts, static-field partials, Thole tensor store) ----------
 	if (mask & (RUN_PAIR | RUN_FIELD | RUN_STORE)) {
-		// tile-pair classes from this configuration's tile bounding boxes (orthorhombic cells; all "near" otherwise)
+		// tile-pair classes from this configuration's tile bounding boxes
 		{
 			ProfScope pc(c, MPMC_K_CLASSES);
 			if (c->tune.no_classes) HIP_TRY(c, hipMemsetAsync(c->d_cls, 0, (size_t)c->n_tile_pairs * sizeof(int), st));
@@ -341,9 +341,9 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		fp.touch_n = fp.store_only ? c->touch_n : -1;
 		for (int k = 0; k < 8; k++) fp.touch[k] = c->touch[k];
 		if (!fp.store_only && compact) c->store_dirty_tiles.clear(); // a full sweep rebuilds every stored tile pair
-		// panels of the Jacobi contraction: two tile pairs of equal class behind one j-tile per wave (orthorhombic cells, stored tensors)
+		// panels of the Jacobi contraction: two tile pairs of equal class behind one j-tile per workgroup (compact solver)
 		c->panels_built = false;
-		if (compact && c->tune.use_panels && c->box.ortho && !c->tune.no_classes && !c->tune.no_uniform && c->n_tiles >= 3) {
+		if (compact && c->tune.use_panels && !c->tune.no_classes && !c->tune.no_uniform && c->n_tiles >= 3) {
 			if (c->seg_tiles != c->n_tiles) { // the table's layout depends on the tile count only
 				std::vector<int> seg((size_t)c->n_tiles + 1, 0);
 				for (int J = 0; J < c->n_tiles; J++) seg[J + 1] = seg[J] + panel_segment_entries(J);

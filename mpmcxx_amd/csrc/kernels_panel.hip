@@ -1,4 +1,4 @@
-// kernels_panel.hip -- the Jacobi contraction of the production path, "panel" form (orthorhombic cells).
+// kernels_panel.hip -- the Jacobi contraction of the production path, "panel" form.
 //
 // One Jacobi iteration is  F = -(A - diag) mu  (reference contract_dipoles, src/System.Energy.cpp:3564-3598, over the matrix of
 // thole_amatrix :2661-2770), evaluated pair by pair:  F_i -= a mu_j - b d (d.mu_j),  F_j -= a mu_i - b d (d.mu_i),  T = a I - b d(x)d.
@@ -19,7 +19,8 @@
 //
 // k_build_panels pairs up, for every j-tile J, the tile pairs (I < J, J) of equal class (then leftovers of equal far/stored kind, with
 // the intersection of their uniform masks); what stays single -- the diagonal tile pair and at most one odd leftover per kind -- runs
-// through the same walk with one member, in the same launch.  (Triclinic cells carry no classes: kernels_sym.hip serves them.)
+// through the same walk with one member, in the same launch.  Triclinic cells: a tile pair is uniform in all three dimensions or in none
+// (the translation B^T img mixes them); the non-uniform ones walk with the full rint(R d) form (TRI).
 // Every partial slot part[source tile][atom] is still written exactly once per iteration: F_k -> part[J][I_k atoms], the combined
 // G -> part[I_0][J atoms], zeros -> part[I_k][J atoms], k > 0.
 #include "kernels.h"
@@ -116,8 +117,8 @@ struct PanAcc {
 };
 
 // one step of the walk: every member against j = (lane + s) & 63 (LDS slot jl = lane + s, no wrap: the image holds every value twice)
-template <bool FAR, int NU, int NI, bool ROT, bool PAD>
-__device__ __forceinline__ void pan_step(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zm, const double2 *__restrict__ s_mm,
+template <bool FAR, int NU, int NI, bool ROT, bool PAD, bool TRI>
+__device__ __forceinline__ void pan_step(const Box &bx, const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zm, const double2 *__restrict__ s_mm,
                                          const double *__restrict__ s_valid, const int jl, const int src4, const double (&L)[3],
                                          const double (&iL)[3], const double (&q)[NI][3], const double (&m)[NI][3], const double2 (&t)[NI],
                                          PanAcc<NI> &A) {
@@ -128,9 +129,16 @@ __device__ __forceinline__ void pan_step(const double2 *__restrict__ s_xy, const
 #pragma unroll
 	for (int k = 0; k < NI; ++k) {
 		double ox = q[k][0] - xj, oy = q[k][1] - yj, oz = q[k][2] - zj;
-		if (NU > 0) ox = fma(-L[0], rint(iL[0] * ox), ox);
-		if (NU > 1) oy = fma(-L[1], rint(iL[1] * oy), oy);
-		if (NU > 2) oz = fma(-L[2], rint(iL[2] * oz), oz);
+		if (TRI) { // general cell without a tile-pair-wide image: the reference's rint(R d), B^T img (values only: nothing here is a predicate)
+			if (NU > 0) {
+				const double dx = ox, dy = oy, dz = oz;
+				(void)min_image_sq<false>(bx, dx, dy, dz, ox, oy, oz);
+			}
+		} else {
+			if (NU > 0) ox = fma(-L[0], rint(iL[0] * ox), ox);
+			if (NU > 1) oy = fma(-L[1], rint(iL[1] * oy), oy);
+			if (NU > 2) oz = fma(-L[2], rint(iL[2] * oz), oz);
+		}
 		double ta, tb;
 		if (FAR) { // bare dipole tensor a = 1/r^3, b = 3/r^5: beyond lambda r = kTholeFarX the Thole damping is dropped (kernels.h)
 			const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
@@ -160,8 +168,8 @@ __device__ __forceinline__ void pan_step(const double2 *__restrict__ s_xy, const
 }
 
 // the walk: n_steps steps from s_first on (64 from 0 for an off-diagonal tile pair, 32 from 1 for a diagonal one); n_steps is a multiple of PIPE
-template <bool FAR, int NU, int NI, int PIPE>
-__device__ __forceinline__ void pan_walk(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zm, const double2 *__restrict__ s_mm,
+template <bool FAR, int NU, int NI, int PIPE, bool TRI>
+__device__ __forceinline__ void pan_walk(const Box &bx, const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zm, const double2 *__restrict__ s_mm,
                                          const double *__restrict__ s_valid, const bool pad, const int lane, const int src4,
                                          const double (&L)[3], const double (&iL)[3], const double (&q)[NI][3], const double (&m)[NI][3],
                                          const double2 *__restrict__ ab, const size_t (&ab_tile)[NI], const int s_first, const int n_steps,
@@ -172,10 +180,10 @@ __device__ __forceinline__ void pan_walk(const double2 *__restrict__ s_xy, const
 #define MPMC_FAR_LOOP(P)                                                                                                               \
 	for (int kc = 0; kc < n_steps - 4; kc += 4, jb += 4) {                                                                             \
 		_Pragma("unroll") for (int u = 0; u < 4; ++u)                                                                                  \
-		    pan_step<true, NU, NI, true, P>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, none, A);                      \
+		    pan_step<true, NU, NI, true, P, TRI>(bx, s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, none, A);                      \
 	}                                                                                                                                  \
-	_Pragma("unroll") for (int u = 0; u < 3; ++u) pan_step<true, NU, NI, true, P>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, none, A); \
-	pan_step<true, NU, NI, false, P>(s_xy, s_zm, s_mm, s_valid, jb + 3, src4, L, iL, q, m, none, A);
+	_Pragma("unroll") for (int u = 0; u < 3; ++u) pan_step<true, NU, NI, true, P, TRI>(bx, s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, none, A); \
+	pan_step<true, NU, NI, false, P, TRI>(bx, s_xy, s_zm, s_mm, s_valid, jb + 3, src4, L, iL, q, m, none, A);
 		if (pad) { // wave-uniform: only the panels whose j-tile is the padded last tile
 			MPMC_FAR_LOOP(true)
 		} else {
@@ -202,7 +210,7 @@ __device__ __forceinline__ void pan_walk(const double2 *__restrict__ s_xy, const
 			double2 t[NI];
 #pragma unroll
 			for (int k = 0; k < NI; ++k) t[k] = buf[k][u];
-			pan_step<false, NU, NI, true, false>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
+			pan_step<false, NU, NI, true, false, TRI>(bx, s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
 #pragma unroll
 			for (int k = 0; k < NI; ++k) buf[k][u] = ld_stream<true>(ab + ab_tile[k] + voff + u * kTile); // refill in place
 			__builtin_amdgcn_sched_barrier(0);
@@ -213,8 +221,8 @@ __device__ __forceinline__ void pan_walk(const double2 *__restrict__ s_xy, const
 		double2 t[NI];
 #pragma unroll
 		for (int k = 0; k < NI; ++k) t[k] = buf[k][u];
-		if (u != PIPE - 1) pan_step<false, NU, NI, true, false>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
-		else pan_step<false, NU, NI, false, false>(s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
+		if (u != PIPE - 1) pan_step<false, NU, NI, true, false, TRI>(bx, s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
+		else pan_step<false, NU, NI, false, false, TRI>(bx, s_xy, s_zm, s_mm, s_valid, jb + u, src4, L, iL, q, m, t, A);
 		__builtin_amdgcn_sched_barrier(0);
 	}
 }
@@ -284,8 +292,12 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	// the four waves split the walk: 16 steps each of the 64 of an off-diagonal tile pair (s = 0..63), 8 each of the 32 of a diagonal one (s = 1..32)
 	const int n_steps = (diag ? 32 : 64) / kPanelWaves, s_first = (diag ? 1 : 0) + w * n_steps;
 	PanAcc<NI> A = {};
-#define MPMC_PWALK(F, N) pan_walk<F, N, NI, PIPE>(s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
-	if (far) {
+#define MPMC_PWALK(F, N) pan_walk<F, N, NI, PIPE, false>(bx, s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
+#define MPMC_PWALK_TRI(F) pan_walk<F, 3, NI, PIPE, true>(bx, s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
+	if (!bx.ortho && nu > 0) { // (a triclinic tile pair is uniform in all three dimensions or in none: k_classify)
+		if (far) MPMC_PWALK_TRI(true);
+		else MPMC_PWALK_TRI(false);
+	} else if (far) {
 		switch (nu) {
 		case 0: MPMC_PWALK(true, 0); break;
 		case 1: MPMC_PWALK(true, 1); break;
@@ -301,6 +313,7 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 		}
 	}
 #undef MPMC_PWALK
+#undef MPMC_PWALK_TRI
 	// the waves' partial sums meet in LDS: F of lane l's own atoms, G parked at the atom it belongs to -- after n_steps - 1 rotations
 	// lane l holds the accumulator of j = (l + s_first + n_steps - 1) & 63
 	{

@@ -476,7 +476,7 @@ void launch_intra_terms(hipStream_t st, const AtomsDev &at, const int *slot_of, 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// tile bounding boxes in wrapped fractional coordinates and tile-pair classes (orthorhombic cells only)
+// tile bounding boxes in wrapped fractional coordinates and tile-pair classes (any cell)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_tile_bounds(AtomsDev at, Box bx, double3 origin_f, double *__restrict__ tb /*[nt][12]*/) {
 	const int lane = threadIdx.x;
@@ -485,9 +485,11 @@ __global__ __launch_bounds__(64) void k_tile_bounds(AtomsDev at, Box bx, double3
 	const bool real = !(at.mf[k].y & AF_PAD);
 	double lo[6], hi[6]; // 0..2 wrapped fractional coordinates, 3..5 raw Cartesian coordinates
 	const double pos[3] = {p.x, p.y, p.z};
+	const double of[3] = {origin_f.x, origin_f.y, origin_f.z};
 	for (int d = 0; d < 3; ++d) {
-		const double of[3] = {origin_f.x, origin_f.y, origin_f.z};
-		double f = bx.r[4 * d] * pos[d] - of[d]; // diagonal cell: fractional coordinate, counted from the origin of the spatial sort
+		// fractional coordinate d = column d of the reciprocal basis . position (the off-diagonal entries of a diagonal cell are exact zeros),
+		// counted from the origin of the spatial sort
+		double f = (((bx.r[d] * pos[0]) + bx.r[3 + d] * pos[1]) + bx.r[6 + d] * pos[2]) - of[d];
 		f -= floor(f);
 		lo[d] = real ? f : 2.0;
 		hi[d] = real ? f : -1.0;
@@ -508,14 +510,24 @@ __global__ __launch_bounds__(64) void k_tile_bounds(AtomsDev at, Box bx, double3
 		}
 }
 
-__global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb, const int2 *__restrict__ tile_pairs, int ntp, Box bx,
+// Lower bound of the minimum-image distance between two tiles from the gaps g_d >= 0 of their fractional bounding boxes on the unit
+// circle.  The image displacement d = B^T f has |f_d| >= g_d in every dimension, so
+//   orthorhombic cell:  |d|^2 >= sum_d (L_d g_d)^2
+//   any cell:           |d| >= g_d / |R_d|  for every d  (R_d: column d of the reciprocal basis, the normal of the planes f_d = const, whose
+//                       spacing is 1 / |R_d|),  and  |d|^2 >= lambda_min(B B^T) |g|^2
+// (cell.plane[d] = 1 / |R_d|, cell.lam_min = lambda_min, both from the host).
+struct CellBounds {
+	double plane[3];
+	double lam_min;
+};
+__global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb, const int2 *__restrict__ tile_pairs, int ntp, Box bx, CellBounds cell,
                                                   double thr_cut2, double thr_far2, int *__restrict__ cls, double4 *__restrict__ tp_shift) {
 	const int t = blockIdx.x * 256 + threadIdx.x;
 	if (t >= ntp) return;
 	const int2 IJ = tile_pairs[t];
 	int c = 0;
 	if (IJ.x != IJ.y) {
-		double d2 = 0;
+		double d2 = 0, g2 = 0, dmax = 0;
 		for (int d = 0; d < 3; ++d) {
 			const double a0 = tb[12 * (size_t)IJ.x + d], a1 = tb[12 * (size_t)IJ.x + 3 + d];
 			const double b0 = tb[12 * (size_t)IJ.y + d], b1 = tb[12 * (size_t)IJ.y + 3 + d];
@@ -523,26 +535,60 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 			if (a1 < b0) gap = fmin(b0 - a1, a0 + 1.0 - b1);
 			else if (b1 < a0) gap = fmin(a0 - b1, b0 + 1.0 - a1);
 			gap = fmax(0.0, gap - 1e-12); // rounding guard: the bound must stay a LOWER bound
-			const double L = fabs(bx.b[4 * d]);
-			d2 += (L * gap) * (L * gap);
+			if (bx.ortho) {
+				const double L = fabs(bx.b[4 * d]);
+				d2 += (L * gap) * (L * gap);
+			} else {
+				g2 += gap * gap;
+				dmax = fmax(dmax, gap * cell.plane[d]);
+			}
 		}
+		if (!bx.ortho) d2 = fmax(dmax * dmax, cell.lam_min * g2) * (1.0 - 1e-12);
 		if (d2 > thr_cut2) c |= CLS_BEYOND_CUTOFF;
 		if (thr_far2 > 0.0 && d2 > thr_far2) c |= CLS_THOLE_FAR;
 	}
 	if (tp_shift) {
-		// Per dimension: is the periodic image index rint(R (x_i - x_j)) the same for every atom pair of the tile pair?  x_i - x_j, the
-		// product and rint are all monotone in their argument (also after rounding), so it suffices that the two extreme
-		// displacements of the RAW coordinate ranges round to the same integer -- the very operations the pair would perform, so
-		// even a pair sitting exactly on the half-box tie (coordinates read from 6-decimal files do) gets the reference's image.
-		// Then d_img = (x_i - B img) - x_j in that dimension.
-		double sh[3];
-		for (int d = 0; d < 3; ++d) {
-			const double ilo = tb[12 * (size_t)IJ.x + 6 + d], ihi = tb[12 * (size_t)IJ.x + 9 + d];
-			const double jlo = tb[12 * (size_t)IJ.y + 6 + d], jhi = tb[12 * (size_t)IJ.y + 9 + d];
-			const double m0 = rint(bx.r[4 * d] * (ilo - jhi)), m1 = rint(bx.r[4 * d] * (ihi - jlo));
-			const bool uni = (m0 == m1) && (ihi >= ilo) && (jhi >= jlo);
-			if (uni) c |= (CLS_UNIFORM_X << d);
-			sh[d] = bx.b[4 * d] * m0;
+		// Is the periodic image index rint(R d) the same for every atom pair of the tile pair?  The subtraction x_i - x_j, the products, the
+		// sums and rint are all monotone in each argument (also after rounding), so it suffices that the very expression the pair would
+		// evaluate (minimum_image, src/System.cpp:1228-1246, same association order) rounds to the same integer at the two extreme corners of
+		// the tiles' RAW coordinate ranges -- even a pair sitting exactly on the half-box tie gets the reference's image.
+		//   orthorhombic cell: per dimension (CLS_UNIFORM_X/Y/Z), shift component B_dd img_d;
+		//   any other cell: the translation B^T img mixes the dimensions, so all three indices must be uniform (all three bits or none).
+		double lo[3], hi[3];
+		bool ok = true;
+		for (int q = 0; q < 3; ++q) {
+			const double ilo = tb[12 * (size_t)IJ.x + 6 + q], ihi = tb[12 * (size_t)IJ.x + 9 + q];
+			const double jlo = tb[12 * (size_t)IJ.y + 6 + q], jhi = tb[12 * (size_t)IJ.y + 9 + q];
+			lo[q] = ilo - jhi;
+			hi[q] = ihi - jlo;
+			ok = ok && (ihi >= ilo) && (jhi >= jlo);
+		}
+		double sh[3] = {0, 0, 0};
+		if (bx.ortho) {
+			for (int d = 0; d < 3; ++d) {
+				const double m0 = rint(bx.r[4 * d] * lo[d]), m1 = rint(bx.r[4 * d] * hi[d]);
+				if ((m0 == m1) && ok) c |= (CLS_UNIFORM_X << d);
+				sh[d] = bx.b[4 * d] * m0;
+			}
+		} else {
+			double img[3];
+			bool uni = ok;
+			for (int p = 0; p < 3; ++p) { // component p: ((R[0][p] d0) + R[1][p] d1) + R[2][p] d2, smallest and largest value over the corner set
+				double e0 = 0.0, e1 = 0.0;
+				for (int q = 0; q < 3; ++q) {
+					const double rq = bx.r[3 * q + p];
+					const double t0 = rq * ((rq >= 0.0) ? lo[q] : hi[q]), t1 = rq * ((rq >= 0.0) ? hi[q] : lo[q]);
+					e0 = (q == 0) ? t0 : e0 + t0;
+					e1 = (q == 0) ? t1 : e1 + t1;
+				}
+				const double m0 = rint(e0), m1 = rint(e1);
+				uni = uni && (m0 == m1);
+				img[p] = m0;
+			}
+			if (uni) {
+				c |= CLS_UNIFORM_X | CLS_UNIFORM_Y | CLS_UNIFORM_Z;
+				for (int p = 0; p < 3; ++p) sh[p] = ((bx.b[p] * img[0]) + bx.b[3 + p] * img[1]) + bx.b[6 + p] * img[2]; // B^T img, as the reference sums it
+			}
 		}
 		tp_shift[t] = make_double4(sh[0], sh[1], sh[2], 0.0);
 	}
@@ -551,10 +597,6 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 
 void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, const int2 *tile_pairs, int n_tile_pairs, double polar_damp,
                          double *tile_bounds, int *cls, double4 *tp_shift, const double origin_f[3], double thole_far_x) {
-	if (!bx.ortho) {
-		(void)hipMemsetAsync(cls, 0, (size_t)n_tile_pairs * sizeof(int), st);
-		return;
-	}
 	const double tmax = (bx.t_lj > bx.t_es) ? bx.t_lj : bx.t_es;
 	const double thr_cut2 = tmax * (1.0 + 1e-9);
 	double thr_far2 = 0.0;
@@ -562,8 +604,31 @@ void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, cons
 		const double rf = thole_far_x / polar_damp;
 		thr_far2 = rf * rf * (1.0 + 1e-9);
 	}
+	CellBounds cell{{0, 0, 0}, 0.0};
+	if (!bx.ortho) { // plane spacings 1 / |R_d| and the smallest eigenvalue of the metric B B^T (Jacobi rotations on the 3 x 3 matrix)
+		for (int d = 0; d < 3; ++d) cell.plane[d] = 1.0 / std::sqrt(bx.r[d] * bx.r[d] + bx.r[3 + d] * bx.r[3 + d] + bx.r[6 + d] * bx.r[6 + d]);
+		double G[3][3];
+		for (int i = 0; i < 3; ++i)
+			for (int j = 0; j < 3; ++j) G[i][j] = bx.b[3 * i] * bx.b[3 * j] + bx.b[3 * i + 1] * bx.b[3 * j + 1] + bx.b[3 * i + 2] * bx.b[3 * j + 2];
+		for (int sweep = 0; sweep < 32; ++sweep)
+			for (int p = 0; p < 2; ++p)
+				for (int q = p + 1; q < 3; ++q) {
+					if (std::fabs(G[p][q]) < 1e-300) continue;
+					const double th = 0.5 * std::atan2(2.0 * G[p][q], G[q][q] - G[p][p]), cs = std::cos(th), sn = std::sin(th);
+					double Rm[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+					Rm[p][p] = cs, Rm[q][q] = cs, Rm[p][q] = sn, Rm[q][p] = -sn;
+					double T[3][3], N[3][3];
+					for (int i = 0; i < 3; ++i)
+						for (int j = 0; j < 3; ++j) T[i][j] = G[i][0] * Rm[0][j] + G[i][1] * Rm[1][j] + G[i][2] * Rm[2][j];
+					for (int i = 0; i < 3; ++i)
+						for (int j = 0; j < 3; ++j) N[i][j] = Rm[0][i] * T[0][j] + Rm[1][i] * T[1][j] + Rm[2][i] * T[2][j];
+					for (int i = 0; i < 3; ++i)
+						for (int j = 0; j < 3; ++j) G[i][j] = N[i][j];
+				}
+		cell.lam_min = std::max(0.0, std::min(G[0][0], std::min(G[1][1], G[2][2])) * (1.0 - 1e-9));
+	}
 	hipLaunchKernelGGL(k_tile_bounds, dim3(at.n_pad / kTile), dim3(kTile), 0, st, at, bx, make_double3(origin_f[0], origin_f[1], origin_f[2]), tile_bounds);
-	hipLaunchKernelGGL(k_classify, dim3((n_tile_pairs + 255) / 256), dim3(256), 0, st, tile_bounds, tile_pairs, n_tile_pairs, bx, thr_cut2,
+	hipLaunchKernelGGL(k_classify, dim3((n_tile_pairs + 255) / 256), dim3(256), 0, st, tile_bounds, tile_pairs, n_tile_pairs, bx, cell, thr_cut2,
 	                   thr_far2, cls, tp_shift);
 }
 

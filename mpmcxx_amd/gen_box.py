@@ -78,6 +78,25 @@ def lattice_box(
     return rows
 
 
+def lattice_box_cell(n_atoms: int, basis, seed: int, charge: float = 0.1, alpha: float = 1.6411, eps: float = 119.8, sigma: float = 3.405) -> List[AtomRow]:
+    """Jittered lattice in the FRACTIONAL coordinates of an arbitrary (triclinic) cell, one atom per molecule, charges +-q: atoms fill the
+    cell evenly whatever its shape (lattice_box fills a cube, which a skewed cell of another volume wraps onto itself)."""
+    n = int(math.ceil(n_atoms ** (1.0 / 3.0) - 1e-9))
+    rng = random.Random(seed)
+    rows: List[AtomRow] = []
+    k = 0
+    for ix in range(n):
+        for iy in range(n):
+            for iz in range(n):
+                if k >= n_atoms:
+                    break
+                k += 1
+                f = [(i + 0.5) / n - 0.5 + rng.uniform(-0.1 / n, 0.1 / n) for i in (ix, iy, iz)]
+                x, y, z = (sum(f[q] * basis[q][p] for q in range(3)) for p in range(3))
+                rows.append(AtomRow(k, "Ar", "Ar", "M", k, x, y, z, 39.948, charge if (k % 2 == 1) else -charge, alpha, eps, sigma))
+    return rows
+
+
 def _rot(rng: random.Random):
     """random rotation matrix from a uniformly drawn unit quaternion."""
     while True:
@@ -224,6 +243,12 @@ def fixture(name: str):
     if name == "ion216_triclinic":
         basis = [[24.0, 0.0, 0.0], [3.0, 23.0, 0.0], [-2.0, 4.0, 22.0]]
         return lattice_box(216, 24.0, 7), basis, dict(POLAR_OPTS)
+    if name == "ion1000_triclinic":  # 16 tiles in a skewed cell: tile classes, uniform images and panels for a non-orthorhombic basis
+        basis = [[40.0, 0.0, 0.0], [5.0, 38.0, 0.0], [-4.0, 6.0, 37.0]]
+        return lattice_box_cell(1000, basis, 21), basis, dict(POLAR_OPTS)
+    if name == "ion4000_triclinic":  # 63 tiles: far-field and beyond-cutoff tile pairs in a skewed cell (large fixture: regenerated, not stored)
+        basis = [[63.4, 0.0, 0.0], [7.0, 61.0, 0.0], [-5.0, 9.0, 60.0]]
+        return lattice_box_cell(4000, basis, 22), basis, dict(POLAR_OPTS)
     if name == "ion216_frozen":  # every 5th atom frozen (quirk 4: frozen handling differs per term)
         return lattice_box(216, 24.0, 7, frozen_every=5), cubic(24.0), dict(POLAR_OPTS)
     if name == "ion216_framework":  # the usual MPMC layout: ONE frozen molecule (150 sites spanning three 64-atom tiles) + 66 mobile atoms
@@ -312,8 +337,9 @@ SMALL_FIXTURES = [
     "ar2", "lj64", "ion64_es", "ion216_polar", "ion216_polar_nopbc", "ion216_triclinic", "ion216_frozen",
     "ion216_precision", "ion216_gamma", "ion216_alpha", "water64_polar", "lj1000", "ion1000_polar",
     "ion216_wolf", "water64_fh2", "water64_fh4", "ion216_fh4_polar", "ion216_gs", "water64_gs_precision", "ion1000_gs", "ion216_framework",
+    "ion1000_triclinic",
 ]
-LARGE_FIXTURES = ["ion10k_es", "ion10k_polar", "ion10k_polar_bead0", "ion10k_polar_bead1"]
+LARGE_FIXTURES = ["ion10k_es", "ion10k_polar", "ion10k_polar_bead0", "ion10k_polar_bead1", "ion4000_triclinic"]
 
 
 def materialize(name: str, outdir: str):

@@ -61,7 +61,7 @@ def main():
         n = len(rows)
         spots = [f"0,1", f"1,0", f"0,{n - 1}", f"{n // 2},{n // 3}"] if n > 3 else ["0,1", "1,0"]
         # small boxes: every atom's E0 / mu / E_ind and the update_com + wrap_all state; 10k boxes: a 64-atom sample (every 157th atom)
-        extra = ["--sample-atoms", "157"] if is_large else ["--dump-atoms", "--dump-com"]
+        extra = ["--sample-atoms", "157" if n > 5000 else "61"] if is_large else ["--dump-atoms", "--dump-com"]
         if opts.get("polarization") == "on" and not is_large:
             extra += ["--amatrix"] + spots
         res = run_harness(inp, extra)
