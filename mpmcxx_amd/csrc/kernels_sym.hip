@@ -483,18 +483,20 @@ __global__ __launch_bounds__(64) void k_tile_bounds(AtomsDev at, Box bx, double3
 	const int k = blockIdx.x * kTile + lane;
 	const double4 p = at.xyzq[k];
 	const bool real = !(at.mf[k].y & AF_PAD);
-	double lo[6], hi[6]; // 0..2 wrapped fractional coordinates, 3..5 raw Cartesian coordinates
+	double lo[6], hi[6]; // 0..2 wrapped fractional coordinates; 3..5 raw coordinates: Cartesian (orthorhombic cell) / fractional (any other)
 	const double pos[3] = {p.x, p.y, p.z};
 	const double of[3] = {origin_f.x, origin_f.y, origin_f.z};
 	for (int d = 0; d < 3; ++d) {
 		// fractional coordinate d = column d of the reciprocal basis . position (the off-diagonal entries of a diagonal cell are exact zeros),
-		// counted from the origin of the spatial sort
-		double f = (((bx.r[d] * pos[0]) + bx.r[3 + d] * pos[1]) + bx.r[6 + d] * pos[2]) - of[d];
+		// wrapped into one period counted from the origin of the spatial sort
+		const double fraw = ((bx.r[d] * pos[0]) + bx.r[3 + d] * pos[1]) + bx.r[6 + d] * pos[2];
+		double f = fraw - of[d];
 		f -= floor(f);
 		lo[d] = real ? f : 2.0;
 		hi[d] = real ? f : -1.0;
-		lo[3 + d] = real ? pos[d] : 1e300;
-		hi[3 + d] = real ? pos[d] : -1e300;
+		const double raw = bx.ortho ? pos[d] : fraw;
+		lo[3 + d] = real ? raw : 1e300;
+		hi[3 + d] = real ? raw : -1e300;
 	}
 	for (int off = 32; off > 0; off >>= 1)
 		for (int d = 0; d < 6; ++d) {
@@ -553,7 +555,11 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 		// evaluate (minimum_image, src/System.cpp:1228-1246, same association order) rounds to the same integer at the two extreme corners of
 		// the tiles' RAW coordinate ranges -- even a pair sitting exactly on the half-box tie gets the reference's image.
 		//   orthorhombic cell: per dimension (CLS_UNIFORM_X/Y/Z), shift component B_dd img_d;
-		//   any other cell: the translation B^T img mixes the dimensions, so all three indices must be uniform (all three bits or none).
+		//   any other cell: the translation B^T img mixes the dimensions, so all three indices must be uniform (all three bits or none), and
+		//   the test runs on the tiles' RAW FRACTIONAL ranges (a tile is compact in fractional coordinates; its Cartesian box is not):
+		//   the pair's own value of (R d)_p differs from the difference of the two atoms' fractional coordinates by rounding only, so a range
+		//   that stays 1e-9 clear of the half-integers on both sides has one image index (a pair ON a half-box tie is left to the general
+		//   path, which rounds it like the reference).
 		double lo[3], hi[3];
 		bool ok = true;
 		for (int q = 0; q < 3; ++q) {
@@ -573,16 +579,9 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 		} else {
 			double img[3];
 			bool uni = ok;
-			for (int p = 0; p < 3; ++p) { // component p: ((R[0][p] d0) + R[1][p] d1) + R[2][p] d2, smallest and largest value over the corner set
-				double e0 = 0.0, e1 = 0.0;
-				for (int q = 0; q < 3; ++q) {
-					const double rq = bx.r[3 * q + p];
-					const double t0 = rq * ((rq >= 0.0) ? lo[q] : hi[q]), t1 = rq * ((rq >= 0.0) ? hi[q] : lo[q]);
-					e0 = (q == 0) ? t0 : e0 + t0;
-					e1 = (q == 0) ? t1 : e1 + t1;
-				}
-				const double m0 = rint(e0), m1 = rint(e1);
-				uni = uni && (m0 == m1);
+			for (int p = 0; p < 3; ++p) { // (lo, hi: extreme differences of the raw fractional coordinate p)
+				const double m0 = rint(lo[p]);
+				uni = uni && (lo[p] - m0 > -0.5 + 1e-9) && (hi[p] - m0 < 0.5 - 1e-9);
 				img[p] = m0;
 			}
 			if (uni) {
