@@ -246,9 +246,9 @@ def fixture(name: str):
     if name == "ion1000_triclinic":  # 16 tiles in a skewed cell: tile classes, uniform images and panels for a non-orthorhombic basis
         basis = [[40.0, 0.0, 0.0], [5.0, 38.0, 0.0], [-4.0, 6.0, 37.0]]
         return lattice_box_cell(1000, basis, 21), basis, dict(POLAR_OPTS)
-    if name == "ion4000_triclinic":  # 63 tiles: far-field and beyond-cutoff tile pairs in a skewed cell (large fixture: regenerated, not stored)
-        basis = [[63.4, 0.0, 0.0], [7.0, 61.0, 0.0], [-5.0, 9.0, 60.0]]
-        return lattice_box_cell(4000, basis, 22), basis, dict(POLAR_OPTS)
+    if name == "ion8000_triclinic":  # 125 tiles: far-field, beyond-cutoff and common-image tile pairs in a skewed cell (large fixture: regenerated, not stored)
+        basis = [[79.8, 0.0, 0.0], [9.0, 77.0, 0.0], [-6.0, 11.0, 75.0]]
+        return lattice_box_cell(8000, basis, 22), basis, dict(POLAR_OPTS)
     if name == "ion216_frozen":  # every 5th atom frozen (quirk 4: frozen handling differs per term)
         return lattice_box(216, 24.0, 7, frozen_every=5), cubic(24.0), dict(POLAR_OPTS)
     if name == "ion216_framework":  # the usual MPMC layout: ONE frozen molecule (150 sites spanning three 64-atom tiles) + 66 mobile atoms
@@ -339,7 +339,7 @@ SMALL_FIXTURES = [
     "ion216_wolf", "water64_fh2", "water64_fh4", "ion216_fh4_polar", "ion216_gs", "water64_gs_precision", "ion1000_gs", "ion216_framework",
     "ion1000_triclinic",
 ]
-LARGE_FIXTURES = ["ion10k_es", "ion10k_polar", "ion10k_polar_bead0", "ion10k_polar_bead1", "ion4000_triclinic"]
+LARGE_FIXTURES = ["ion10k_es", "ion10k_polar", "ion10k_polar_bead0", "ion10k_polar_bead1", "ion8000_triclinic"]
 
 
 def materialize(name: str, outdir: str):

@@ -1,6 +1,6 @@
 """GPU (MI355X): non-orthorhombic cells get the same machinery as orthorhombic ones (round 3): tile-pair classes from rigorous lower
 bounds in fractional coordinates (far-field and beyond-cutoff tile pairs), tile-pair-wide periodic images, and the panel form of the
-Jacobi contraction -- against reference-made goldens (tests/golden/ion1000_triclinic, ion4000_triclinic: oracle/make_golden.py) and
+Jacobi contraction -- against reference-made goldens (tests/golden/ion1000_triclinic, ion8000_triclinic: oracle/make_golden.py) and
 against the same evaluation with the classes switched off."""
 import numpy as np
 import pytest
@@ -11,14 +11,14 @@ from mpmcxx_amd import energy
 pytestmark = pytest.mark.gpu
 
 
-def test_4000_atom_triclinic_box_matches_reference_and_uses_the_classes(tmp_path):
-    g = util.golden("ion4000_triclinic")
-    atoms, basis, opts = util.load_generated("ion4000_triclinic", tmp_path)
+def test_8000_atom_triclinic_box_matches_reference_and_uses_the_classes(tmp_path):
+    g = util.golden("ion8000_triclinic")
+    atoms, basis, opts = util.load_generated("ion8000_triclinic", tmp_path)
     S = energy.System(atoms, basis, opts)
     S.energy()
     r = S.observables
-    util.assert_counts(r, g, False, label="ion4000_triclinic")
-    util.assert_energies(r, g, False, label="ion4000_triclinic")
+    util.assert_counts(r, g, False, label="ion8000_triclinic")
+    util.assert_energies(r, g, False, label="ion8000_triclinic")
     assert r["polar_iterations"] == int(g["polar_iterations"])
     mu, E, F = S.dipoles()
     st = g["sample_stride"]
@@ -28,7 +28,8 @@ def test_4000_atom_triclinic_box_matches_reference_and_uses_the_classes(tmp_path
     # the classes are at work in this skewed cell: tile pairs beyond the damping range are not stored, some share one periodic image
     ps = S.pair_stats()
     assert ps["tile_pairs_far"] > 0.3 * ps["tile_pairs"], ps
-    assert ps["nonuniform_dims_x_pairs_far"] < 3 * ps["pairs_far"], ps  # (3 per pair = no tile pair with a common image)
+    # (3 non-uniform dimensions per pair = no tile pair with a common image: in a skewed cell it is all three dimensions or none)
+    assert ps["nonuniform_dims_x_pairs_far"] < 3 * ps["pairs_far"] and ps["nonuniform_dims_x_pairs_stored"] < 3 * ps["pairs_stored"], ps
     e_cls, mu_cls = r["energy"], mu.copy()
     S.close()
     # the same box with every tile pair "near" (all tensors stored, no image shortcut): same numbers to rounding

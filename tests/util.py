@@ -17,7 +17,7 @@ SMALL = ["ar2", "lj64", "ion64_es", "ion216_polar", "ion216_polar_nopbc", "ion21
          "ion216_precision", "ion216_gamma", "ion216_alpha", "water64_polar", "lj1000", "ion1000_polar",
          "ion216_wolf", "water64_fh2", "water64_fh4", "ion216_fh4_polar", "ion216_gs", "water64_gs_precision", "ion1000_gs", "ion216_framework",
          "ion1000_triclinic"]
-LARGE = ["ion10k_es", "ion10k_polar", "ion4000_triclinic"]
+LARGE = ["ion10k_es", "ion10k_polar", "ion8000_triclinic"]
 
 ENERGY_KEYS = [("energy", "total"), ("rd_energy", "rd"), ("coulombic_energy", "es"), ("polarization_energy", "polar"),
                ("es_real", "es_real"), ("es_recip", "es_recip"), ("es_self", "es_self"),
