@@ -385,9 +385,10 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		c->last_fp_valid = !fp.store_only;
 		ProfScope p(c, MPMC_K_PAIR);
 		// the fast sweep (kernels_pair.hip) where it applies -- orthorhombic cell, Ewald electrostatics, alpha r_c inside its erfc table --
-		// and, by default, where the table is large (small tables: four waves per tile pair in k_pair_fused, a latency matter); the tile
-		// pairs with a special atom, which it skips, go through k_pair_fused on their list
-		const bool sweep = c->tune.pair_kernel != 1 && c->d_sweep_blocks && (c->tune.pair_kernel == 2 || fp.pair_waves == 1) &&
+		// and, by default, where the table has more than kSweepMinPairs tile pairs (below that the 64 dependent steps of its one wave per
+		// tile pair are a latency chain: four waves per tile pair in k_pair_fused); the tile pairs with a special atom, which it skips,
+		// go through k_pair_fused on their list
+		const bool sweep = c->tune.pair_kernel != 1 && c->d_sweep_blocks && (c->tune.pair_kernel == 2 || c->n_tile_pairs > kSweepMinPairs) &&
 		                   pair_sweep_covers(c->box, fp, c->ewald_alpha);
 		c->last_pair_was_sweep = sweep;
 		if (sweep) {

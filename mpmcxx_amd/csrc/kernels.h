@@ -148,6 +148,10 @@ struct PairSweepParams {
 	int nt;         // tiles
 	int have_shift; // tp_shift / CLS_UNIFORM_* are valid
 };
+// Tables with more tile pairs than this take the sweep by default.  Measured (profiles/r03_sweep_sizes.txt), k_pair_fused (four waves per
+// tile pair up to kPairSplitMax) against the sweep: one evaluation at a time +2 % at 3000 atoms (1128 tile pairs), -3 % at 5000 (3160),
+// -5 % at 7000, -9 % at 10 000; 32 beads in flight the sweep wins from 3000 atoms on (+4 % evaluations/s, +4.5 % at 5000, +9 % at 7000).
+constexpr int kSweepMinPairs = 2048;
 // host: the device layout of the erfc table, 3 * 512 double2 = (c0,c1)[512], (c2,c3)[512], (c4,G)[512]  (erfc_table.cpp)
 constexpr int kErfTableDouble2 = 3 * 512;
 void erfc_table_device_layout(double2 *out /*[kErfTableDouble2]*/);
