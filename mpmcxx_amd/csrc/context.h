@@ -30,7 +30,7 @@ struct EvPair {
 };
 
 // Measurement / A-B switches (mpmc_debug_configure; the library reads no environment variable for any of them).  The defaults are the
-// production path; none of them changes a result beyond the last bits (tests/test_gpu_tuning.py holds every one to the reference).
+// production path; none of them changes a result beyond the last bits (tests/test_gpu_round3_fixes.py holds every one to the reference).
 struct mpmc_tuning {
 	int stream_mode = -1;   // "side_stream": -1 by table size (kOneStreamMaxPairs), 0 never fork the side stream, 1 always
 	int pair_kernel = 0;    // "pair_kernel": 0 the fast sweep (kernels_pair.hip) where it applies and the table is large, 1 never, 2 wherever it applies
