@@ -6,6 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import test_gpu_random as T
+if "sweep" in sys.argv:  # force the fast pair sweep (kernels_pair.hip) onto these small tables, where the default is k_pair_fused
+    sys.argv.remove("sweep")
+    from mpmcxx_amd import energy as _E
+    _E.configure("pair_kernel", 2)
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 30

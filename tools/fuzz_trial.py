@@ -12,6 +12,10 @@ import test_gpu_random as T
 import util
 from mpmcxx_amd import energy
 from oracle import OracleSystem
+if "sweep" in sys.argv:  # force the fast pair sweep (kernels_pair.hip) onto these small tables, where the default is k_pair_fused
+    sys.argv.remove("sweep")
+    from mpmcxx_amd import energy as _E
+    _E.configure("pair_kernel", 2)
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -28,6 +32,11 @@ for seed in range(first, first + count):
         continue
     if not polar_only:
         opts.update(polarization=0, polar_iterative=0, polar_ewald=0, rd_only=int(rng.random() < 0.3))
+        r_ext = rng.random()  # adjacent physics of the delta kernels (round 3): Wolf electrostatics, Feynman-Hibbs corrections
+        if r_ext < 0.2 and not opts["rd_only"]:
+            opts.update(wolf=1)
+        elif r_ext < 0.4:
+            opts.update(feynman_hibbs=1, feynman_hibbs_order=int(rng.choice([2, 4])), temperature=float(rng.uniform(20, 150)))
     elif rng.random() < 0.5:
         opts["solver"] = str(rng.choice(["auto", "compact", "matrix_free"]))
     ids = atoms["mol_id"]
@@ -57,13 +66,15 @@ for seed in range(first, first + count):
             assert S.trial_observables["n_lj_in_cutoff"] == F.observables["n_lj_in_cutoff"], (step, "n_lj")
             if not opts["rd_only"]:
                 assert S.trial_observables["n_es_in_cutoff"] == F.observables["n_es_in_cutoff"], (step, "n_es")
+            if not opts["polarization"]:
+                assert not S.last_trial_was_full(), (step, "a full evaluation instead of delta energies")
             F.close()
             if rng.random() < 0.5:
                 S.accept(); pos = full; e_acc = e_trial
             else:
                 S.reject()
         ref = OracleSystem(dict(atoms, pos=pos), basis, opts).energy()
-        if np.isfinite(ref["energy"]):
+        if np.isfinite(ref["energy"]):  # (the oracle's Wolf total carries no real / reciprocal split: the totals are compared)
             assert util.close(S.energy(), ref["energy"]) and util.close(e_acc, ref["energy"], 1e-9), ("final", e_acc, ref["energy"])
         S.close()
     except Exception as e:  # noqa: BLE001
