@@ -863,7 +863,10 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 	else if (k == "polar_delta") t.no_polar_delta = !on;
 	else if (k == "inline_move") t.no_inline_move = !on;
 	else if (k == "trace_panel") t.trace_panel = on;
-	else if (k == "tensor_budget_mb") {
+	else if (k == "panel_replicas") {
+		if (!c || v < 1 || v > 64) return MPMC_ERR_ARG;
+		c->debug_panel_replicas = v;
+	} else if (k == "tensor_budget_mb") {
 		if (value < 0) return MPMC_ERR_ARG;
 		t.tensor_budget_mb = (long long)value;
 	} else return MPMC_ERR_ARG;

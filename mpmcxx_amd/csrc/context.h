@@ -110,6 +110,7 @@ struct mpmc_ctx {
 	bool last_pair_was_sweep = false; // (diagnostics: which kernel the last evaluation's pair pass ran)
 	FusedParams last_fp{};            // the pair pass's parameters in the last evaluation (mpmc_debug_time_pair replays it)
 	bool last_fp_valid = false;
+	int debug_panel_replicas = 1;     // mpmc_debug_configure "panel_replicas": grid repetitions of mpmc_debug_time_panel's launches
 	double4 *h_xyzq = nullptr;       // PINNED host mirror of d_xyzq (slot order, max_pad entries): position updates copy from it asynchronously;
 	hipEvent_t ev_xyzq = nullptr;    // marks the last copy out of it done -- whoever is about to write the mirror waits for that copy only
 	bool xyzq_in_flight = false;     // (mirror_guard), not for the evaluations queued behind it

@@ -569,9 +569,10 @@ extern "C" int mpmc_debug_time_panel(mpmc_ctx *c, int reps, double *ms_per_launc
 		launch_dipole_iter_panel(c->stream, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels, c->n_panel_entries,
 		                         c->d_ab, c->d_part, c->d_gpart, nullptr, nullptr);
 	HIP_TRY(c, hipEventRecord(e0, c->stream));
+	const int replicas = c->debug_panel_replicas; // (> 1: every launch carries the grid that many times: what a batched launch would cost per system)
 	for (int r = 0; r < reps; r++)
 		launch_dipole_iter_panel(c->stream, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels, c->n_panel_entries,
-		                         c->d_ab, c->d_part, c->d_gpart, nullptr, nullptr);
+		                         c->d_ab, c->d_part, c->d_gpart, nullptr, nullptr, replicas);
 	HIP_TRY(c, hipEventRecord(e1, c->stream));
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipEventSynchronize(e1));

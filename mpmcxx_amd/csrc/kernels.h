@@ -196,7 +196,8 @@ void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int 
 // i-side partial sums -> part[J][I atoms] (the usual slots, upper triangle + diagonal only); j-side -> gpart[entry][64][3]
 void launch_dipole_iter_panel(hipStream_t st, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                               const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart,
-                              const int *converged = nullptr, long long *trace = nullptr /*measurement only (MPMC_TRACE_PANEL=1)*/);
+                              const int *converged = nullptr, long long *trace = nullptr /*measurement only (trace_panel)*/,
+                              int replicas = 1 /*measurement only: the grid repeated in y (mpmc_debug_time_panel)*/);
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,
                                 const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr,
                                 int *ctl, int *host_flag, int it);

@@ -484,9 +484,9 @@ void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int 
 
 void launch_dipole_iter_panel(hipStream_t st, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                               const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart,
-                              const int *converged, long long *trace) {
+                              const int *converged, long long *trace, int replicas) {
 	if (n_entries <= 0) return;
-	dim3 grid(n_entries), block(kTile * kPanelWaves);
+	dim3 grid(n_entries, replicas > 1 ? replicas : 1), block(kTile * kPanelWaves); // (replicas: measurement only -- the same work blockIdx.y times)
 	hipLaunchKernelGGL((k_dipole_iter_panel<4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace);
 }
 
