@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec; the fp64 matrix peak is the same number)
+FP64_FMA_SUSTAINED_TFLOPS = 59.0  # what tools/microbench_f64.hip measures for back-to-back v_fma_f64 on all SIMDs (profiles/r01_microbench_f64.txt): the chip holds ~1.8 GHz under fp64 load
 # Algorithmic fp64 flops per unordered pair, counted the way the peak is: FMA = 2, add / sub / mul = 1, v_rsq / v_rcp = 1;
 # rounding (v_rndne), conversions, compares and lane moves are NOT flops.  "nu" = dimensions of the pair's tile pair WITHOUT a
 # tile-pair-wide periodic image (k_classify): there the minimum image costs mul + (rint) + fma = 3 (Jacobi kernels, which may fuse) or
@@ -425,6 +426,9 @@ def main():
                  "consistent": bool(ms * launches_per_step <= ms_per_step),
                  "clock": ("100 launches back to back between ONE pair of HIP events on the kernel's stream, per launch (kernel alone on the GPU)"
                            if back_to_back.get(cls_key) else "HIP events around every launch on the kernel's stream")}
+            # context, not the judged fraction: against the FMA rate the chip sustains (clock under fp64 load), and the ceiling of THIS instruction
+            # stream at that rate -- algorithmic flops per issued VALU instruction (PMC) x the sustained issue rate
+            e["frac_of_sustained_fma_rate"] = ach / FP64_FMA_SUSTAINED_TFLOPS
             if src.get(cls_key) and back_to_back.get(cls_key):
                 e["avg_launch_ms_event_pair_per_launch"] = src[cls_key]
             t = pmc.get(kernel)
@@ -435,6 +439,10 @@ def main():
                     e["frac_by_trace_clock"] = flops / (t["trace_avg_launch_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
                 if t.get("executed_flops_per_launch"):
                     e["frac_executed"] = t["executed_flops_per_launch"] / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
+                if t.get("valu_wave_insts_per_launch"):
+                    # every VALU instruction an FMA on 64 lanes would be 128 flops: the share of that which is algorithmic work
+                    e["algorithmic_flops_per_valu_slot"] = flops / (128.0 * t["valu_wave_insts_per_launch"])
+                    e["ceiling_frac_of_this_instruction_stream"] = e["algorithmic_flops_per_valu_slot"] * FP64_FMA_SUSTAINED_TFLOPS / FP64_VALU_PEAK_TFLOPS
             return e
 
         # dominant kernel: the one with the largest share of the device time of an evaluation (alone-on-the-GPU durations)

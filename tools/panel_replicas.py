@@ -3,7 +3,9 @@
 only; the repeated systems write the same values into the same slots).  usage: python tools/panel_replicas.py"""
 import sys, tempfile, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mpmcxx_amd import energy
+import bench  # noqa: E402
+from mpmcxx_amd import energy  # noqa: E402
+
 atoms, basis, opts = bench.build_case(10000, tempfile.mkdtemp())
 S = energy.System(atoms, basis, opts)
 S.configure("side_stream", 0)
