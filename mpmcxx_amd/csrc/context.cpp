@@ -454,8 +454,9 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 			mf[k] = make_int2(-1 - k, AF_PAD | AF_FROZEN | AF_NULL_RD | AF_ZERO_SIGMA | AF_ZERO_Q | AF_ZERO_ALPHA);
 		}
 	}
-	{ // tile pairs with a "special" atom (what pair_flags / lj_mix look at) are the generic pair kernel's: their list, in tile-pair order
-		constexpr int kSpecial = AF_FROZEN | AF_NULL_RD | AF_HAS_DISP | AF_NEG_SIGMA | AF_ZERO_SIGMA | AF_ZERO_Q;
+	{ // tile pairs with an atom whose flags change lj_mix (sigma < 0, dispersion coefficients) are the generic pair kernel's (the sweep masks
+	  // everything else itself): their list, in tile-pair order
+		constexpr int kSpecial = AF_HAS_DISP | AF_NEG_SIGMA;
 		const int nt = c->n_tiles;
 		std::vector<char> special((size_t)nt, 0);
 		bool any = false;

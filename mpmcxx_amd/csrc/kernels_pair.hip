@@ -15,9 +15,11 @@
 //  * per dimension with a tile-pair-wide periodic image (CLS_UNIFORM_*, k_classify) the displacement is  (x_i - x_j) - B img : two
 //    subtractions that round exactly like the reference's  d - B rint(R d)  (same operands, same order), instead of five operations.
 //    The squared distance is still  ((dx^2) + dy^2) + dz^2  unfused: pair inclusion stays bit-exact (pair_math.h);
-//  * tile pairs of "plain" atoms only (no frozen / chargeless / sigma- or epsilon-less atoms; padding is handled): no flag words, the
-//    exclusion logic is "same molecule" (INTRA) or nothing at all (every molecule one atom); everything else is left to k_pair_fused,
-//    which the host launches on the list of tile pairs with a special atom (launch_pair_fused ... tp_list);
+//  * three grades of exclusion logic, chosen per tile pair (wave-uniform): MODE 0 none at all (plain atoms, every molecule one atom);
+//    MODE 1 "same molecule" (plain atoms); MODE 2 the flag words of pair_exclusions for tile pairs with frozen / chargeless / sigma- or
+//    epsilon-less atoms (masks by and / or of the two flag words, ~11 VALU instructions more).  Only what lj_mix treats specially --
+//    sigma < 0 ("attractive only") and dispersion coefficients -- is left to k_pair_fused, which the host launches on the list of those
+//    tile pairs (launch_pair_fused ... tp_list);
 //  * in-cutoff counts are popcounts of the execution mask on the scalar unit, not per-lane counters; LJ / Coulomb / field code is
 //    spelled with fma where the reference's rounding does not decide a predicate.
 #include "kernels.h"
@@ -28,13 +30,14 @@ namespace mpmc {
 
 constexpr int kSweepWaves = 4;
 constexpr int kSpecialAtom = AF_FROZEN | AF_NULL_RD | AF_HAS_DISP | AF_NEG_SIGMA | AF_ZERO_SIGMA | AF_ZERO_Q; // (what pair_flags / lj_mix look at)
+constexpr int kUnmaskable = AF_HAS_DISP | AF_NEG_SIGMA; // these change the MIXING (lj_mix), not just the masks: the generic kernel keeps them
 constexpr double kTwoOverSqrtPi = 2.0 * kOneOverSqrtPi;
 
 __device__ __forceinline__ int sweep_tp_index(int I, int J, int nt) { return I * nt - (I * (I - 1)) / 2 + (J - I); }
 
 struct SweepI { // the i-atom a lane owns
 	double x, y, z, q, hs, e2; // position, charge, sigma / 2, 2 sqrt(epsilon)
-	int mol;
+	int mol, fl;
 };
 struct SweepAcc {
 	double e_lj, e_re;
@@ -43,9 +46,9 @@ struct SweepAcc {
 };
 
 // one step: lane l against j = slot jl of the (doubled) j-tile image
-template <int UM, bool FIELD, bool INTRA, bool PAD>
+template <int UM, bool FIELD, int MODE, bool PAD>
 __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zq, const double2 *__restrict__ s_se,
-                                           const int *__restrict__ s_mol, const double2 *__restrict__ s_tab, const int jl, const int lane,
+                                           const int2 *__restrict__ s_mf, const double2 *__restrict__ s_tab, const int jl, const int lane,
                                            const SweepI &I, const double shx, const double shy, const double shz, const Box &bx,
                                            const PairSweepParams &pp, const bool half, const bool i_real, const bool store,
                                            double2 *__restrict__ ab_row /*this step's 64 slots of the tensor store (wave-uniform)*/, SweepAcc &A, int &n_lj,
@@ -63,16 +66,27 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 	const double ri2 = ((ox * ox) + oy * oy) + oz * oz;
 	const double ir = fast_rsqrt_1(ri2);
 	const double r = ri2 * ir;
-	int molj = 0;
-	if (INTRA) molj = s_mol[jl];
+	int2 mfj = make_int2(0, 0);
+	if (MODE >= 1 || PAD) mfj = s_mf[jl]; // molecule id, flags (padding slots: negative ids, AF_PAD)
 	// lanes that form a real pair at this step: all of them, except in tile pairs with padding slots (PAD: the last tile) and in the
 	// closing half step of a diagonal tile pair (half, wave-uniform: the compiler peels that step)
 	bool ok = true;
-	if (PAD) ok = i_real && (s_mol[jl] >= 0);
+	if (PAD) ok = i_real && (mfj.x >= 0);
 	if (half) ok = ok && (lane < 32);
-	const bool intra = INTRA && (I.mol == molj);
+	// pair_exclusions (src/System.cpp:1035-1197) for what this grade of tile pair can hold:
+	//   frozen pair (both frozen): no LJ, no Coulomb, no field -- only the Thole tensor;   excl_rd / excl_es: same molecule, or an atom without
+	//   sigma / epsilon (rd) resp. without charge (es);   no_field: both charges zero (real_term :2916).  MODE 0 / 1 know none / only "same molecule".
+	const bool intra = (MODE >= 1) && (I.mol == mfj.x);
+	bool frozen = false, excl_rd = intra, excl_es = intra, no_field = false;
+	if (MODE == 2) {
+		const int any = I.fl | mfj.y, both = I.fl & mfj.y;
+		frozen = (both & AF_FROZEN) != 0;
+		excl_rd = intra || (any & AF_NULL_RD) != 0;
+		excl_es = intra || (any & AF_ZERO_Q) != 0;
+		no_field = (both & AF_ZERO_Q) != 0 || (ri2 == 0.0);
+	}
 
-	if (store) { // thole_amatrix couples every pair: no cutoff, no exclusions (:2694-2767)
+	if (store) { // thole_amatrix couples every pair: no cutoff, no exclusions, frozen included (:2694-2767)
 		const double ir2 = ir * ir;
 		const double ir3 = ir2 * ir, ir5 = (ir2 * ir2) * ir;
 		const double lr = pp.polar_damp * r;
@@ -83,20 +97,23 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 			damp2 = fma(-explr, (lr * lr) * (lr * (1.0 / 6.0)), damp1); // damp1 - e^{-lr} lr^3/6
 		}
 		double ta = damp1 * ir3, tb = (3.0 * damp2) * ir5;
-		if (PAD || half) {
-			ta = ok ? ta : 0.0;
-			tb = ok ? tb : 0.0;
+		if (PAD || half || MODE == 2) {
+			// (coincident sites -- a dummy site on top of an atom -- exist among special atoms: the reference's MAXVALUE guard (:2704-2705) times
+			// its vanishing damping factors is 0)
+			const bool live = ok && !(MODE == 2 && ri2 == 0.0);
+			ta = live ? ta : 0.0;
+			tb = live ? tb : 0.0;
 		}
 		ab_row[lane] = make_double2(ta, tb);
 	}
 
 	// the inclusion predicates, and the counts of the pairs they admit: wave-level masks and popcounts (scalar unit), taken OUTSIDE the
 	// divergent region.  t_es <= t_lj (pair_math.h Box), so the Coulomb pairs are a subset of the LJ shell.
-	const bool in_lj = ok && (ri2 <= bx.t_lj);          // rimg - 1e-12 < rc  (lj :934)
-	const bool in_es = ok && (ri2 <= bx.t_es);         // (implies in_lj)  !(rimg > rc)  (coulombic_real :1490, real_term :2917)
-	const bool lj_on = in_lj && !intra;                  // plain atoms: rd_excluded = es_excluded = same molecule (src/System.cpp:1035-1197)
+	const bool in_lj = ok && !frozen && (ri2 <= bx.t_lj); // rimg - 1e-12 < rc  (lj :934)
+	const bool in_es = ok && !frozen && (ri2 <= bx.t_es); // (implies in_lj)  !(rimg > rc)  (coulombic_real :1490, real_term :2917)
+	const bool lj_on = in_lj && !excl_rd, es_on = in_es && !excl_es;
 	n_lj += __popcll(__builtin_amdgcn_ballot_w64(lj_on));
-	n_es += __popcll(__builtin_amdgcn_ballot_w64(in_es && !intra));
+	n_es += __popcll(__builtin_amdgcn_ballot_w64(es_on));
 	asm volatile("" : "+s"(n_lj), "+s"(n_es)); // (the sums are wanted HERE, in scalar registers: sunk behind the divergent region the masks make a round trip through VGPRs)
 	if (in_lj) {
 		const double2 se = s_se[jl];
@@ -107,7 +124,8 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 			const double s6 = s3 * s3;
 			A.e_lj = fma(e4, fma(s6, s6, -s6), A.e_lj); // 4 eps (s^12 - s^6)  (:965-993)
 		}
-		if (in_es) {
+		const bool fld_on = FIELD && in_es && !(MODE == 2 && no_field);
+		if (es_on || fld_on) {
 			const double x = r * pp.ewald_alpha;
 			const double xs = x * MPMC_ERFTAB_INV_H;
 			const int it = (int)xs;
@@ -121,10 +139,10 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 #pragma unroll
 			for (int k = MPMC_ERFTAB_EXP_DEG - 1; k >= 0; --k) p = hstep(p, t, e[k]);
 			const double G = c4g.y * p; // exp(-x^2)
-			if (!intra) A.e_re = fma((I.q * zq.y) * (G * w), ir, A.e_re); // q_i q_j erfc(alpha r) / r
-			if (FIELD) { // real_term :2919-2934: (2 alpha r / sqrt(pi) exp(-alpha^2 r^2) + erfc) / r^3, erf form (= that - 1) for excluded pairs
+			if (es_on) A.e_re = fma((I.q * zq.y) * (G * w), ir, A.e_re); // q_i q_j erfc(alpha r) / r
+			if (fld_on) { // real_term :2919-2934: (2 alpha r / sqrt(pi) exp(-alpha^2 r^2) + erfc) / r^3, erf form (= that - 1) for es_excluded pairs
 				double B = G * fma(kTwoOverSqrtPi, x, w);
-				if (INTRA) B -= intra ? 1.0 : 0.0;
+				if (MODE >= 1) B -= excl_es ? 1.0 : 0.0;
 				const double fac = B * ((ir * ir) * ir);
 				const double fj = fac * zq.y, fi = fac * I.q;
 				A.ex = fma(fj, ox, A.ex);
@@ -138,9 +156,9 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 	}
 }
 
-template <int UM, bool FIELD, bool INTRA, bool PAD>
+template <int UM, bool FIELD, int MODE, bool PAD>
 __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zq, const double2 *__restrict__ s_se,
-                                        const int *__restrict__ s_mol, const double2 *__restrict__ s_tab, const int lane, const SweepI &I,
+                                        const int2 *__restrict__ s_mf, const double2 *__restrict__ s_tab, const int lane, const SweepI &I,
                                         const double shx, const double shy, const double shz, const Box &bx, const PairSweepParams &pp,
                                         const bool diag, const bool i_real, const bool store,
                                         double2 *__restrict__ ab_tile, SweepAcc &A, int &n_lj, int &n_es) {
@@ -149,7 +167,7 @@ __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, con
 	for (int k = 0; k < n; ++k) {
 		const int s = s0 + k;
 		const bool last = (k == n - 1);
-		sweep_step<UM, FIELD, INTRA, PAD>(s_xy, s_zq, s_se, s_mol, s_tab, lane + s, lane, I, shx, shy, shz, bx, pp, diag && last, i_real, store,
+		sweep_step<UM, FIELD, MODE, PAD>(s_xy, s_zq, s_se, s_mf, s_tab, lane + s, lane, I, shx, shy, shz, bx, pp, diag && last, i_real, store,
 		                                  ab_tile + s * kTile, A, n_lj, n_es);
 		if (FIELD && !last) {
 			A.gx = rot_from_next(A.gx);
@@ -168,8 +186,8 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
                                                                  double2 *__restrict__ ab) {
 	__shared__ double2 s_tab[3 * MPMC_ERFTAB_PIECES];
 	__shared__ double2 s_xy[2 * kTile], s_zq[2 * kTile], s_se[2 * kTile];
-	__shared__ int s_mol[2 * kTile];
-	__shared__ int s_jflags[2];
+	__shared__ int2 s_mf[2 * kTile];
+	__shared__ int s_jflags[3];
 	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int2 blk = blocks[blockIdx.x];
 	const int J = __builtin_amdgcn_readfirstlane(blk.x), I = __builtin_amdgcn_readfirstlane(blk.y) + w;
@@ -183,12 +201,13 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 		s_xy[lane] = s_xy[lane + kTile] = make_double2(pj.x, pj.y);
 		s_zq[lane] = s_zq[lane + kTile] = make_double2(pj.z, pj.w);
 		s_se[lane] = s_se[lane + kTile] = make_double2(0.5 * lj.x, 2.0 * lj.y);
-		s_mol[lane] = s_mol[lane + kTile] = mj.x; // (padding slots carry negative ids)
+		s_mf[lane] = s_mf[lane + kTile] = mj; // (padding slots carry negative ids and AF_PAD)
 		const bool padj = (mj.y & AF_PAD) != 0;
-		const int any_spec = __any(!padj && (mj.y & kSpecialAtom) != 0), any_pad = __any(padj);
+		const int any_unmask = __any(!padj && (mj.y & kUnmaskable) != 0), any_pad = __any(padj), any_spec = __any(!padj && (mj.y & kSpecialAtom) != 0);
 		if (lane == 0) {
-			s_jflags[0] = any_spec;
+			s_jflags[0] = any_unmask;
 			s_jflags[1] = any_pad;
+			s_jflags[2] = any_spec;
 		}
 	}
 	__syncthreads();
@@ -200,8 +219,10 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 	const double2 li = at.lj[i];
 	const int2 mi = at.mf[i];
 	const bool i_real = !(mi.y & AF_PAD);
-	// a tile pair with a special atom belongs to the generic kernel (the host launches it on exactly these: same predicate)
-	if (__builtin_amdgcn_readfirstlane(s_jflags[0]) || __any(i_real && (mi.y & kSpecialAtom) != 0)) return;
+	// a tile pair with an atom whose flags change the MIXING (sigma < 0, dispersion coefficients) belongs to the generic kernel (the host
+	// launches it on exactly these: same predicate); any other special atom (frozen, chargeless, sigma- or epsilon-less) selects the masked grade
+	if (__builtin_amdgcn_readfirstlane(s_jflags[0]) || __any(i_real && (mi.y & kUnmaskable) != 0)) return;
+	const bool special = __builtin_amdgcn_readfirstlane(s_jflags[2]) || __any(i_real && (mi.y & kSpecialAtom) != 0);
 	const bool pad = __builtin_amdgcn_readfirstlane(s_jflags[1]) || __any(!i_real);
 	const bool diag = (I == J);
 	const int cl = cls[tp];
@@ -229,6 +250,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 	Ai.x = pi.x, Ai.y = pi.y, Ai.z = pi.z, Ai.q = pi.w;
 	Ai.hs = 0.5 * li.x, Ai.e2 = 2.0 * li.y;
 	Ai.mol = mi.x;
+	Ai.fl = mi.y;
 	const int um = (pp.have_shift && !pad) ? ((cl / CLS_UNIFORM_X) & 7) : 0; // (the padded tile's pairs take the general image path: one variant)
 	double shx = 0.0, shy = 0.0, shz = 0.0; // B img of the tile pair's common image, per uniform dimension (wave-uniform: scalar loads)
 	if (pp.have_shift) {
@@ -238,21 +260,28 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 	SweepAcc A = {};
 	int n_lj = 0, n_es = 0;
 	double2 *ab_tile = store ? ab + (size_t)tp * (kTile * kTile) : nullptr;
-#define MPMC_SWEEP(M) sweep_walk<M, FIELD, INTRA, false>(s_xy, s_zq, s_se, s_mol, s_tab, lane, Ai, shx, shy, shz, bx, pp, diag, i_real, store, ab_tile, A, n_lj, n_es)
-	switch (um) {
-	case 0:
-		if (pad) sweep_walk<0, FIELD, INTRA, true>(s_xy, s_zq, s_se, s_mol, s_tab, lane, Ai, shx, shy, shz, bx, pp, diag, i_real, store, ab_tile, A, n_lj, n_es);
-		else MPMC_SWEEP(0);
-		break;
-	case 1: MPMC_SWEEP(1); break;
-	case 2: MPMC_SWEEP(2); break;
-	case 3: MPMC_SWEEP(3); break;
-	case 4: MPMC_SWEEP(4); break;
-	case 5: MPMC_SWEEP(5); break;
-	case 6: MPMC_SWEEP(6); break;
-	default: MPMC_SWEEP(7); break;
+#define MPMC_SWEEP_ARGS s_xy, s_zq, s_se, s_mf, s_tab, lane, Ai, shx, shy, shz, bx, pp, diag, i_real, store, ab_tile, A, n_lj, n_es
+#define MPMC_SWEEP_UM(MODE)                                                        \
+	switch (um) {                                                                  \
+	case 0:                                                                        \
+		if (pad) sweep_walk<0, FIELD, MODE, true>(MPMC_SWEEP_ARGS);                \
+		else sweep_walk<0, FIELD, MODE, false>(MPMC_SWEEP_ARGS);                   \
+		break;                                                                     \
+	case 1: sweep_walk<1, FIELD, MODE, false>(MPMC_SWEEP_ARGS); break;             \
+	case 2: sweep_walk<2, FIELD, MODE, false>(MPMC_SWEEP_ARGS); break;             \
+	case 3: sweep_walk<3, FIELD, MODE, false>(MPMC_SWEEP_ARGS); break;             \
+	case 4: sweep_walk<4, FIELD, MODE, false>(MPMC_SWEEP_ARGS); break;             \
+	case 5: sweep_walk<5, FIELD, MODE, false>(MPMC_SWEEP_ARGS); break;             \
+	case 6: sweep_walk<6, FIELD, MODE, false>(MPMC_SWEEP_ARGS); break;             \
+	default: sweep_walk<7, FIELD, MODE, false>(MPMC_SWEEP_ARGS); break;            \
 	}
-#undef MPMC_SWEEP
+	if (special) {
+		MPMC_SWEEP_UM(2)
+	} else {
+		MPMC_SWEEP_UM((INTRA ? 1 : 0))
+	}
+#undef MPMC_SWEEP_UM
+#undef MPMC_SWEEP_ARGS
 
 	if (FIELD) {
 		const int jown = (lane + (diag ? 32 : 63)) & 63; // the j-atom whose accumulator this lane ended up holding

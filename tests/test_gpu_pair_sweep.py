@@ -1,7 +1,7 @@
 """GPU (MI355X): the fast pair sweep (csrc/kernels_pair.hip: erfc table in LDS, four tile pairs per workgroup behind one j-tile, uniform
-periodic images, plain-atom tile pairs) against the reference goldens, the oracle and the generic kernel it replaces.  By default the
-library uses it for large tables only (more than kPairSplitMax tile pairs: the 10 000-atom boxes of test_gpu_large); here it is forced
-onto small boxes, where the fixtures and the oracle are.  Tolerance 1e-9 per component, pair counts bit-exact."""
+periodic images, three grades of exclusion logic) against the reference goldens, the oracle and the generic kernel it replaces.  By default
+the library uses it for tables of more than kSweepMinPairs = 2048 tile pairs (the 10 000-atom boxes of test_gpu_parity / test_gpu_config5);
+here it is forced onto small boxes, where the fixtures and the oracle are.  Tolerance 1e-9 per component, pair counts bit-exact."""
 import numpy as np
 import pytest
 
@@ -113,8 +113,9 @@ def test_plain_random_systems_match_oracle(seed, force_sweep):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_mixed_random_systems_match_oracle(seed, force_sweep):
-    """frozen / chargeless / sigma- and epsilon-less atoms in some tiles: those tile pairs go through the generic kernel on its list,
-    the others through the sweep, in the same evaluation."""
+    """frozen / chargeless / sigma- and epsilon-less atoms in some tiles: those tile pairs take the sweep's masked grade (MODE 2), the plain
+    ones its lean grades, and the tile pairs with a sigma < 0 or dispersion-coefficient atom go through the generic kernel on its list --
+    all in the same evaluation."""
     rng = np.random.default_rng(5000 + seed)
     n = [129, 200, 321, 450][seed % 4]
     cell = ["cubic", "ortho"][seed % 2]
