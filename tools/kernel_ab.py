@@ -22,7 +22,17 @@ from mpmcxx_amd import energy  # noqa: E402
 
 reps = int(os.environ.get("KAB_REPS", "5"))
 natoms = int(os.environ.get("KAB_NATOMS", "10000"))
-atoms, basis, opts = bench.build_case(natoms, tempfile.mkdtemp())
+if os.environ.get("KAB_WATER") == "1":  # natoms / 3 rigid three-site polarizable molecules (sigma- and epsilon-less, partly non-polarizable H sites)
+    from mpmcxx_amd import gen_box, pqr
+
+    wd = tempfile.mkdtemp()
+    nm = natoms // 3
+    L = 14.0 * (nm / 64.0) ** (1.0 / 3.0)
+    gen_box.write_pqr(os.path.join(wd, "w.pqr"), gen_box.molecular_box(nm, L, 5, extra_neutral=False))
+    gen_box.write_input(os.path.join(wd, "w.in"), "w.pqr", gen_box.cubic(L), dict(gen_box.POLAR_OPTS))
+    atoms, basis, opts = pqr.load_case(os.path.join(wd, "w.in"))
+else:
+    atoms, basis, opts = bench.build_case(natoms, tempfile.mkdtemp())
 specs = sys.argv[1:] or ["default:"]
 for rnd in (1, 2):
     for spec in specs:
