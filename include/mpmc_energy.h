@@ -141,7 +141,7 @@ typedef struct mpmc_result {
 #define MPMC_K_TENSOR 3      /* dense thole_amatrix rows (mpmc_thole_amatrix)        */
 #define MPMC_K_DIPOLE_ITER 4 /* Jacobi contraction, stored tensors streamed (one launch per iteration; MATRIX_FREE: its kernel) */
 #define MPMC_K_REDUCE 5      /* dipole update / final reductions / polarization energy */
-#define MPMC_K_DIPOLE_FAR 6  /* Jacobi contraction, far-field tile pairs recomputed (one launch per iteration; MPMC_JACOBI=split only) */
+#define MPMC_K_DIPOLE_FAR 6  /* unused since ABI 4 (the two-kernel form of the Jacobi contraction is gone); the slot stays for layout stability */
 #define MPMC_K_CLASSES 7     /* tile bounding boxes, tile-pair classes, panel table of the Jacobi contraction     */
 #define MPMC_K_COUNT 8
 typedef struct mpmc_timings {

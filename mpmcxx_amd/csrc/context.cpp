@@ -897,7 +897,7 @@ extern "C" int mpmc_debug_upload_counts(mpmc_ctx *c, long long *out2) {
 	return 0;
 }
 
-// measurement only: per-workgroup time stamps of the last panel launch (tools/panel_trace.py); 0 entries unless MPMC_TRACE_PANEL=1
+// measurement only: per-workgroup time stamps of the last panel launch (tools/panel_trace.py); 0 entries unless the context was configured with trace_panel = 1
 extern "C" int mpmc_debug_panel_trace(mpmc_ctx *c, long long *out4, int max_entries) {
 	if (!c || !out4) return -1;
 	if (!c->d_trace) return 0;

@@ -265,7 +265,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		return MPMC_OK;
 	}
 	// the scalar block: zeroed by the post kernel of the evaluation before this one; cleared here only when something else used it since
-	// (the static-terms pass, the lockstep path of pi.cpp, an evaluation that failed half way)
+	// (the static-terms pass, an upload of the atoms, an evaluation that failed half way)
 	if (!c->scal_clean) HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (S_COUNT + C_COUNT) * sizeof(double), st));
 	c->scal_clean = false;
 	if (static_ride) { // first thing on the main stream: its slots are nobody else's (S_LRC_PAIR, S_LRC_SELF, S_ES_SELF)

@@ -59,7 +59,8 @@ enum : int {
 // tiles' bounding boxes, so almost every pair of a far tile pair is much further out).  Measured on the 10 000-atom box: the polarization
 // energy moves by 6e-15 relative between x = 40 and x = 30 (1.4e-12 at x = 26), dipoles by < 1e-13 of the largest one.  The store shrinks from 5299 to
 // 2576 of 12 403 tile pairs (347 -> 169 MB read per Jacobi iteration), which is worth 6-8 % of the whole-job rate: with 32 beads in
-// flight the aggregate HBM traffic (3.7 TB/s at x = 40) is a co-bottleneck.  MPMC_THOLE_FAR_X overrides (>= 20).
+// flight the aggregate HBM traffic (3.7 TB/s at x = 40) is a co-bottleneck.  A compile-time constant: it is the knob of an approximation
+// (rounds 1-2 read it from the environment).
 constexpr double kTholeFarX = 30.0;
 
 // reciprocal space: structure factors for every k, then energy + O(N) atom terms
