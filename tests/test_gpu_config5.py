@@ -96,3 +96,27 @@ def test_dense_mfma_solver_at_full_size(tmp_path):
     total, tensor = S.memory_usage()
     assert total > 6 * 2 ** 30  # the dense matrix really is resident
     S.close()
+
+
+@pytest.mark.parametrize("name", ["ion10k_polar", "ion10k_polar_bead0", "ion8000_triclinic"])
+def test_every_atom_of_the_large_boxes(name, tmp_path):
+    """round 3: E0 / mu / E_ind of EVERY atom of the large polarizable boxes against the reference's own vectors (tests/golden/NAME_atoms.npz,
+    oracle/make_golden_atoms.py), not only the 64-atom sample of the JSON goldens."""
+    import os
+
+    g = np.load(os.path.join(util.GOLDEN, f"{name}_atoms.npz"))
+    atoms, basis, opts = util.load_generated(name, tmp_path)
+    S = energy.System(atoms, basis, opts)
+    e = S.energy()
+    assert util.close(e, float(g["total"])) and util.close(S.observables["polarization_energy"], float(g["polar"]))
+    mu, E, F = S.dipoles()
+    assert mu.shape == g["mu"].shape
+    assert util.max_rel(E, g["ef_static"]) < util.REL_TOL
+    assert util.max_rel(mu, g["mu"]) < util.REL_TOL
+    assert util.max_rel(F, g["ef_induced"]) < util.REL_TOL
+    # ... and atom by atom, relative to the atom's own dipole where that is not tiny
+    scale = np.abs(g["mu"]).max()
+    big = np.linalg.norm(g["mu"], axis=1) > 1e-3 * scale
+    rel = np.linalg.norm(mu - g["mu"], axis=1)[big] / np.linalg.norm(g["mu"], axis=1)[big]
+    assert rel.max() < 1e-8, rel.max()
+    S.close()
