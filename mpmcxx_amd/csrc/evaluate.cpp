@@ -104,6 +104,7 @@ static int ensure_polar_buffers(mpmc_ctx *c) {
 		if ((rc = dev_alloc(c, &c->d_e_recip_part, recip_slices_capacity(np))) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_e_real, 3 * np)) != MPMC_OK) return rc;
 		if ((rc = dev_alloc(c, &c->d_e_real_trial, 3 * np)) != MPMC_OK) return rc;
+		if ((rc = dev_alloc(c, &c->d_gs_ul, 6 * np)) != MPMC_OK) return rc; // Gauss-Seidel sweeps: fields of the tiles above / below
 		// (dev_alloc zero-fills on the context's stream; nothing in this library touches the null stream, which is unordered against
 		// our non-blocking streams)
 	}
@@ -459,7 +460,8 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				if (want_rrms) HIP_TRY(c, hipMemcpyAsync(mu_old, mu, 3 * (size_t)at.n_pad * sizeof(double), hipMemcpyDeviceToDevice, st));
 				{
 					ProfScope p(c, MPMC_K_DIPOLE_ITER);
-					launch_gs_sweep(st, at, c->box, o.polar_damp, c->d_e_static, mu, c->d_e_induced, c->d_part);
+					launch_gs_sweep(st, at, c->box, o.polar_damp, c->d_e_static, mu, c->d_e_induced, c->d_part, c->d_tile_pairs, c->d_cls,
+					                (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_gs_ul, c->d_gs_ul + 3 * (size_t)c->max_pad);
 				}
 				if (want_rrms) {
 					ProfScope p(c, MPMC_K_REDUCE);

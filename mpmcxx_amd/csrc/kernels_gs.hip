@@ -2,112 +2,156 @@
 // with the in-place update of :3590-3592).
 //
 // The reference walks the atoms in atom_array order; atom i sees the NEW dipoles of every j < i and the OLD dipoles of every
-// j > i.  That order is part of the result, so this solver runs with the identity atom order (no spatial sort, context.cpp)
-// and sweeps the tiles of 64 consecutive atoms one after the other:
-//
-//   k_gs_rows   for the 64 rows of tile I: partial induced fields from every OTHER tile J, one workgroup per J, read straight
-//               from the in-place dipole array (tiles J < I already hold this sweep's values, tiles J > I the previous ones).
-//               Matrix-free: T_ij is rebuilt from the positions with the reference's damping (thole_amatrix :2731-2757).
-//   k_gs_tile   one wave: adds the partials in tile order, then walks the 64 atoms of tile I sequentially -- at step k every
-//               lane j contributes T_kj mu_j with its CURRENT dipole, a wave sum gives row k, lane k stores its new dipole.
-//   k_gs_finish rrms / "broke tolerance" flag from (mu before the sweep, mu after), as calc_dipole_rrms :3147-3177 and
-//               are_we_done_yet :3227-3236 do with old_mu / new_mu.
-// The sweep is inherently serial over tiles (2 launches per tile); it is here for coverage of the reference's option, the
-// production path is the Jacobi iteration of kernels_sym.hip.
+// j > i.  That order is part of the result, so this solver runs with the identity atom order (no spatial sort, context.cpp).
+// With tiles of 64 consecutive atoms, the induced field of an atom of tile K is
+//     U (tiles > K, old dipoles)  +  L (tiles < K, this sweep's dipoles)  +  the in-tile part (old for j > i, new for j < i).
+// Round 3 (the round-2 review's item 10): the sweep is a pipeline instead of 2 x 157 launches of 113 us per tile --
+//   * U of ALL tiles comes from ONE launch up front: the matrix-free symmetric Jacobi kernel (k_dipole_iter_hybrid, null store) on the
+//     old dipoles gives every tile pair's row sums; k_gs_upper_sum adds the slots of the tiles above each tile (tile order);
+//   * then ONE launch per tile K (k_gs_stage, nt - K workgroups): workgroup w adds T_{K+w, K-1} mu_{K-1}^{new} -- the dipoles the
+//     launch before has just finished -- into L of tile K + w; workgroup 0 goes on to solve tile K: the in-tile tensors (a, b) into LDS by
+//     four waves, the old-dipole part of every row in parallel, then the 64 atoms one after the other with NO wave reduction -- the atom
+//     whose turn it is closes its row (lane-local sum), its new dipole is broadcast, and every later lane adds T_jk mu_k to its row.
+//   Nothing spins on a flag: the order is the stream's.  Sums are taken in tile order, then lane order: reproducible.
+//   k_gs_finish: rrms / "broke tolerance" flag from (mu before the sweep, mu after), as calc_dipole_rrms :3147-3177 and
+//   are_we_done_yet :3227-3236 do with old_mu / new_mu.
 #include "kernels.h"
 #include "device_math.h"
 
 namespace mpmc {
 
-template <bool ORTHO>
-__global__ __launch_bounds__(64) void k_gs_rows(AtomsDev at, Box bx, double lambda, const double *__restrict__ mu, int I,
-                                                double *__restrict__ part /*[nt][64][3]*/) {
-	__shared__ double4 s_xyzq[kTile];
-	__shared__ double s_mu[kTile * 3];
-	__shared__ int s_fl[kTile];
-	const int lane = threadIdx.x, J = blockIdx.x;
-	double fx = 0, fy = 0, fz = 0;
-	if (J != I) {
-		const int i = I * kTile + lane;
-		const double4 pi = at.xyzq[i];
-		const int jg = J * kTile + lane;
-		s_xyzq[lane] = at.xyzq[jg];
-		s_fl[lane] = at.mf[jg].y;
-		s_mu[3 * lane + 0] = mu[3 * (size_t)jg + 0];
-		s_mu[3 * lane + 1] = mu[3 * (size_t)jg + 1];
-		s_mu[3 * lane + 2] = mu[3 * (size_t)jg + 2];
-		__syncthreads();
-		for (int jj = 0; jj < kTile; ++jj) {
-			if (s_fl[jj] & (AF_PAD | AF_ZERO_ALPHA)) continue; // mu_j == 0 for non-polarizable sites (:3571-3576)
-			const double4 pj = s_xyzq[jj];
-			double ox, oy, oz;
-			const double r = min_image<ORTHO>(bx, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, ox, oy, oz);
-			double a, b;
-			thole_ab(r, lambda, a, b);
-			const double mx = s_mu[3 * jj], my = s_mu[3 * jj + 1], mz = s_mu[3 * jj + 2];
-			const double t3 = b * (((ox * mx) + oy * my) + oz * mz);
-			fx -= a * mx - t3 * ox;
-			fy -= a * my - t3 * oy;
-			fz -= a * mz - t3 * oz;
-		}
+constexpr int kGsWaves = 4;
+
+// (a, b) of thole_amatrix (:2731-2757) from the squared image distance; r = 0 gives (0, 0): the reference's MAXVALUE guard times its
+// vanishing damping factors (:2704-2705)
+__device__ __forceinline__ double2 gs_thole_ab(double r2, double lambda) {
+	const double ir = fast_rsqrt(r2);
+	const double r = r2 * ir;
+	const double ir3 = ir * ir * ir, ir5 = ir3 * ir * ir;
+	const double lr = lambda * r;
+	const double explr = exp_fast(-lr);
+	const double damp1 = fma(-explr, fma(lr, fma(0.5, lr, 1.0), 1.0), 1.0);
+	const double damp2 = fma(-explr, (lr * lr) * (lr * (1.0 / 6.0)), damp1);
+	return (r2 > 0.0) ? make_double2(damp1 * ir3, 3.0 * damp2 * ir5) : make_double2(0.0, 0.0);
+}
+
+// U[i] = sum over the tiles ABOVE the atom's tile of the row slots the symmetric kernel wrote: part[J][i], J > tile(i), in tile order
+__global__ __launch_bounds__(64) void k_gs_upper_sum(const double *__restrict__ part, int nt, int n_pad, double *__restrict__ U, double *__restrict__ L) {
+	const int I = blockIdx.x, i = I * kTile + threadIdx.x;
+	double f[3] = {0, 0, 0};
+#pragma unroll 4
+	for (int J = I + 1; J < nt; ++J) {
+		const double *q = part + ((size_t)J * n_pad + i) * 3;
+		f[0] += q[0];
+		f[1] += q[1];
+		f[2] += q[2];
 	}
-	double *o = part + ((size_t)J * kTile + lane) * 3;
-	o[0] = fx;
-	o[1] = fy;
-	o[2] = fz;
-}
-
-__device__ __forceinline__ double wave_sum_all(double v) { // every lane receives the total (fixed butterfly order)
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-	return v;
+	for (int d = 0; d < 3; ++d) {
+		U[3 * (size_t)i + d] = f[d];
+		L[3 * (size_t)i + d] = 0.0; // the lower part starts every sweep from zero
+	}
 }
 
 template <bool ORTHO>
-__global__ __launch_bounds__(64) void k_gs_tile(AtomsDev at, Box bx, double lambda, const double *__restrict__ e_static,
-                                                const double *__restrict__ part, int n_tiles, int I, double *__restrict__ mu,
-                                                double *__restrict__ e_induced) {
-	const int lane = threadIdx.x;
-	const int i = I * kTile + lane;
-	const double4 p = at.xyzq[i];
+__global__ __launch_bounds__(64 * kGsWaves) void k_gs_stage(AtomsDev at, Box bx, double lambda, const double *__restrict__ e_static,
+                                                           const double *__restrict__ U, double *__restrict__ L, int K, double *__restrict__ mu,
+                                                           double *__restrict__ e_induced) {
+	__shared__ double4 s_pos[kTile];          // source tile (K - 1) in the push, then tile K itself in the solve
+	__shared__ double s_mu[3][kTile];
+	__shared__ double s_p[kGsWaves][3][kTile]; // partial sums of the four waves
+	__shared__ double2 s_T[kTile][kTile];      // workgroup 0: (a, b) of the in-tile pairs, [column][row]
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int J = K + (int)blockIdx.x;
+	const int i = J * kTile + lane;
+	const double4 pi = at.xyzq[i];
+	double low[3] = {0, 0, 0};
+	if (K > 0) { // L_J += T_{J, K-1} mu_{K-1}: lane = row atom, the four waves share the 64 source atoms
+		if (w == 0) {
+			const int sg = (K - 1) * kTile + lane;
+			s_pos[lane] = at.xyzq[sg];
+			const bool src_live = !(at.mf[sg].y & (AF_PAD | AF_ZERO_ALPHA));
+			for (int d = 0; d < 3; ++d) s_mu[d][lane] = src_live ? mu[3 * (size_t)sg + d] : 0.0;
+		}
+		__syncthreads();
+		double f[3] = {0, 0, 0};
+		for (int jj = w * (kTile / kGsWaves); jj < (w + 1) * (kTile / kGsWaves); ++jj) {
+			const double4 pj = s_pos[jj];
+			double ox, oy, oz;
+			const double r2 = min_image_sq<ORTHO>(bx, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, ox, oy, oz);
+			const double2 t = gs_thole_ab(r2, lambda);
+			const double mx = s_mu[0][jj], my = s_mu[1][jj], mz = s_mu[2][jj];
+			const double t3 = t.y * fma(oz, mz, fma(oy, my, ox * mx));
+			f[0] = fma(-t.x, mx, fma(t3, ox, f[0]));
+			f[1] = fma(-t.x, my, fma(t3, oy, f[1]));
+			f[2] = fma(-t.x, mz, fma(t3, oz, f[2]));
+		}
+		for (int d = 0; d < 3; ++d) s_p[w][d][lane] = f[d];
+		__syncthreads();
+		if (w == 0)
+			for (int d = 0; d < 3; ++d) {
+				low[d] = L[3 * (size_t)i + d] + (((s_p[0][d][lane] + s_p[1][d][lane]) + s_p[2][d][lane]) + s_p[3][d][lane]);
+				L[3 * (size_t)i + d] = low[d];
+			}
+	}
+	if (blockIdx.x != 0) return; // (every workgroup but the first has only pushed)
+	// ---- solve tile K ----------------------------------------------------------------------------------------------------------
+	__syncthreads(); // (the push has read s_pos / s_mu / s_p: about to be reused)
 	const double al = at.alpha[i];
 	const bool live = (i < at.n) && (al != 0.0) && !(at.mf[i].y & AF_PAD);
-	double acc[3] = {0, 0, 0};
-	for (int J = 0; J < n_tiles; ++J) { // tile order = the reference's j order up to association
-		if (J == I) continue;
-		const double *q = part + ((size_t)J * kTile + lane) * 3;
-		acc[0] += q[0];
-		acc[1] += q[1];
-		acc[2] += q[2];
+	double m[3] = {0, 0, 0};
+	if (live)
+		for (int d = 0; d < 3; ++d) m[d] = mu[3 * (size_t)i + d]; // the previous sweep's dipole ("old")
+	if (w == 0) {
+		s_pos[lane] = pi;
+		for (int d = 0; d < 3; ++d) s_mu[d][lane] = m[d];
 	}
-	double m[3] = {mu[3 * (size_t)i], mu[3 * (size_t)i + 1], mu[3 * (size_t)i + 2]};
-	if (!live) m[0] = m[1] = m[2] = 0.0;
-	const double e0[3] = {e_static[3 * (size_t)i], e_static[3 * (size_t)i + 1], e_static[3 * (size_t)i + 2]};
-	double eind[3] = {0, 0, 0};
-	for (int k = 0; k < kTile; ++k) {
-		// row k of the tile: lane j supplies - T_kj mu_j (displacement = pos_k - pos_j, the pair order of minimum_image :1202)
-		const double kx = __shfl(p.x, k, 64), ky = __shfl(p.y, k, 64), kz = __shfl(p.z, k, 64);
-		double cx = 0, cy = 0, cz = 0;
-		if (lane != k && live) {
+	__syncthreads();
+	// in-tile tensors and the old-dipole part of every row: wave w takes the columns [16 w, 16 w + 16); column c contributes to row `lane`
+	// with the OLD dipole of c when c > lane
+	{
+		double f[3] = {0, 0, 0};
+		for (int c = w * (kTile / kGsWaves); c < (w + 1) * (kTile / kGsWaves); ++c) {
+			const double4 pc = s_pos[c];
 			double ox, oy, oz;
-			const double r = min_image<ORTHO>(bx, kx - p.x, ky - p.y, kz - p.z, ox, oy, oz);
-			double a, b;
-			thole_ab(r, lambda, a, b);
-			const double t3 = b * (((ox * m[0]) + oy * m[1]) + oz * m[2]);
-			cx = -(a * m[0] - t3 * ox);
-			cy = -(a * m[1] - t3 * oy);
-			cz = -(a * m[2] - t3 * oz);
-		}
-		const double sx = wave_sum_all(cx), sy = wave_sum_all(cy), sz = wave_sum_all(cz);
-		if (lane == k) {
-			if (live) {
-				eind[0] = acc[0] + sx;
-				eind[1] = acc[1] + sy;
-				eind[2] = acc[2] + sz;
-				m[0] = al * (e0[0] + eind[0]); // :3586-3592: new_mu, and mu = new_mu at once
-				m[1] = al * (e0[1] + eind[1]);
-				m[2] = al * (e0[2] + eind[2]);
+			const double r2 = min_image_sq<ORTHO>(bx, pi.x - pc.x, pi.y - pc.y, pi.z - pc.z, ox, oy, oz);
+			const double2 t = (c == lane) ? make_double2(0.0, 0.0) : gs_thole_ab(r2, lambda);
+			s_T[c][lane] = t;
+			if (c > lane) {
+				const double mx = s_mu[0][c], my = s_mu[1][c], mz = s_mu[2][c];
+				const double t3 = t.y * fma(oz, mz, fma(oy, my, ox * mx));
+				f[0] = fma(-t.x, mx, fma(t3, ox, f[0]));
+				f[1] = fma(-t.x, my, fma(t3, oy, f[1]));
+				f[2] = fma(-t.x, mz, fma(t3, oz, f[2]));
 			}
+		}
+		for (int d = 0; d < 3; ++d) s_p[w][d][lane] = f[d];
+	}
+	__syncthreads();
+	if (w != 0) return;
+	// row = E-field pieces that are complete before the walk: tiles above (U), tiles below (L), in-tile atoms behind this one (old dipoles)
+	double row[3], eind[3] = {0, 0, 0};
+	for (int d = 0; d < 3; ++d)
+		row[d] = (U[3 * (size_t)i + d] + low[d]) + (((s_p[0][d][lane] + s_p[1][d][lane]) + s_p[2][d][lane]) + s_p[3][d][lane]);
+	const double e0[3] = {e_static[3 * (size_t)i], e_static[3 * (size_t)i + 1], e_static[3 * (size_t)i + 2]};
+	for (int k = 0; k < kTile; ++k) {
+		// atom k closes its row (everything in front of it has been added) and takes its new dipole at once (:3586-3592) ...
+		if (lane == k && live) {
+			for (int d = 0; d < 3; ++d) {
+				eind[d] = row[d];
+				m[d] = al * (e0[d] + eind[d]);
+			}
+		}
+		// ... which every later atom of the tile sees: row_j -= T_jk mu_k
+		const double mkx = __shfl(m[0], k, 64), mky = __shfl(m[1], k, 64), mkz = __shfl(m[2], k, 64);
+		if (lane > k) {
+			const double4 pk = s_pos[k];
+			double ox, oy, oz;
+			(void)min_image_sq<ORTHO>(bx, pi.x - pk.x, pi.y - pk.y, pi.z - pk.z, ox, oy, oz);
+			const double2 t = s_T[k][lane];
+			const double t3 = t.y * fma(oz, mkz, fma(oy, mky, ox * mkx));
+			row[0] = fma(-t.x, mkx, fma(t3, ox, row[0]));
+			row[1] = fma(-t.x, mky, fma(t3, oy, row[1]));
+			row[2] = fma(-t.x, mkz, fma(t3, oz, row[2]));
 		}
 	}
 	for (int d = 0; d < 3; ++d) {
@@ -138,16 +182,14 @@ __global__ __launch_bounds__(256) void k_gs_finish(AtomsDev at, const double *__
 }
 
 void launch_gs_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, const double *e_static, double *mu, double *e_induced,
-                     double *part) {
+                     double *part, const int2 *tile_pairs, const int *cls, const double4 *tp_shift, int n_tile_pairs, double *U, double *L) {
 	const int nt = at.n_pad / kTile;
-	for (int I = 0; I < nt; ++I) {
-		if (bx.ortho) {
-			hipLaunchKernelGGL(k_gs_rows<true>, dim3(nt), dim3(kTile), 0, st, at, bx, polar_damp, mu, I, part);
-			hipLaunchKernelGGL(k_gs_tile<true>, dim3(1), dim3(kTile), 0, st, at, bx, polar_damp, e_static, part, nt, I, mu, e_induced);
-		} else {
-			hipLaunchKernelGGL(k_gs_rows<false>, dim3(nt), dim3(kTile), 0, st, at, bx, polar_damp, mu, I, part);
-			hipLaunchKernelGGL(k_gs_tile<false>, dim3(1), dim3(kTile), 0, st, at, bx, polar_damp, e_static, part, nt, I, mu, e_induced);
-		}
+	// tiles above: every tile pair's row sums on the old dipoles in one launch, then the slots of the tiles above each tile
+	launch_dipole_iter_hybrid(st, at, bx, mu, tile_pairs, cls, tp_shift, n_tile_pairs, nullptr, part, polar_damp, nullptr);
+	hipLaunchKernelGGL(k_gs_upper_sum, dim3(nt), dim3(kTile), 0, st, part, nt, at.n_pad, U, L);
+	for (int K = 0; K < nt; ++K) {
+		if (bx.ortho) hipLaunchKernelGGL(k_gs_stage<true>, dim3(nt - K), dim3(kTile * kGsWaves), 0, st, at, bx, polar_damp, e_static, U, L, K, mu, e_induced);
+		else hipLaunchKernelGGL(k_gs_stage<false>, dim3(nt - K), dim3(kTile * kGsWaves), 0, st, at, bx, polar_damp, e_static, U, L, K, mu, e_induced);
 	}
 }
 
