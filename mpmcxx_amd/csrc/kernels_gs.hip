@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_stage(AtomsDev at, Box bx,
 	for (int d = 0; d < 3; ++d)
 		row[d] = (U[3 * (size_t)i + d] + low[d]) + (((s_p[0][d][lane] + s_p[1][d][lane]) + s_p[2][d][lane]) + s_p[3][d][lane]);
 	const double e0[3] = {e_static[3 * (size_t)i], e_static[3 * (size_t)i + 1], e_static[3 * (size_t)i + 2]};
+#pragma unroll 4
 	for (int k = 0; k < kTile; ++k) {
 		// atom k closes its row (everything in front of it has been added) and takes its new dipole at once (:3586-3592) ...
 		if (lane == k && live) {
