@@ -55,6 +55,7 @@ int main(int argc, char **argv) {
 			}
 			mc.systems.push_back(&s);
 		}
+		mc.moltype_names = beads[0]->moltype_names;
 		mc.init();
 		mc.use_trial_moves = trial;
 		const std::string base = outdir + "/" + mc.cfg.job_name;

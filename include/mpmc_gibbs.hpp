@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "mpmc_io.hpp"
+#include "mpmc_rotation.hpp"
 #include "mpmc_pimc.hpp" // Rando: the reference's ONE global engine (src/Rando.h)
 #include "mpmc_system.hpp"
 
@@ -319,34 +320,13 @@ private:
 		}
 	}
 
-	struct Quat { // reference src/Quaternion.cpp
-		double x, y, z, w;
-		static Quat axis_angle_degree(double ax, double ay, double az, double angle) { // :32-60
-			angle /= 57.2957795; // (the reference's degree -> radian constant, 2.3e-10 short of 180 / pi: part of the trajectory)
-			const double magnitude = std::sqrt(ax * ax + ay * ay + az * az);
-			if (magnitude == 0.0) return Quat{0, 0, 0, 1};
-			ax /= magnitude;
-			ay /= magnitude;
-			az /= magnitude;
-			const double sinAngle = std::sin(angle / 2.0);
-			return Quat{ax * sinAngle, ay * sinAngle, az * sinAngle, std::cos(angle / 2.0)};
-		}
-		Quat mul(const Quat &r) const { // :105-113
-			const double rw = w * r.w - x * r.x - y * r.y - z * r.z;
-			const double rx = w * r.x + x * r.w + y * r.z - z * r.y;
-			const double ry = w * r.y - x * r.z + y * r.w + z * r.x;
-			const double rz = w * r.z + x * r.y - y * r.x + z * r.w;
-			return Quat{rx, ry, rz, rw};
-		}
-		Quat conjugate() const { return Quat{-x, -y, -z, w}; }
-	};
 	// Molecule::rotate_rand + Molecule::rotate on `atoms` about `c` (src/Molecule.cpp:128-203)
 	void rotate_rand(std::vector<Atom> &atoms, int first, int last, const std::array<double, 3> &c, double scale) {
 		const double x = rng.rand_normal();
 		const double y = rng.rand_normal();
 		const double z = rng.rand_normal();
 		const double angle = rng.rand() * 360 * scale;
-		const Quat q = Quat::axis_angle_degree(x, y, z, angle), qc = q.conjugate();
+		const Rotor spin = Rotor::about_axis_degrees(x, y, z, angle);
 		for (int k = first; k < last; k++) {
 			Atom &a = atoms[k];
 			a.pos[0] -= c[0];
@@ -355,11 +335,10 @@ private:
 		}
 		for (int k = first; k < last; k++) {
 			Atom &a = atoms[k];
-			const Quat p{a.pos[0], a.pos[1], a.pos[2], 0.0};
-			const Quat r = q.mul(p.mul(qc)); // rand_rotation * (position_vector * rand_rotation_conjugate)
-			a.pos[0] = r.x;
-			a.pos[1] = r.y;
-			a.pos[2] = r.z;
+			const Vec3 r = spin.turn_right_first(Vec3{{a.pos[0], a.pos[1], a.pos[2]}});
+			a.pos[0] = r[0];
+			a.pos[1] = r[1];
+			a.pos[2] = r[2];
 			a.pos[0] += c[0];
 			a.pos[1] += c[1];
 			a.pos[2] += c[2];
@@ -368,21 +347,21 @@ private:
 
 	// System::pick_Gibbs_move, src/System.MonteCarlo.cpp:509-720
 	int pick_Gibbs_move() {
-		int num_molecules_exchange[2] = {0, 0};
+		int n_exchangeable[2] = {0, 0};
 		std::vector<int> exchange[2];
 		for (int i = 0; i < 2; i++)
 			for (int m = 0; m < n_molecules(i); m++)
 				if (!mol_frozen(i, m)) {
 					exchange[i].push_back(m);
-					++num_molecules_exchange[i];
+					++n_exchangeable[i];
 				}
 		{
-			const double volume_prob = cfg.volume_probability + 0.0; // (+ spinflip probability: quantum rotation is off)
-			const double transfer_prob = cfg.transfer_probability + volume_prob;
-			const double dice_roll = get_rand(0);
-			if (dice_roll < volume_prob) {
+			const double p_volume = cfg.volume_probability + 0.0; // (+ spinflip probability: quantum rotation is off)
+			const double p_transfer = cfg.transfer_probability + p_volume;
+			const double pick = get_rand(0);
+			if (pick < p_volume) {
 				movetype[0] = movetype[1] = MPMC_MOVETYPE_VOLUME;
-			} else if (dice_roll < transfer_prob) {
+			} else if (pick < p_transfer) {
 				if (get_rand(0) < 0.5) {
 					movetype[0] = MPMC_MOVETYPE_REMOVE;
 					movetype[1] = MPMC_MOVETYPE_INSERT;
@@ -395,12 +374,12 @@ private:
 			}
 		}
 		for (int i = 0; i < 2; i++) {
-			--num_molecules_exchange[i];
+			--n_exchangeable[i];
 			const int pick = (int)std::floor(get_rand(i) * systems[i]->observables->N);
 			if (pick < 0 || pick >= (int)exchange[i].size()) throw 3001; // no_molecules_in_system
 			altered[i] = exchange[i][pick];
 			// the box must keep one molecule: a removal of the last one becomes a displacement (checked inside the loop, as the reference does)
-			if ((!num_molecules_exchange[0] && movetype[0] == MPMC_MOVETYPE_REMOVE) || (!num_molecules_exchange[1] && movetype[1] == MPMC_MOVETYPE_REMOVE))
+			if ((!n_exchangeable[0] && movetype[0] == MPMC_MOVETYPE_REMOVE) || (!n_exchangeable[1] && movetype[1] == MPMC_MOVETYPE_REMOVE))
 				movetype[0] = movetype[1] = MPMC_MOVETYPE_DISPLACE;
 		}
 		for (int i = 0; i < 2; i++) { // checkpoint->molecule_backup = new Molecule(*molecule_altered)

@@ -63,6 +63,7 @@ inline void read_pqr(const std::string &path, System &s) {
 	std::ifstream f(path);
 	if (!f) throw 1000; // fopen_fail_read
 	s.atoms.clear();
+	s.moltype_names.clear();
 	std::string line;
 	bool have_mol = false;
 	long cur_molid = 0;
@@ -97,6 +98,12 @@ inline void read_pqr(const std::string &path, System &s) {
 		a.sigma = v[7];
 		a.frozen = (flag == "f") ? 1 : 0;
 		a.molecule = mol_index;
+		for (size_t k = 0; k < s.moltype_names.size() && a.moltype < 0; k++)
+			if (s.moltype_names[k] == t[3]) a.moltype = (int)k;
+		if (a.moltype < 0) {
+			s.moltype_names.push_back(t[3]);
+			a.moltype = (int)s.moltype_names.size() - 1;
+		}
 		double c;
 		if (t.size() > 16 && to_double(t[16], c)) a.c6 = c;
 		if (t.size() > 17 && to_double(t[17], c)) a.c8 = c;

@@ -13,10 +13,11 @@
 //   PI_perturb_bead_COMs_ENTIRE_SYSTEM :1402-1449
 //   PI_calculate_energy / kinetic / potential :734-824 (mpmc::PathIntegralEnsembleT)
 //   Molecule::update_COM / translate / translate_rand_pbc / move_to_   src/Molecule.cpp:259-345
-//   Quaternion (axis-angle construction, product, rotate)              src/Quaternion.cpp:16-127
-// Scope: rigid molecules without orientational path-integral data (no `bond_length` / `reduced_mass` / orientation-site entries:
-// PI_perturb_beads_orientations returns at :1565 without drawing random numbers), no spin flips, no insert / remove, no simulated
-// annealing.  All P images live in this process (one context per image; images may sit on different devices).
+//   PI_perturb_beads_orientations / generate_orientation_configs / apply_orientation_configs :1559-1698, Molecule::orient
+//                                src/Molecule.cpp:211-254, PI_orientational_mu_length2 :978-1039 (molecule types that carry
+//                                sorbate_orientation_site / sorbate_bondlength / sorbate_reducedMass entries)
+//   rotations                    include/mpmc_rotation.hpp (arithmetic of src/Quaternion.cpp:16-127, src/Vector3D.*)
+// Scope: rigid molecules, no spin flips, no insert / remove, no simulated annealing.  All P images live in this process (one context per image; images may sit on different devices).
 #pragma once
 
 #include <array>
@@ -28,6 +29,7 @@
 #include <vector>
 
 #include "mpmc_io.hpp"
+#include "mpmc_rotation.hpp"
 #include "mpmc_system.hpp"
 
 namespace mpmc {
@@ -47,7 +49,28 @@ private:
 
 enum { MOVETYPE_DISPLACE = 2, MOVETYPE_PERTURB_BEADS = 6 };
 
+// per-molecule-type data of the orientational bead moves (input keys sorbate_orientation_site / sorbate_bondlength / sorbate_reducedMass;
+// reference table: src/SimulationControl.cpp:2975-3072).  Records keep the order in which their molecule type was first named.
+struct SorbateRecord {
+	std::string moltype;
+	int orientation_site = -1;
+	double bond_length = 0, reduced_mass = 0; // Angstrom, kg
+};
+
 struct PimcSettings {
+	std::vector<SorbateRecord> sorbates;
+	SorbateRecord &sorbate(const std::string &moltype) { // the record of a type, appended when new
+		for (SorbateRecord &r : sorbates)
+			if (r.moltype == moltype) return r;
+		sorbates.push_back(SorbateRecord());
+		sorbates.back().moltype = moltype;
+		return sorbates.back();
+	}
+	int sorbate_position(const std::string &moltype) const {
+		for (size_t k = 0; k < sorbates.size(); k++)
+			if (sorbates[k].moltype == moltype) return (int)k;
+		return -1;
+	}
 	std::string job_name = "job";
 	unsigned int numsteps = 0, corrtime = 0, seed = 0;
 	bool seed_set = false, parallel_restarts = false;
@@ -76,7 +99,11 @@ inline PimcSettings read_pimc_settings(const std::string &path) {
 		} else if (k == "feynman_hibbs") {
 			if (onoff(t[1])) throw 3000; // invalid_input: the reference refuses Feynman-Hibbs corrections in a path-integral run (SimulationControl.cpp:1938-1944)
 		} else if (k == "sorbate_orientation_site" || k == "sorbate_bondlength" || k == "sorbate_reducedmass") {
-			throw 4004; // orientational bead moves (:1559-1698) are not mirrored: the reference itself never accepts one
+			if (t.size() < 3 || !to_double(t[2], v)) throw 3000; // invalid_input (src/SimulationControl.cpp:306-339)
+			SorbateRecord &r = c.sorbate(t[1]);
+			if (k == "sorbate_orientation_site") r.orientation_site = (int)v;
+			else if (k == "sorbate_bondlength") r.bond_length = v;
+			else r.reduced_mass = v;
 		} else if (k == "numsteps" || k == "corrtime" || k == "seed" || k == "move_factor" || k == "rot_factor" || k == "bead_perturb_probability" ||
 		           k == "temperature" || k == "pi_trial_chain_length") {
 			if (!to_double(t[1], v)) throw 3000; // invalid_input
@@ -99,6 +126,7 @@ class PathIntegralNVT {
 public:
 	PimcSettings cfg;
 	std::vector<SystemT *> systems; // the P images, all local
+	std::vector<std::string> moltype_names; // System::moltype_names of the PQR the images were read from (only the orientational bead moves look at it)
 	PathIntegralEnsembleT<SystemT> pi;
 	Rando rng;
 	unsigned int step = 0;
@@ -130,7 +158,7 @@ public:
 		pi.nSys = nSys;
 		pi.temperature = cfg.temperature;
 		rng.seed(cfg.seed);
-		starterBead = 0;
+		chain_start = 0;
 		com.assign(nSys, {{0, 0, 0}});
 		mol_mass.assign(nSys, 0.0);
 		backup_pos.assign(nSys, {});
@@ -162,15 +190,17 @@ public:
 		for (step = 1; step <= cfg.numsteps; step++) {
 			const double potential_init = potential_current;
 			const double chain_init = (move == MOVETYPE_PERTURB_BEADS) ? PI_chain_mass_length2() : 0;
+			const double orient_init = (move == MOVETYPE_PERTURB_BEADS) ? PI_orientational_mu_length2() : 0;
 			PI_make_move(move, !use_trial_moves);
 			const double chain_trial = (move == MOVETYPE_PERTURB_BEADS) ? PI_chain_mass_length2() : 0;
+			const double orient_trial = (move == MOVETYPE_PERTURB_BEADS) ? PI_orientational_mu_length2() : 0;
 			double potential_trial = use_trial_moves ? PI_trial_potential() : PI_calculate_potential();
 			const int failed = use_trial_moves ? systems[0]->trial_result().iterator_failed : systems[0]->iterator_failed;
 			if (!std::isfinite(potential_trial)) { // a bad contact is a reject (:128-131)
 				potential_trial = obs.energy = kMaxValue;
 				boltzmann_factor = 0;
 			} else {
-				boltzmann_factor = PI_NVT_boltzmann_factor(move, potential_trial - potential_init, chain_trial - chain_init);
+				boltzmann_factor = PI_NVT_boltzmann_factor(move, potential_trial - potential_init, chain_trial - chain_init, orient_trial - orient_init);
 			}
 			if ((rng.rand() < boltzmann_factor) && (failed == 0)) {
 				register_move(move, true);
@@ -218,15 +248,15 @@ public:
 	// ---- pieces (public so that tests can drive them one by one) --------------------------------------------------------
 	// SimulationControl::PI_pick_NVT_move, :1047-1116
 	int PI_pick_NVT_move() {
-		const double dice_roll_for_move = rng.rand();
-		const double dice_roll_for_target = rng.rand();
+		const double u_move = rng.rand();
+		const double u_target = rng.rand();
 		std::vector<int> perturbable;
 		const std::vector<Atom> &a = systems[0]->atoms;
 		for (size_t m = 0; m + 1 < mol_first.size(); m++)
 			if (!a[mol_first[m + 1] - 1].frozen) perturbable.push_back((int)m); // Molecule::frozen = flag of the last atom row (src/System.cpp:684)
 		if (perturbable.empty()) throw 3001; // no_molecules_in_system
-		target = perturbable[(int)std::floor(perturbable.size() * dice_roll_for_target)];
-		movetype = (dice_roll_for_move < cfg.bead_perturb_probability) ? MOVETYPE_PERTURB_BEADS : MOVETYPE_DISPLACE;
+		target = perturbable[(int)std::floor(perturbable.size() * u_target)];
+		movetype = (u_move < cfg.bead_perturb_probability) ? MOVETYPE_PERTURB_BEADS : MOVETYPE_DISPLACE;
 		const int first = mol_first[target], count = mol_first[target + 1] - first;
 		for (int s = 0; s < nSys; s++) { // checkpoint->molecule_backup = copy of the molecule about to be altered (:1107)
 			backup_pos[s].resize(3 * (size_t)count);
@@ -238,7 +268,10 @@ public:
 
 	void PI_make_move(int mv, bool upload = true) { // :1121-1160
 		if (mv == MOVETYPE_DISPLACE) PI_displace();
-		else if (mv == MOVETYPE_PERTURB_BEADS) PI_perturb_bead_COMs(cfg.PI_trial_chain_length); // orientations: no data, no draws (:1565)
+		else if (mv == MOVETYPE_PERTURB_BEADS) { // PI_perturb_beads :1392-1397
+			PI_perturb_beads_orientations();
+			PI_perturb_bead_COMs(cfg.PI_trial_chain_length);
+		}
 		else throw 12000; // invalid_monte_carlo_move
 		if (!upload) return;
 		const int first = mol_first[target], count = mol_first[target + 1] - first;
@@ -265,29 +298,29 @@ public:
 
 	// SimulationControl::PI_displace, :1320-1387
 	void PI_displace() {
-		double dice_rolls[6];
-		for (int i = 0; i < 6; i++) dice_rolls[i] = rng.rand();
+		double draws[6];
+		for (int i = 0; i < 6; i++) draws[i] = rng.rand();
 		double pi_com[3] = {0, 0, 0};
 		for (int s = 0; s < nSys; s++) {
 			update_COM(s);
-			translate_rand_pbc(s, cfg.move_factor, systems[s]->pbc.cutoff, dice_rolls);
+			translate_rand_pbc(s, cfg.move_factor, systems[s]->pbc.cutoff, draws);
 			for (int d = 0; d < 3; d++) pi_com[d] = pi_com[d] + com[s][d];
 		}
 		for (int d = 0; d < 3; d++) pi_com[d] /= nSys;
-		const double diceX = rng.rand_normal();
-		const double diceY = rng.rand_normal();
-		const double diceZ = rng.rand_normal();
-		const double dice_angle = rng.rand() * cfg.rot_factor;
-		const Quat rotation = Quat::axis_angle_degree(diceX, diceY, diceZ, dice_angle);
+		const double axis_x = rng.rand_normal();
+		const double axis_y = rng.rand_normal();
+		const double axis_z = rng.rand_normal();
+		const double turn_deg = rng.rand() * cfg.rot_factor;
+		const Rotor spin = Rotor::about_axis_degrees(axis_x, axis_y, axis_z, turn_deg);
 		const int first = mol_first[target], last = mol_first[target + 1];
 		for (int s = 0; s < nSys; s++) {
 			translate(s, -pi_com[0], -pi_com[1], -pi_com[2]);
 			for (int i = first; i < last; i++) {
 				double *p = systems[s]->atoms[i].pos;
-				const Quat r = rotation.mul(Quat{p[0], p[1], p[2], 0.0}).mul(rotation.conjugate()); // Quaternion::rotate :124-127
-				p[0] = r.x;
-				p[1] = r.y;
-				p[2] = r.z;
+				const Vec3 r = spin.turn_left_first(Vec3{{p[0], p[1], p[2]}});
+				p[0] = r[0];
+				p[1] = r[1];
+				p[2] = r[2];
 			}
 			translate(s, pi_com[0], pi_com[1], pi_com[2]);
 			update_COM(s);
@@ -301,10 +334,10 @@ public:
 		const double P = (double)nSys;
 		update_COM(0);
 		const double Mass = AMU2KG * mol_mass[0];
-		int prevBead_idx = starterBead;
-		int bead_idx = (prevBead_idx + 1) % nSys;
-		const int finalBead_idx = (prevBead_idx + n + 1) % nSys;
-		starterBead = (starterBead + 1) % nSys;
+		int anchor = chain_start;
+		int placed = (anchor + 1) % nSys;
+		const int far_end = (anchor + n + 1) % nSys;
+		chain_start = (chain_start + 1) % nSys;
 
 		std::vector<std::array<double, 3>> beads(nSys);
 		double chain_COM[3] = {0, 0, 0};
@@ -329,9 +362,9 @@ public:
 			perturbation[1] = rng.rand_normal();
 			perturbation[0] = rng.rand_normal();
 			for (int d = 0; d < 3; d++)
-				beads[bead_idx][d] = ((init_factor * beads[prevBead_idx][d]) + (term_factor * beads[finalBead_idx][d])) + (sigma_factor * perturbation[d]);
-			prevBead_idx = (prevBead_idx + 1) % nSys;
-			bead_idx = (prevBead_idx + 1) % nSys;
+				beads[placed][d] = ((init_factor * beads[anchor][d]) + (term_factor * beads[far_end][d])) + (sigma_factor * perturbation[d]);
+			anchor = (anchor + 1) % nSys;
+			placed = (anchor + 1) % nSys;
 		}
 		double delta_COM[3] = {0, 0, 0};
 		for (int s = 0; s < nSys; s++)
@@ -356,6 +389,124 @@ public:
 		for (SystemT *s : systems) s->atoms_changed();
 	}
 
+	// ---- orientational bead moves (:1559-1698): a molecule type with an orientation site and a bond length gets, before the COM
+	// perturbation, one orientation per image from the bisection sampler of Subramanian et al., J. Chem. Phys. 146, 094105 (2017)
+	int sorbate_of_target() const {
+		const Atom &last = systems[0]->atoms[mol_first[target + 1] - 1]; // Molecule::moleculetype = the label of its last row (src/System.cpp:681)
+		if (last.moltype < 0 || (size_t)last.moltype >= moltype_names.size()) return -1;
+		return cfg.sorbate_position(moltype_names[last.moltype]);
+	}
+	// The reference's get_orientation_site returns the POSITION of the type's record in its table, not the site number stored in
+	// it (src/SimulationControl.cpp:2996-3004: `return (int) it->second`): the first type named in the input orients by its atom 0,
+	// the second by its atom 1, ...  The stock binary's trajectories are made that way, so this driver does the same.
+	int orientation_handle() const {
+		const int k = sorbate_of_target();
+		if (k >= 0 && k >= mol_first[target + 1] - mol_first[target]) throw 9000; // (the reference walks off the molecule's atom list here)
+		return k;
+	}
+	double sorbate_bond_length() const {
+		const int k = sorbate_of_target();
+		return k < 0 ? 0.0 : cfg.sorbates[k].bond_length;
+	}
+
+	// SimulationControl::PI_orientational_mu_length2, :978-1039
+	double PI_orientational_mu_length2() {
+		const int handle = orientation_handle();
+		const double bond_length = sorbate_bond_length();
+		if (handle < 0 || bond_length <= 0) return 0.0;
+		const double ANGSTROM2METER = 1.0e-10;
+		std::vector<Vec3> bonds;
+		for (int s = 0; s < nSys; s++) {
+			update_COM(s);
+			const double *hp = systems[s]->atoms[mol_first[target] + handle].pos;
+			const Vec3 from_com = sub3(Vec3{{hp[0], hp[1], hp[2]}}, com[s]);
+			bonds.push_back(scaled3(bond_length, unit3(from_com)));
+		}
+		double sum = 0.0;
+		for (int i = 0; i < nSys; i++) {
+			const Vec3 d = sub3(bonds[i], bonds[(i + 1) % nSys]);
+			sum += dot3(d, d);
+		}
+		sum *= (ANGSTROM2METER * ANGSTROM2METER);
+		return sum;
+	}
+
+	void PI_perturb_beads_orientations() { // :1559-1570
+		const int handle = orientation_handle();
+		if (handle < 0 || sorbate_bond_length() <= 0) return;
+		generate_orientation_configs();
+		for (int s = 0; s < nSys; s++) orient(s, orientations[s], handle); // apply_orientation_configs :1684-1698
+	}
+
+	void generate_orientation_configs() { // :1575-1598
+		const double kB = 1.3806503e-23, METER2ANGSTROM = 1.0e10;
+		const int k = sorbate_of_target();
+		const double reduced_mass = k < 0 ? -1.0 : cfg.sorbates[k].reduced_mass;
+		if (reduced_mass < 0) throw 6000; // missing_required_datum
+		double bond = sorbate_bond_length();
+		if (bond < 0) throw 6000;
+		bond /= METER2ANGSTROM;
+		const double b2 = bond * bond;
+		const double mu_kT = reduced_mass * kB * cfg.temperature;
+		orientations.assign(nSys, Vec3{{0, 0, 0}});
+		Vec3 first;
+		first[0] = rng.rand_normal(); // Vector3D::randomize, src/Vector3D.cpp:119-124
+		first[1] = rng.rand_normal();
+		first[2] = rng.rand_normal();
+		orientations[0] = unit3(first);
+		place_orientations(0, (unsigned)nSys, 2, (unsigned)nSys, b2, mu_kT);
+	}
+	// :1599-1679 -- the orientation halfway (in chain index) between images `lo` and `hi`, then the two halves
+	void place_orientations(unsigned lo, unsigned hi, unsigned level, unsigned n_images, double b2, double mu_kT) {
+		const double pi_ = 3.141592653589793238462643383279502884L, h = 6.626068e-34;
+		const double two_pi = 2.0 * pi_;
+		if (level > n_images) return;
+		const unsigned mid = (lo + hi) / 2;
+		const Vec3 a = orientations[lo], c = orientations[(hi == n_images) ? 0 : hi];
+		const Vec3 mean_dir = unit3(divided3(add3(a, c), 2.0));
+		Vec3 side; // a vector orthogonal to mean_dir
+		double opening = 0; // angle between a and c
+		if (level > 2) {
+			side = sub3(c, a);
+			opening = angle3(a, c);
+		} else { // a == c: any direction that differs from mean_dir serves to build an orthogonal one
+			const Vec3 other = unit3(add3(Vec3{{1, 2, -3}}, mean_dir));
+			side = cross3(other, mean_dir);
+		}
+		const double u = rng.rand();
+		const double lambda2 = h * h / (two_pi * mu_kT);
+		const double kh = pi_ * b2 / lambda2;                       // Eq. (13b) of the paper
+		const double K = 4.0 * kh * level * std::cos(opening * 0.5); // Eq. (17b)
+		const double tilt = std::acos(1.0 + (1.0 / K) * std::log(1.0 - u * (1.0 - std::exp(-2.0 * K)))); // Eq. (18)
+		const double azimuth = rng.rand() * two_pi;
+		const Vec3 tilt_axis = Rotor::about_axis(mean_dir[0], mean_dir[1], mean_dir[2], azimuth).turn_left_first(side);
+		orientations[mid] = Rotor::about_axis(tilt_axis[0], tilt_axis[1], tilt_axis[2], tilt).turn_left_first(mean_dir);
+		if (level < n_images) {
+			place_orientations(lo, mid, level * 2, n_images, b2, mu_kT);
+			place_orientations(mid, hi, level * 2, n_images, b2, mu_kT);
+		}
+	}
+	// Molecule::orient, src/Molecule.cpp:211-254: turn image s of the altered molecule about its COM so that atom `handle` points along `dir`
+	void orient(int s, const Vec3 &dir, int handle) {
+		update_COM(s);
+		const Vec3 centre = com[s];
+		translate(s, -centre[0], -centre[1], -centre[2]);
+		const int first = mol_first[target], last = mol_first[target + 1];
+		const double *hp = systems[s]->atoms[first + handle].pos;
+		const Vec3 now = unit3(Vec3{{hp[0], hp[1], hp[2]}});
+		const double turn = std::acos(dot3(now, dir) / length3(dir));
+		const Vec3 axis = cross3(now, dir);
+		const Rotor spin = Rotor::about_axis(axis[0], axis[1], axis[2], turn);
+		for (int i = first; i < last; i++) {
+			double *p = systems[s]->atoms[i].pos;
+			const Vec3 r = spin.turn_left_first(Vec3{{p[0], p[1], p[2]}});
+			p[0] = r[0];
+			p[1] = r[1];
+			p[2] = r[2];
+		}
+		translate(s, centre[0], centre[1], centre[2]);
+	}
+
 	// SimulationControl::PI_chain_mass_length2() for the altered molecule, :905-965
 	double PI_chain_mass_length2() {
 		const double AMU2KG = 1.66053873e-27, ANGSTROM2METER = 1.0e-10;
@@ -371,7 +522,7 @@ public:
 	}
 
 	// SimulationControl::PI_NVT_boltzmann_factor, :490-547
-	double PI_NVT_boltzmann_factor(int mv, double delta_energy, double delta_chain) const {
+	double PI_NVT_boltzmann_factor(int mv, double delta_energy, double delta_chain, double delta_orient = 0) const {
 		const double pi_ = 3.141592653589793238462643383279502884L, h = 6.626068e-34, kB = 1.3806503e-23; // src/constants.h:13-20
 		const double T = cfg.temperature;
 		if (mv == MOVETYPE_PERTURB_BEADS) {
@@ -379,7 +530,10 @@ public:
 			const double PIchain_2_K = (P * pi_ * pi_ * kB * T) / (2.0 * h * h);
 			const double potential_contrib = delta_energy / T;
 			const double PI_COM_contrib = delta_chain * PIchain_2_K;
-			const double PI_orientation_contrib = 0;
+			// The orientational chain measure enters WITHOUT the reduced mass (:515-520 reads it and does not use it), i.e. ~1e27 per
+			// A^2: from images that start with one common orientation every orientational trial has delta_orient > 0 and is rejected,
+			// and a trial that shortened the chain would be accepted whatever its energy.  Part of the reference's trajectories.
+			const double PI_orientation_contrib = (sorbate_of_target() >= 0) ? delta_orient * PIchain_2_K : 0;
 			return std::exp(-potential_contrib - PI_COM_contrib - PI_orientation_contrib);
 		}
 		return std::exp(-delta_energy / T);
@@ -411,35 +565,14 @@ public:
 
 private:
 	static constexpr double kMaxValue = 1.0e40; // src/constants.h:56
-	int nSys = 0, target = 0, movetype = MOVETYPE_DISPLACE, starterBead = 0;
+	int nSys = 0, target = 0, movetype = MOVETYPE_DISPLACE, chain_start = 0;
 	std::vector<int> mol_first;
 	std::vector<std::array<double, 3>> com; // Molecule::com of the altered molecule in every image
 	std::vector<double> mol_mass;           // Molecule::mass
+	std::vector<Vec3> orientations;         // one unit vector per image (SimulationControl::orientations)
 	std::vector<std::vector<double>> backup_pos;
 	std::vector<observables_t> checkpoint_obs;
 	observables_t checkpoint_sys_obs;
-
-	struct Quat { // reference src/Quaternion.cpp
-		double x, y, z, w;
-		static Quat axis_angle_degree(double ax, double ay, double az, double angle) { // :32-60
-			angle /= 57.2957795;
-			const double magnitude = std::sqrt(ax * ax + ay * ay + az * az);
-			if (magnitude == 0.0) return Quat{0, 0, 0, 1};
-			ax = ax / magnitude;
-			ay = ay / magnitude;
-			az = az / magnitude;
-			const double sinAngle = std::sin(angle / 2.0);
-			return Quat{ax * sinAngle, ay * sinAngle, az * sinAngle, std::cos(angle / 2.0)};
-		}
-		Quat mul(const Quat &r) const { // :105-113
-			const double rw = w * r.w - x * r.x - y * r.y - z * r.z;
-			const double rx = w * r.x + x * r.w + y * r.z - z * r.y;
-			const double ry = w * r.y - x * r.z + y * r.w + z * r.x;
-			const double rz = w * r.z + x * r.y - y * r.x + z * r.w;
-			return Quat{rx, ry, rz, rw};
-		}
-		Quat conjugate() const { return Quat{-x, -y, -z, w}; }
-	};
 
 	void update_COM(int s) { // Molecule::update_COM, src/Molecule.cpp:259-281
 		const int first = mol_first[target], last = mol_first[target + 1];
@@ -468,13 +601,13 @@ private:
 			p[2] += z;
 		}
 	}
-	void translate_rand_pbc(int s, double scale, double cutoff, const double dice[6]) { // :296-321
-		double trans_x = scale * dice[0] * cutoff;
-		double trans_y = scale * dice[1] * cutoff;
-		double trans_z = scale * dice[2] * cutoff;
-		if (dice[3] < 0.5) trans_x *= -1.0;
-		if (dice[4] < 0.5) trans_y *= -1.0;
-		if (dice[5] < 0.5) trans_z *= -1.0;
+	void translate_rand_pbc(int s, double scale, double cutoff, const double u[6]) { // :296-321
+		double trans_x = scale * u[0] * cutoff;
+		double trans_y = scale * u[1] * cutoff;
+		double trans_z = scale * u[2] * cutoff;
+		if (u[3] < 0.5) trans_x *= -1.0;
+		if (u[4] < 0.5) trans_y *= -1.0;
+		if (u[5] < 0.5) trans_z *= -1.0;
 		const int first = mol_first[target], last = mol_first[target + 1];
 		for (int i = first; i < last; i++) {
 			double *p = systems[s]->atoms[i].pos;

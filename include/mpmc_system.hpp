@@ -62,6 +62,7 @@ struct Atom {
 	double c6 = 0, c8 = 0, c10 = 0;
 	int frozen = 0;
 	int molecule = 0; // index of the owning molecule (consecutive atoms with equal index form one Molecule)
+	int moltype = -1; // index into System::moltype_names (the molecule-type column of the PQR row; -1: not recorded)
 	// written by energy():
 	double mu[3] = {0, 0, 0}, ef_static[3] = {0, 0, 0}, ef_induced[3] = {0, 0, 0};
 };
@@ -89,6 +90,7 @@ public:
 	// ---- state ----
 	PeriodicBoundary pbc;
 	std::vector<Atom> atoms;
+	std::vector<std::string> moltype_names; // molecule-type labels met by read_pqr, in order of first appearance (Atom::moltype indexes it)
 	int natoms = 0;
 	int iterator_failed = 0;
 	double last_volume = 0;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# oracle/make_pi_golden.sh -- regenerates the stock-binary path-integral goldens under tests/golden/{pi001,pi_ion27,pi_h2,pi_water64,pi_frozen,pi_tri,pi_nopbc,pi_wolf,pi_gs,pi_ion1000}
+# oracle/make_pi_golden.sh -- regenerates the stock-binary path-integral goldens under tests/golden/{pi001,pi_ion27,pi_h2,pi_water64,pi_frozen,pi_tri,pi_nopbc,pi_wolf,pi_gs,pi_ion1000,pi_h2_orient}
 # by running the UNMODIFIED reference executable (oracle/_ref/mpmcxx, built in place by `make -C oracle ref`) on the
 # committed inputs.  Test infrastructure; needs /root/reference (container only).  Outputs are data: the energy / dipole /
 # field traces, the final averages block and the final bead geometries ("long_output on" = %.6f coordinates).
@@ -30,4 +30,5 @@ run_case pi_tri input.in 4 tri        # triclinic cell, Jacobi terminated by pol
 run_case pi_nopbc input.in 4 nopbc    # static field without Ewald (thole_field_nopbc), polar_gamma, dipole rrms
 run_case pi_wolf input.in 4 wolf      # Wolf electrostatics, no LRC
 run_case pi_gs input.in 4 gs          # Gauss-Seidel sweeps + dipole rrms
+run_case pi_h2_orient input.in 4 h2or   # orientational bead moves: per-image restart files with scattered orientations (oracle/make_pi_orient_fixture.py), sorbate_* keys
 run_case pi_ion1000 input.in 4 ion1000 rows-only   # 1000 polarizable ions: energy.dat rows and averages only (size)

@@ -140,6 +140,7 @@ int main(int argc, char **argv) {
 		std::vector<std::unique_ptr<OracleBead>> beads;
 		mpmc::PathIntegralNVT<OracleBead> mc;
 		mc.cfg = mpmc::read_pimc_settings(argv[1]);
+		mc.moltype_names = proto.moltype_names;
 		for (int b = 0; b < P; b++) {
 			beads.emplace_back(new OracleBead());
 			OracleBead &o = *beads.back();
@@ -150,6 +151,13 @@ int main(int argc, char **argv) {
 			o.ewald_alpha = proto.ewald_alpha, o.polar_ewald_alpha = proto.polar_ewald_alpha;
 			o.pbc = proto.pbc;
 			o.atoms = proto.atoms;
+			if (mc.cfg.parallel_restarts) { // one geometry per image: JOB.restart-%04d.pqr next to the input file
+				char name[64];
+				std::snprintf(name, sizeof name, ".restart-%04d.pqr", b);
+				mpmc::System image;
+				mpmc::read_pqr(mpmc::io_detail::dirname_of(argv[1]) + "/" + mc.cfg.job_name + name, image);
+				o.atoms = image.atoms;
+			}
 			mc.systems.push_back(&o);
 		}
 		mc.init();

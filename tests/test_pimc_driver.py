@@ -28,6 +28,9 @@ CASES = {
     "pi_nopbc": ("input.in", 4, "nopbc"),  # polar_ewald off (thole_field_nopbc), polar_gamma 1.03, dipole rrms
     "pi_wolf": ("input.in", 4, "wolf"),  # Wolf electrostatics, rd_lrc off
     "pi_gs": ("input.in", 4, "gs"),  # Gauss-Seidel sweeps, dipole rrms
+    # orientational bead moves (sorbate_orientation_site / sorbate_bondlength / sorbate_reducedMass): the four images start from restart files
+    # with scattered orientations, so that a quarter of the bead moves is accepted and every row depends on the orientation sampler
+    "pi_h2_orient": ("input.in", 4, "h2or"),
     "pi_ion1000": ("input.in", 4, "ion1000"),  # 1000 polarizable ions, 12 steps: rows and acceptance rates only (no final geometries kept)
 }
 LIBDIR = os.path.join(util.ROOT, "mpmcxx_amd")
@@ -97,9 +100,9 @@ def test_driver_refuses_what_it_does_not_cover(pimc_check, tmp_path):
     out = subprocess.run([pimc_check, str(p), "8", str(tmp_path)], stdout=subprocess.PIPE, text=True)
     assert out.returncode == 1 and json.loads(out.stdout)["error"] == 3000  # as the reference: no Feynman-Hibbs corrections in a PI run
     p = tmp_path / "orient.in"
-    p.write_text(src.replace("Ar-Ar-4A.pqr", os.path.join(util.GOLDEN, "pi001", "Ar-Ar-4A.pqr")) + "\nsorbate_bondlength Ar 0.742\n")
+    p.write_text(src.replace("Ar-Ar-4A.pqr", os.path.join(util.GOLDEN, "pi001", "Ar-Ar-4A.pqr")) + "\nsorbate_bondlength Ar\n")
     out = subprocess.run([pimc_check, str(p), "8", str(tmp_path)], stdout=subprocess.PIPE, text=True)
-    assert out.returncode == 1 and json.loads(out.stdout)["error"] == 4004  # orientational bead moves are refused, not silently skipped
+    assert out.returncode == 1 and json.loads(out.stdout)["error"] == 3000  # a sorbate_* key without its value
     out = subprocess.run([pimc_check, os.path.join(util.GOLDEN, "pi001", "equilibrate.in"), "6", str(tmp_path)], stdout=subprocess.PIPE, text=True)
     assert out.returncode == 1 and json.loads(out.stdout)["error"] == 9003  # the Trotter number must be a power of two >= 4
 
