@@ -89,7 +89,8 @@ def test_pi_1000_ion_box_stock_driver_checks_every_call(tmp_path):
 
 
 @pytest.mark.parametrize("mode", ["gpu", "both"])
-@pytest.mark.parametrize("case,job", [("pi_h2", "h2pi"), ("pi_water64", "water64"), ("pi_frozen", "frozen"), ("pi_tri", "tri"), ("pi_gs", "gs"), ("pi_nopbc", "nopbc"), ("pi_wolf", "wolf")])
+@pytest.mark.parametrize("case,job", [("pi_h2", "h2pi"), ("pi_water64", "water64"), ("pi_frozen", "frozen"), ("pi_tri", "tri"), ("pi_gs", "gs"), ("pi_nopbc", "nopbc"), ("pi_wolf", "wolf"),
+                                      ("pi_h2_orient", "h2or")])  # (orientational bead moves, per-image restart files)
 def test_pi_boxes_through_the_stock_driver(tmp_path, case, job, mode):
     """Rigid molecules through the stock driver (rotation + translation moves, wrapall): 8 LJ diatomics, 64 three-site polarizable
     molecules with a neutral polarizable atom, and a frozen charged framework with mobile polar diatomics (intramolecular exclusions, the erf form of the field for chargeless partners, Ewald,
