@@ -140,25 +140,33 @@ __device__ __forceinline__ void pan_step(const Box &bx, const double2 *__restric
 			if (NU > 2) oz = fma(-L[2], rint(iL[2] * oz), oz);
 		}
 		double ta, tb;
-		if (FAR) { // bare dipole tensor a = 1/r^3, b = 3/r^5: beyond lambda r = kTholeFarX the Thole damping is dropped (kernels.h)
+		if (FAR) { // bare dipole tensor T = a (w d (x) d - 1), a = 1/r^3, w = 3/r^2: beyond lambda r = kTholeFarX the Thole damping is dropped (kernels.h)
 			const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
 			const double ir = fast_rsqrt_1(r2);
 			const double ir2 = ir * ir;
 			ta = ir2 * ir;
 			if (PAD) ta *= vj; // padded slots of the last tile
-			tb = ta * (3.0 * ir2);
+			tb = 3.0 * ir2; // (w, not b = a w: the factor a is applied once per component below, which saves the product a w)
+			const double sj = tb * fma(oz, mjz, fma(oy, mjy, ox * mjx));
+			const double si = tb * fma(oz, m[k][2], fma(oy, m[k][1], ox * m[k][0]));
+			A.f[k][0] = fma(ta, fma(sj, ox, -mjx), A.f[k][0]);
+			A.f[k][1] = fma(ta, fma(sj, oy, -mjy), A.f[k][1]);
+			A.f[k][2] = fma(ta, fma(sj, oz, -mjz), A.f[k][2]);
+			A.g[0] = fma(ta, fma(si, ox, -m[k][0]), A.g[0]);
+			A.g[1] = fma(ta, fma(si, oy, -m[k][1]), A.g[1]);
+			A.g[2] = fma(ta, fma(si, oz, -m[k][2]), A.g[2]);
 		} else {
 			ta = t[k].x;
 			tb = t[k].y;
+			const double dj = tb * fma(oz, mjz, fma(oy, mjy, ox * mjx));
+			const double di = tb * fma(oz, m[k][2], fma(oy, m[k][1], ox * m[k][0]));
+			A.f[k][0] = fma(-ta, mjx, fma(dj, ox, A.f[k][0]));
+			A.f[k][1] = fma(-ta, mjy, fma(dj, oy, A.f[k][1]));
+			A.f[k][2] = fma(-ta, mjz, fma(dj, oz, A.f[k][2]));
+			A.g[0] = fma(-ta, m[k][0], fma(di, ox, A.g[0]));
+			A.g[1] = fma(-ta, m[k][1], fma(di, oy, A.g[1]));
+			A.g[2] = fma(-ta, m[k][2], fma(di, oz, A.g[2]));
 		}
-		const double dj = tb * fma(oz, mjz, fma(oy, mjy, ox * mjx));
-		const double di = tb * fma(oz, m[k][2], fma(oy, m[k][1], ox * m[k][0]));
-		A.f[k][0] = fma(-ta, mjx, fma(dj, ox, A.f[k][0]));
-		A.f[k][1] = fma(-ta, mjy, fma(dj, oy, A.f[k][1]));
-		A.f[k][2] = fma(-ta, mjz, fma(dj, oz, A.f[k][2]));
-		A.g[0] = fma(-ta, m[k][0], fma(di, ox, A.g[0]));
-		A.g[1] = fma(-ta, m[k][1], fma(di, oy, A.g[1]));
-		A.g[2] = fma(-ta, m[k][2], fma(di, oz, A.g[2]));
 	}
 	if (ROT) {
 		A.g[0] = rot_from_next(A.g[0]);
