@@ -908,6 +908,17 @@ extern "C" int mpmc_debug_panel_trace(mpmc_ctx *c, long long *out4, int max_entr
 	return n;
 }
 
+// measurement only: the work table of the panel kernel, { tile pair A, tile pair B or -1, uniform mask | far << 3 | diagonal << 4, J } per workgroup
+extern "C" int mpmc_debug_panel_table(mpmc_ctx *c, int *out4, int max_entries) {
+	if (!c || !out4) return -1;
+	if (!c->d_panels || !c->panels_built) return 0;
+	const int n = std::min(max_entries, c->n_panel_entries);
+	if (hipSetDevice(c->device) != hipSuccess) return -1;
+	if (hipMemcpyAsync(out4, c->d_panels, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+	if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+	return n;
+}
+
 extern "C" int mpmc_memory_usage(mpmc_ctx *c, int64_t *total, int64_t *tensor) {
 	if (!c) return MPMC_ERR_ARG;
 	if (total) *total = c->bytes_total;
