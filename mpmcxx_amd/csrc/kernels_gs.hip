@@ -10,8 +10,9 @@
 //     old dipoles gives every tile pair's row sums; k_gs_upper_sum adds the slots of the tiles above each tile (tile order);
 //   * then ONE launch per tile K (k_gs_stage, nt - K workgroups): workgroup w adds T_{K+w, K-1} mu_{K-1}^{new} -- the dipoles the
 //     launch before has just finished -- into L of tile K + w; workgroup 0 goes on to solve tile K: the in-tile tensors (a, b) into LDS by
-//     four waves, the old-dipole part of every row in parallel, then the 64 atoms one after the other with NO wave reduction -- the atom
-//     whose turn it is closes its row (lane-local sum), its new dipole is broadcast, and every later lane adds T_jk mu_k to its row.
+//     eight waves, the old-dipole part of every row in parallel, then the 64 atoms one after the other with NO wave reduction, branch or
+//     mask -- the new dipole of the atom whose turn it is is read with v_readlane, and every lane adds T_jk mu_k to its row (the slots of
+//     rows at or in front of k hold zero tensors).
 //   Nothing spins on a flag: the order is the stream's.  Sums are taken in tile order, then lane order: reproducible.
 //   k_gs_finish: rrms / "broke tolerance" flag from (mu before the sweep, mu after), as calc_dipole_rrms :3147-3177 and
 //   are_we_done_yet :3227-3236 do with old_mu / new_mu.
@@ -20,7 +21,7 @@
 
 namespace mpmc {
 
-constexpr int kGsWaves = 4;
+constexpr int kGsWaves = 8;
 
 // (a, b) of thole_amatrix (:2731-2757) from the squared image distance; r = 0 gives (0, 0): the reference's MAXVALUE guard times its
 // vanishing damping factors (:2704-2705)
@@ -52,20 +53,27 @@ __global__ __launch_bounds__(64) void k_gs_upper_sum(const double *__restrict__ 
 	}
 }
 
+// value of lane k (wave-uniform k) of a double: two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double gs_lane_value(double v, int k) {
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+	return __hiloint2double(hi, lo);
+}
+
 template <bool ORTHO>
 __global__ __launch_bounds__(64 * kGsWaves) void k_gs_stage(AtomsDev at, Box bx, double lambda, const double *__restrict__ e_static,
                                                            const double *__restrict__ U, double *__restrict__ L, int K, double *__restrict__ mu,
                                                            double *__restrict__ e_induced) {
 	__shared__ double4 s_pos[kTile];          // source tile (K - 1) in the push, then tile K itself in the solve
 	__shared__ double s_mu[3][kTile];
-	__shared__ double s_p[kGsWaves][3][kTile]; // partial sums of the four waves
-	__shared__ double2 s_T[kTile][kTile];      // workgroup 0: (a, b) of the in-tile pairs, [column][row]
+	__shared__ double s_p[kGsWaves][3][kTile]; // partial sums of the waves
+	__shared__ double2 s_T[kTile][kTile];      // workgroup 0: (a, b) of the in-tile pairs behind the diagonal, [column][row]; (0, 0) for column >= row
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int J = K + (int)blockIdx.x;
 	const int i = J * kTile + lane;
 	const double4 pi = at.xyzq[i];
+	constexpr int kShare = kTile / kGsWaves; // source atoms (push) / columns (solve) per wave
 	double low[3] = {0, 0, 0};
-	if (K > 0) { // L_J += T_{J, K-1} mu_{K-1}: lane = row atom, the four waves share the 64 source atoms
+	if (K > 0) { // L_J += T_{J, K-1} mu_{K-1}: lane = row atom, the waves share the 64 source atoms
 		if (w == 0) {
 			const int sg = (K - 1) * kTile + lane;
 			s_pos[lane] = at.xyzq[sg];
@@ -74,7 +82,8 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_stage(AtomsDev at, Box bx,
 		}
 		__syncthreads();
 		double f[3] = {0, 0, 0};
-		for (int jj = w * (kTile / kGsWaves); jj < (w + 1) * (kTile / kGsWaves); ++jj) {
+#pragma unroll 2
+		for (int jj = w * kShare; jj < (w + 1) * kShare; ++jj) {
 			const double4 pj = s_pos[jj];
 			double ox, oy, oz;
 			const double r2 = min_image_sq<ORTHO>(bx, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, ox, oy, oz);
@@ -89,15 +98,19 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_stage(AtomsDev at, Box bx,
 		__syncthreads();
 		if (w == 0)
 			for (int d = 0; d < 3; ++d) {
-				low[d] = L[3 * (size_t)i + d] + (((s_p[0][d][lane] + s_p[1][d][lane]) + s_p[2][d][lane]) + s_p[3][d][lane]);
+				double sum = s_p[0][d][lane];
+#pragma unroll
+				for (int v = 1; v < kGsWaves; ++v) sum += s_p[v][d][lane];
+				low[d] = L[3 * (size_t)i + d] + sum;
 				L[3 * (size_t)i + d] = low[d];
 			}
 	}
 	if (blockIdx.x != 0) return; // (every workgroup but the first has only pushed)
 	// ---- solve tile K ----------------------------------------------------------------------------------------------------------
 	__syncthreads(); // (the push has read s_pos / s_mu / s_p: about to be reused)
-	const double al = at.alpha[i];
-	const bool live = (i < at.n) && (al != 0.0) && !(at.mf[i].y & AF_PAD);
+	const double al_raw = at.alpha[i];
+	const bool live = (i < at.n) && (al_raw != 0.0) && !(at.mf[i].y & AF_PAD);
+	const double al = live ? al_raw : 0.0;
 	double m[3] = {0, 0, 0};
 	if (live)
 		for (int d = 0; d < 3; ++d) m[d] = mu[3 * (size_t)i + d]; // the previous sweep's dipole ("old")
@@ -106,16 +119,18 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_stage(AtomsDev at, Box bx,
 		for (int d = 0; d < 3; ++d) s_mu[d][lane] = m[d];
 	}
 	__syncthreads();
-	// in-tile tensors and the old-dipole part of every row: wave w takes the columns [16 w, 16 w + 16); column c contributes to row `lane`
-	// with the OLD dipole of c when c > lane
+	// in-tile tensors and the old-dipole part of every row: wave w takes the columns [kShare w, kShare (w + 1)); column c contributes to
+	// row `lane` with the OLD dipole of c when c > lane.  What the walk below reads -- columns behind the row's own atom, live rows only --
+	// goes to LDS; every other slot holds (0, 0), so that the walk needs neither a branch nor a mask.
 	{
 		double f[3] = {0, 0, 0};
-		for (int c = w * (kTile / kGsWaves); c < (w + 1) * (kTile / kGsWaves); ++c) {
+#pragma unroll 2
+		for (int c = w * kShare; c < (w + 1) * kShare; ++c) {
 			const double4 pc = s_pos[c];
 			double ox, oy, oz;
 			const double r2 = min_image_sq<ORTHO>(bx, pi.x - pc.x, pi.y - pc.y, pi.z - pc.z, ox, oy, oz);
 			const double2 t = (c == lane) ? make_double2(0.0, 0.0) : gs_thole_ab(r2, lambda);
-			s_T[c][lane] = t;
+			s_T[c][lane] = (c < lane && live) ? t : make_double2(0.0, 0.0);
 			if (c > lane) {
 				const double mx = s_mu[0][c], my = s_mu[1][c], mz = s_mu[2][c];
 				const double t3 = t.y * fma(oz, mz, fma(oy, my, ox * mx));
@@ -126,29 +141,54 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_stage(AtomsDev at, Box bx,
 		}
 		for (int d = 0; d < 3; ++d) s_p[w][d][lane] = f[d];
 	}
+	// Orthorhombic cell: when the whole tile lies within a quarter cell of its first atom (spatially sorted tiles do not, GS runs in
+	// atom order: molecules usually do), the minimum image of any in-tile pair is the plain difference of positions unwrapped around that
+	// atom, and the walk spends three subtractions on it instead of the image arithmetic.
+	double ux = pi.x, uy = pi.y, uz = pi.z;
+	bool compact = false;
+	if (ORTHO && w == 0) {
+		const double rx = gs_lane_value(pi.x, 0), ry = gs_lane_value(pi.y, 0), rz = gs_lane_value(pi.z, 0);
+		ux = pi.x - bx.b[0] * rint(bx.r[0] * (pi.x - rx));
+		uy = pi.y - bx.b[4] * rint(bx.r[4] * (pi.y - ry));
+		uz = pi.z - bx.b[8] * rint(bx.r[8] * (pi.z - rz));
+		const bool near = fabs(ux - rx) < 0.25 * fabs(bx.b[0]) && fabs(uy - ry) < 0.25 * fabs(bx.b[4]) && fabs(uz - rz) < 0.25 * fabs(bx.b[8]);
+		compact = !__any(live && !near); // (rows that are not live hold zeros in s_T: their displacement does not matter)
+	}
 	__syncthreads();
 	if (w != 0) return;
+	if (compact) s_pos[lane] = make_double4(ux, uy, uz, 0.0); // (one wave from here on: LDS operations of a wave complete in order)
 	// row = E-field pieces that are complete before the walk: tiles above (U), tiles below (L), in-tile atoms behind this one (old dipoles)
-	double row[3], eind[3] = {0, 0, 0};
-	for (int d = 0; d < 3; ++d)
-		row[d] = (U[3 * (size_t)i + d] + low[d]) + (((s_p[0][d][lane] + s_p[1][d][lane]) + s_p[2][d][lane]) + s_p[3][d][lane]);
-	const double e0[3] = {e_static[3 * (size_t)i], e_static[3 * (size_t)i + 1], e_static[3 * (size_t)i + 2]};
-#pragma unroll 4
-	for (int k = 0; k < kTile; ++k) {
-		// atom k closes its row (everything in front of it has been added) and takes its new dipole at once (:3586-3592) ...
-		if (lane == k && live) {
-			for (int d = 0; d < 3; ++d) {
-				eind[d] = row[d];
-				m[d] = al * (e0[d] + eind[d]);
-			}
-		}
-		// ... which every later atom of the tile sees: row_j -= T_jk mu_k
-		const double mkx = __shfl(m[0], k, 64), mky = __shfl(m[1], k, 64), mkz = __shfl(m[2], k, 64);
-		if (lane > k) {
+	double row[3], e0[3];
+	for (int d = 0; d < 3; ++d) {
+		double sum = s_p[0][d][lane];
+#pragma unroll
+		for (int v = 1; v < kGsWaves; ++v) sum += s_p[v][d][lane];
+		row[d] = live ? (U[3 * (size_t)i + d] + low[d]) + sum : 0.0;
+		e0[d] = live ? e_static[3 * (size_t)i + d] : 0.0;
+	}
+	// The walk (:3586-3592): atom k's row is complete when its turn comes (everything in front of it has been added), its new dipole
+	// alpha (E0 + row) goes to every later atom of the tile at once: row_j -= T_jk mu_k.  Rows at or in front of k read (0, 0) and stay as
+	// they are, so every lane can evaluate alpha (E0 + row) at every step and the value lane k holds is the one that counts.
+	if (compact) {
+#pragma unroll 8
+		for (int k = 0; k < kTile - 1; ++k) {
+			const double mkx = gs_lane_value(al * (e0[0] + row[0]), k), mky = gs_lane_value(al * (e0[1] + row[1]), k), mkz = gs_lane_value(al * (e0[2] + row[2]), k);
 			const double4 pk = s_pos[k];
+			const double2 t = s_T[k][lane];
+			const double ox = ux - pk.x, oy = uy - pk.y, oz = uz - pk.z;
+			const double t3 = t.y * fma(oz, mkz, fma(oy, mky, ox * mkx));
+			row[0] = fma(-t.x, mkx, fma(t3, ox, row[0]));
+			row[1] = fma(-t.x, mky, fma(t3, oy, row[1]));
+			row[2] = fma(-t.x, mkz, fma(t3, oz, row[2]));
+		}
+	} else {
+#pragma unroll 4
+		for (int k = 0; k < kTile - 1; ++k) {
+			const double mkx = gs_lane_value(al * (e0[0] + row[0]), k), mky = gs_lane_value(al * (e0[1] + row[1]), k), mkz = gs_lane_value(al * (e0[2] + row[2]), k);
+			const double4 pk = s_pos[k];
+			const double2 t = s_T[k][lane];
 			double ox, oy, oz;
 			(void)min_image_sq<ORTHO>(bx, pi.x - pk.x, pi.y - pk.y, pi.z - pk.z, ox, oy, oz);
-			const double2 t = s_T[k][lane];
 			const double t3 = t.y * fma(oz, mkz, fma(oy, mky, ox * mkx));
 			row[0] = fma(-t.x, mkx, fma(t3, ox, row[0]));
 			row[1] = fma(-t.x, mky, fma(t3, oy, row[1]));
@@ -156,8 +196,8 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_stage(AtomsDev at, Box bx,
 		}
 	}
 	for (int d = 0; d < 3; ++d) {
-		mu[3 * (size_t)i + d] = m[d];
-		e_induced[3 * (size_t)i + d] = eind[d];
+		mu[3 * (size_t)i + d] = al * (e0[d] + row[d]); // (0 for the slots that are not live)
+		e_induced[3 * (size_t)i + d] = row[d];
 	}
 }
 
