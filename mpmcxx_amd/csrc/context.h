@@ -173,6 +173,8 @@ struct mpmc_ctx {
 	double *d_e_recip_part = nullptr, *d_part = nullptr, *d_e_static = nullptr, *d_mu[2] = {nullptr, nullptr}, *d_e_induced = nullptr,
 	       *d_rrms = nullptr;
 	size_t cap_part = 0;
+	double2 *d_gs_blocks = nullptr; // Gauss-Seidel sweeps: the in-tile 3 x 3 blocks (k_gs_blocks), cap_gs_blocks double2 elements
+	size_t cap_gs_blocks = 0;
 	double *d_gs_ul = nullptr; // Gauss-Seidel sweeps (kernels_gs.hip): [2][max_pad][3] induced-field parts from the tiles above / below
 	int mu_cur = 0;
 	// dense A rows scratch

@@ -445,6 +445,17 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			HIP_TRY(c, hipMemsetAsync(ctl, 0, 3 * sizeof(int), st));
 			c->h_flag[2] = c->h_flag[3] = 0; // (nothing of an earlier solve can still be in flight: every evaluation is waited for)
 		}
+		if (o.polar_gs) { // the in-tile blocks of the sweeps: positions and polarizabilities only, once per evaluation
+			const size_t need = gs_block_store_elements(c->n_tiles);
+			if (need > c->cap_gs_blocks) {
+				dev_free(c, &c->d_gs_blocks, c->cap_gs_blocks);
+				c->cap_gs_blocks = 0;
+				if ((rc = dev_alloc(c, &c->d_gs_blocks, need)) != MPMC_OK) return rc;
+				c->cap_gs_blocks = need;
+			}
+			ProfScope p(c, MPMC_K_TENSOR);
+			launch_gs_blocks(st, at, c->box, o.polar_damp, c->d_gs_blocks);
+		}
 		int it = 0;
 		bool keep = true;
 		while (keep) {
@@ -461,7 +472,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				{
 					ProfScope p(c, MPMC_K_DIPOLE_ITER);
 					launch_gs_sweep(st, at, c->box, o.polar_damp, c->d_e_static, mu, c->d_e_induced, c->d_part, c->d_tile_pairs, c->d_cls,
-					                (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_gs_ul, c->d_gs_ul + 3 * (size_t)c->max_pad);
+					                (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_gs_ul, c->d_gs_ul + 3 * (size_t)c->max_pad, c->d_gs_blocks);
 				}
 				if (want_rrms) {
 					ProfScope p(c, MPMC_K_REDUCE);

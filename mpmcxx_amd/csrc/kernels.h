@@ -214,8 +214,11 @@ void launch_dense_matvec(hipStream_t st, const double *a, int n_pad, const doubl
 // ---- Gauss-Seidel sweeps (kernels_gs.hip): `polar_gs on`, identity atom order, matrix-free ---------------------------
 // one sweep over all tiles in atom order: mu is updated in place, e_induced receives each atom's induced field.  part: the slots of the
 // symmetric kernel [nt][n_pad][3]; U, L: [n_pad][3] (tiles above / below); tile_pairs, cls, tp_shift: this evaluation's tile-pair tables
+size_t gs_block_store_elements(int n_tiles); // double2 elements of the in-tile block store of the Gauss-Seidel sweeps
+void launch_gs_blocks(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, double2 *blocks);
 void launch_gs_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, const double *e_static, double *mu, double *e_induced,
-                     double *part, const int2 *tile_pairs, const int *cls, const double4 *tp_shift, int n_tile_pairs, double *U, double *L);
+                     double *part, const int2 *tile_pairs, const int *cls, const double4 *tp_shift, int n_tile_pairs, double *U, double *L,
+                     const double2 *blocks);
 void launch_gs_finish(hipStream_t st, const AtomsDev &at, const double *mu_old, const double *mu_new, int want_rrms, double *rrms_atom,
                       double allowed_sqerr, int *not_done_flag);
 
