@@ -264,12 +264,15 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	const double L[3] = {pick(bx.b[0], bx.b[4], bx.b[8], p0), pick(bx.b[0], bx.b[4], bx.b[8], p1), pick(bx.b[0], bx.b[4], bx.b[8], p2)};
 	const double iL[3] = {pick(bx.r[0], bx.r[4], bx.r[8], p0), pick(bx.r[0], bx.r[4], bx.r[8], p1), pick(bx.r[0], bx.r[4], bx.r[8], p2)};
 
+	// The permutation is applied by the ADDRESS of the loads (component p_d of an atom's record: a wave-uniform base, the lane's offset), not by
+	// selects on loaded values: the prologue of a wave is paid once per 16 steps.
+	const double *__restrict__ xyz = reinterpret_cast<const double *>(at.xyzq); // { x, y, z, q } per atom
+	const double *__restrict__ xp[3] = {xyz + p0, xyz + p1, xyz + p2}, *__restrict__ mp[3] = {mu + p0, mu + p1, mu + p2};
 	if (w == 0) { // j-tile into LDS, permuted, every value twice (slot l + s never wraps)
-		const double4 pj = at.xyzq[j0 + lane];
-		const double mx = mu[3 * (size_t)(j0 + lane)], my = mu[3 * (size_t)(j0 + lane) + 1], mz = mu[3 * (size_t)(j0 + lane) + 2];
-		const double2 xy = make_double2(pick(pj.x, pj.y, pj.z, p0), pick(pj.x, pj.y, pj.z, p1));
-		const double2 zm = make_double2(pick(pj.x, pj.y, pj.z, p2), pick(mx, my, mz, p0));
-		const double2 mm = make_double2(pick(mx, my, mz, p1), pick(mx, my, mz, p2));
+		const unsigned a4 = 4u * (unsigned)(j0 + lane), a3 = 3u * (unsigned)(j0 + lane);
+		const double2 xy = make_double2(xp[0][a4], xp[1][a4]);
+		const double2 zm = make_double2(xp[2][a4], mp[0][a3]);
+		const double2 mm = make_double2(mp[1][a3], mp[2][a3]);
 		s_xy[lane] = s_xy[lane + kTile] = xy;
 		s_zm[lane] = s_zm[lane + kTile] = zm;
 		s_mm[lane] = s_mm[lane + kTile] = mm;
@@ -282,17 +285,16 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	for (int k = 0; k < NI; ++k) {
 		const int I = tile_pairs[tps[k]].x;
 		Is[k] = I;
-		const int i = I * kTile + lane;
-		const double4 pi = at.xyzq[i];
+		const unsigned a4 = 4u * (unsigned)(I * kTile + lane), a3 = 3u * (unsigned)(I * kTile + lane);
+		// the i-atom moves by the tile pair's common lattice vector in the uniform dimensions (wave-uniform: scalar registers; x - 0.0 = x)
 		const double4 sh = tp_shift[tps[k]];
-		const double px = (um & 1) ? pi.x - sh.x : pi.x, py = (um & 2) ? pi.y - sh.y : pi.y, pz = (um & 4) ? pi.z - sh.z : pi.z;
-		q[k][0] = pick(px, py, pz, p0);
-		q[k][1] = pick(px, py, pz, p1);
-		q[k][2] = pick(px, py, pz, p2);
-		const double mx = mu[3 * (size_t)i], my = mu[3 * (size_t)i + 1], mz = mu[3 * (size_t)i + 2];
-		m[k][0] = pick(mx, my, mz, p0);
-		m[k][1] = pick(mx, my, mz, p1);
-		m[k][2] = pick(mx, my, mz, p2);
+		const double sx = (um & 1) ? sh.x : 0.0, sy = (um & 2) ? sh.y : 0.0, sz = (um & 4) ? sh.z : 0.0;
+		q[k][0] = xp[0][a4] - pick(sx, sy, sz, p0);
+		q[k][1] = xp[1][a4] - pick(sx, sy, sz, p1);
+		q[k][2] = xp[2][a4] - pick(sx, sy, sz, p2);
+		m[k][0] = mp[0][a3];
+		m[k][1] = mp[1][a3];
+		m[k][2] = mp[2][a3];
 		ab_tile[k] = (size_t)tps[k] * (kTile * kTile);
 	}
 	__syncthreads();
