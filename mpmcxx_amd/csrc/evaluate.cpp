@@ -385,7 +385,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		c->last_fp = fp;
 		c->last_fp_valid = !fp.store_only;
 		ProfScope p(c, MPMC_K_PAIR);
-		// the fast sweep (kernels_pair.hip) where it applies -- orthorhombic cell, Ewald electrostatics, alpha r_c inside its erfc table --
+		// the fast sweep (kernels_pair.hip) where it applies -- Ewald electrostatics, alpha r_c inside its erfc table --
 		// and, by default, where the table has more than kSweepMinPairs tile pairs (below that the 64 dependent steps of its one wave per
 		// tile pair are a latency chain: four waves per tile pair in k_pair_fused); the tile pairs with a special atom, which it skips,
 		// go through k_pair_fused on their list

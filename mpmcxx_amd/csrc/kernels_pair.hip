@@ -1,4 +1,4 @@
-// kernels_pair.hip -- the pair sweep of the production path (orthorhombic cells, Ewald electrostatics), rebuilt for VALU issue.
+// kernels_pair.hip -- the pair sweep of the production path (any cell, Ewald electrostatics), rebuilt for VALU issue.
 //
 // Same work as k_pair_fused (kernels_sym.hip): lj() (src/System.Energy.cpp:897-993), the erfc part of coulombic_real() (:1484-1510), the
 // real-space static field real_term() (:2900-2940, both atoms of a pair), the in-cutoff pair counts, and the Thole tensor store
@@ -46,7 +46,7 @@ struct SweepAcc {
 };
 
 // one step: lane l against j = slot jl of the (doubled) j-tile image
-template <int UM, bool FIELD, int MODE, bool PAD>
+template <int UM, bool FIELD, int MODE, bool PAD, bool TRI>
 __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zq, const double2 *__restrict__ s_se,
                                            const int2 *__restrict__ s_mf, const double2 *__restrict__ s_tab, const int jl, const int lane,
                                            const SweepI &I, const double shx, const double shy, const double shz, const Box &bx,
@@ -56,14 +56,20 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 	const double2 xy = s_xy[jl], zq = s_zq[jl];
 	const double dx = I.x - xy.x, dy = I.y - xy.y, dz = I.z - zq.x;
 	// minimum image (src/System.cpp:1228-1246), diagonal cell: d - B rint(R d); with a tile-pair-wide image index B rint(R d) is shx
-	double ox, oy, oz;
-	if (UM & 1) ox = dx - shx;
-	else ox = dx - bx.b[0] * rint(bx.r[0] * dx);
-	if (UM & 2) oy = dy - shy;
-	else oy = dy - bx.b[4] * rint(bx.r[4] * dy);
-	if (UM & 4) oz = dz - shz;
-	else oz = dz - bx.b[8] * rint(bx.r[8] * dz);
-	const double ri2 = ((ox * ox) + oy * oy) + oz * oz;
+	// general cell (TRI): the translation B^T img mixes the dimensions, so a tile pair has one image for all three (UM = 7, k_classify) or
+	// every pair takes the reference's full form rint(R d), B^T img
+	double ox, oy, oz, ri2;
+	if (TRI && UM == 0) {
+		ri2 = min_image_sq<false>(bx, dx, dy, dz, ox, oy, oz);
+	} else {
+		if (UM & 1) ox = dx - shx;
+		else ox = dx - bx.b[0] * rint(bx.r[0] * dx);
+		if (UM & 2) oy = dy - shy;
+		else oy = dy - bx.b[4] * rint(bx.r[4] * dy);
+		if (UM & 4) oz = dz - shz;
+		else oz = dz - bx.b[8] * rint(bx.r[8] * dz);
+		ri2 = ((ox * ox) + oy * oy) + oz * oz;
+	}
 	const double ir = fast_rsqrt_1(ri2);
 	const double r = ri2 * ir;
 	int2 mfj = make_int2(0, 0);
@@ -156,7 +162,7 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 	}
 }
 
-template <int UM, bool FIELD, int MODE, bool PAD>
+template <int UM, bool FIELD, int MODE, bool PAD, bool TRI = false>
 __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zq, const double2 *__restrict__ s_se,
                                         const int2 *__restrict__ s_mf, const double2 *__restrict__ s_tab, const int lane, const SweepI &I,
                                         const double shx, const double shy, const double shz, const Box &bx, const PairSweepParams &pp,
@@ -167,7 +173,7 @@ __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, con
 	for (int k = 0; k < n; ++k) {
 		const int s = s0 + k;
 		const bool last = (k == n - 1);
-		sweep_step<UM, FIELD, MODE, PAD>(s_xy, s_zq, s_se, s_mf, s_tab, lane + s, lane, I, shx, shy, shz, bx, pp, diag && last, i_real, store,
+		sweep_step<UM, FIELD, MODE, PAD, TRI>(s_xy, s_zq, s_se, s_mf, s_tab, lane + s, lane, I, shx, shy, shz, bx, pp, diag && last, i_real, store,
 		                                  ab_tile + s * kTile, A, n_lj, n_es);
 		if (FIELD && !last) {
 			A.gx = rot_from_next(A.gx);
@@ -264,7 +270,10 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 #define MPMC_SWEEP_UM(MODE)                                                        \
 	switch (um) {                                                                  \
 	case 0:                                                                        \
-		if (pad) sweep_walk<0, FIELD, MODE, true>(MPMC_SWEEP_ARGS);                \
+		if (!bx.ortho) {                                                           \
+			if (pad) sweep_walk<0, FIELD, MODE, true, true>(MPMC_SWEEP_ARGS);      \
+			else sweep_walk<0, FIELD, MODE, false, true>(MPMC_SWEEP_ARGS);         \
+		} else if (pad) sweep_walk<0, FIELD, MODE, true>(MPMC_SWEEP_ARGS);         \
 		else sweep_walk<0, FIELD, MODE, false>(MPMC_SWEEP_ARGS);                   \
 		break;                                                                     \
 	case 1: sweep_walk<1, FIELD, MODE, false>(MPMC_SWEEP_ARGS); break;             \
@@ -321,7 +330,7 @@ int pair_sweep_blocks(int n_tiles, int2 *out) {
 }
 
 bool pair_sweep_covers(const Box &bx, const FusedParams &fp, double ewald_alpha) {
-	if (!bx.ortho || !fp.do_es || fp.do_field == 2 || fp.wolf || fp.fh_order || fp.store_only) return false;
+	if (!fp.do_es || fp.do_field == 2 || fp.wolf || fp.fh_order || fp.store_only) return false;
 	if (fp.do_field == 1 && fp.polar_ewald_alpha != fp.ewald_alpha) return false;
 	const double tmax = (bx.t_lj > bx.t_es) ? bx.t_lj : bx.t_es;
 	return ewald_alpha * std::sqrt(tmax) * (1.0 + 1e-9) < MPMC_ERFTAB_XMAX; // every in-cutoff pair inside the table

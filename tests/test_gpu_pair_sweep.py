@@ -19,9 +19,10 @@ def force_sweep():
     energy.configure("pair_kernel", 0)
 
 
-# orthorhombic cells with Ewald electrostatics: the sweep's domain (ion216_alpha sets two different alphas: the generic kernel keeps it)
+# Ewald electrostatics in any cell: the sweep's domain (ion216_alpha sets two different alphas: the generic kernel keeps it); the skewed
+# cells take the reference's full image arithmetic per pair, or one common image per tile pair where k_classify found one
 SWEEP_FIXTURES = ["ion64_es", "ion216_polar", "ion216_frozen", "ion216_precision", "ion216_gamma", "water64_polar", "ion1000_polar",
-                  "ion216_framework"]
+                  "ion216_framework", "ion216_triclinic", "ion1000_triclinic"]
 
 
 @pytest.mark.parametrize("name", SWEEP_FIXTURES)
@@ -44,9 +45,9 @@ def test_sweep_matches_reference_golden(name, force_sweep):
     S.close()
 
 
-@pytest.mark.parametrize("name", ["ion216_alpha", "ion216_polar_nopbc", "ion216_triclinic", "ion216_wolf", "water64_fh2", "lj64"])
+@pytest.mark.parametrize("name", ["ion216_alpha", "ion216_polar_nopbc", "ion216_wolf", "water64_fh2", "lj64"])
 def test_outside_its_domain_the_generic_kernel_runs(name, force_sweep):
-    """two Ewald alphas, no-PBC field, triclinic cell, Wolf, Feynman-Hibbs, LJ only: not the sweep's -- and still the reference's numbers."""
+    """two Ewald alphas, no-PBC field, Wolf, Feynman-Hibbs, LJ only: not the sweep's -- and still the reference's numbers."""
     g = util.golden(name)
     atoms, basis, opts = util.load_fixture(name)
     S = energy.System(atoms, basis, opts)
@@ -56,7 +57,7 @@ def test_outside_its_domain_the_generic_kernel_runs(name, force_sweep):
     S.close()
 
 
-@pytest.mark.parametrize("name", ["ion1000_polar", "water64_polar", "ion216_framework"])
+@pytest.mark.parametrize("name", ["ion1000_polar", "water64_polar", "ion216_framework", "ion1000_triclinic"])
 def test_sweep_and_generic_kernel_agree_to_1e12(name):
     atoms, basis, opts = util.load_fixture(name)
     res = {}
