@@ -257,7 +257,8 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 	Ai.hs = 0.5 * li.x, Ai.e2 = 2.0 * li.y;
 	Ai.mol = mi.x;
 	Ai.fl = mi.y;
-	const int um = (pp.have_shift && !pad) ? ((cl / CLS_UNIFORM_X) & 7) : 0; // (the padded tile's pairs take the general image path: one variant)
+	int um = (pp.have_shift && !pad) ? ((cl / CLS_UNIFORM_X) & 7) : 0; // (the padded tile's pairs take the general image path: one variant)
+	if (!bx.ortho && um != 7) um = 0; // a skewed cell's translation mixes the components: one common image for all three indices, or the full form
 	double shx = 0.0, shy = 0.0, shz = 0.0; // B img of the tile pair's common image, per uniform dimension (wave-uniform: scalar loads)
 	if (pp.have_shift) {
 		const double4 sh = tp_shift[tp];

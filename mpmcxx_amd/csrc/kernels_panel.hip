@@ -19,8 +19,9 @@
 //
 // k_build_panels pairs up, for every j-tile J, the tile pairs (I < J, J) of equal class (then leftovers of equal far/stored kind, with
 // the intersection of their uniform masks); what stays single -- the diagonal tile pair and at most one odd leftover per kind -- runs
-// through the same walk with one member, in the same launch.  Triclinic cells: a tile pair is uniform in all three dimensions or in none
-// (the translation B^T img mixes them); the non-uniform ones walk with the full rint(R d) form (TRI).
+// through the same walk with one member, in the same launch.  Skewed cells: "dimension" = lattice direction; the i-atom is pre-shifted by the
+// lattice vectors of the directions with a common index (a whole vector: B^T img mixes the Cartesian components), the others cost the row of R,
+// rint and the lattice vector per pair (TRI, instantiated per mask for the far-field walk).
 // Every partial slot part[source tile][atom] is still written exactly once per iteration: F_k -> part[J][I_k atoms], the combined
 // G -> part[I_0][J atoms], zeros -> part[I_k][J atoms], k > 0.
 #include "kernels.h"
@@ -129,10 +130,20 @@ __device__ __forceinline__ void pan_step(const Box &bx, const double2 *__restric
 #pragma unroll
 	for (int k = 0; k < NI; ++k) {
 		double ox = q[k][0] - xj, oy = q[k][1] - yj, oz = q[k][2] - zj;
-		if (TRI) { // general cell without a tile-pair-wide image: the reference's rint(R d), B^T img (values only: nothing here is a predicate)
-			if (NU > 0) {
-				const double dx = ox, dy = oy, dz = oz;
-				(void)min_image_sq<false>(bx, dx, dy, dz, ox, oy, oz);
+		if (TRI) { // general cell: NU is the MASK of the lattice directions without a tile-pair-wide image index; each one costs the row of R,
+			// rint and the lattice vector (values only: nothing here is a predicate)
+			const double dx = ox, dy = oy, dz = oz;
+			if (NU & 1) {
+				const double n0 = rint(fma(bx.r[6], dz, fma(bx.r[3], dy, bx.r[0] * dx)));
+				ox = fma(-n0, bx.b[0], ox), oy = fma(-n0, bx.b[1], oy), oz = fma(-n0, bx.b[2], oz);
+			}
+			if (NU & 2) {
+				const double n1 = rint(fma(bx.r[7], dz, fma(bx.r[4], dy, bx.r[1] * dx)));
+				ox = fma(-n1, bx.b[3], ox), oy = fma(-n1, bx.b[4], oy), oz = fma(-n1, bx.b[5], oz);
+			}
+			if (NU & 4) {
+				const double n2 = rint(fma(bx.r[8], dz, fma(bx.r[5], dy, bx.r[2] * dx)));
+				ox = fma(-n2, bx.b[6], ox), oy = fma(-n2, bx.b[7], oy), oz = fma(-n2, bx.b[8], oz);
 			}
 		} else {
 			if (NU > 0) ox = fma(-L[0], rint(iL[0] * ox), ox);
@@ -252,7 +263,7 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	const int nonuni = (~um) & 7;
 	const int nu = __popc(nonuni);
 	unsigned packed = 0x24; // x y z
-	switch (nonuni) {
+	switch (bx.ortho ? nonuni : 7) { // (a skewed cell keeps its order: the walk is instantiated per mask there)
 	case 2: packed = 0x21; break; // y | x z
 	case 4: packed = 0x12; break; // z | x y
 	case 5: packed = 0x18; break; // x z | y
@@ -288,7 +299,10 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 		const unsigned a4 = 4u * (unsigned)(I * kTile + lane), a3 = 3u * (unsigned)(I * kTile + lane);
 		// the i-atom moves by the tile pair's common lattice vector in the uniform dimensions (wave-uniform: scalar registers; x - 0.0 = x)
 		const double4 sh = tp_shift[tps[k]];
-		const double sx = (um & 1) ? sh.x : 0.0, sy = (um & 2) ? sh.y : 0.0, sz = (um & 4) ? sh.z : 0.0;
+		// (skewed cell: the shift is the whole vector of THIS member's common directions -- zero where it has none; a direction common for the
+		// member but not for the panel is rounded per pair all the same and comes out as index 0)
+		const bool whole = !bx.ortho;
+		const double sx = (whole || (um & 1)) ? sh.x : 0.0, sy = (whole || (um & 2)) ? sh.y : 0.0, sz = (whole || (um & 4)) ? sh.z : 0.0;
 		q[k][0] = xp[0][a4] - pick(sx, sy, sz, p0);
 		q[k][1] = xp[1][a4] - pick(sx, sy, sz, p1);
 		q[k][2] = xp[2][a4] - pick(sx, sy, sz, p2);
@@ -303,10 +317,19 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	const int n_steps = (diag ? 32 : 64) / kPanelWaves, s_first = (diag ? 1 : 0) + w * n_steps;
 	PanAcc<NI> A = {};
 #define MPMC_PWALK(F, N) pan_walk<F, N, NI, PIPE, false>(bx, s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
-#define MPMC_PWALK_TRI(F) pan_walk<F, 3, NI, PIPE, true>(bx, s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
-	if (!bx.ortho && nu > 0) { // (a triclinic tile pair is uniform in all three dimensions or in none: k_classify)
-		if (far) MPMC_PWALK_TRI(true);
-		else MPMC_PWALK_TRI(false);
+#define MPMC_PWALK_TRI(F, M) pan_walk<F, M, NI, PIPE, true>(bx, s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
+	if (!bx.ortho && nu > 0) { // skewed cell: the far-field walk per mask of directions without a common index; the (few) stored ones take all three
+		if (far) {
+			switch (nonuni) {
+			case 1: MPMC_PWALK_TRI(true, 1); break;
+			case 2: MPMC_PWALK_TRI(true, 2); break;
+			case 3: MPMC_PWALK_TRI(true, 3); break;
+			case 4: MPMC_PWALK_TRI(true, 4); break;
+			case 5: MPMC_PWALK_TRI(true, 5); break;
+			case 6: MPMC_PWALK_TRI(true, 6); break;
+			default: MPMC_PWALK_TRI(true, 7); break;
+			}
+		} else MPMC_PWALK_TRI(false, 7);
 	} else if (far) {
 		switch (nu) {
 		case 0: MPMC_PWALK(true, 0); break;

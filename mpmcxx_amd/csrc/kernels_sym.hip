@@ -555,7 +555,8 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 		// evaluate (minimum_image, src/System.cpp:1228-1246, same association order) rounds to the same integer at the two extreme corners of
 		// the tiles' RAW coordinate ranges -- even a pair sitting exactly on the half-box tie gets the reference's image.
 		//   orthorhombic cell: per dimension (CLS_UNIFORM_X/Y/Z), shift component B_dd img_d;
-		//   any other cell: the translation B^T img mixes the dimensions, so all three indices must be uniform (all three bits or none), and
+		//   any other cell: bit p = the index along lattice vector p is common; the translation B^T img mixes the Cartesian components, so
+		//   the shift is a whole vector (the sum over the common directions), and
 		//   the test runs on the tiles' RAW FRACTIONAL ranges (a tile is compact in fractional coordinates; its Cartesian box is not):
 		//   the pair's own value of (R d)_p differs from the difference of the two atoms' fractional coordinates by rounding only, so a range
 		//   that stays 1e-9 clear of the half-integers on both sides has one image index (a pair ON a half-box tie is left to the general
@@ -577,17 +578,17 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 				sh[d] = bx.b[4 * d] * m0;
 			}
 		} else {
-			double img[3];
-			bool uni = ok;
-			for (int p = 0; p < 3; ++p) { // (lo, hi: extreme differences of the raw fractional coordinate p)
+			double img[3]; // (lo, hi: extreme differences of the raw fractional coordinate p)
+			for (int p = 0; p < 3; ++p) {
 				const double m0 = rint(lo[p]);
-				uni = uni && (lo[p] - m0 > -0.5 + 1e-9) && (hi[p] - m0 < 0.5 - 1e-9);
-				img[p] = m0;
+				const bool uni = ok && (lo[p] - m0 > -0.5 + 1e-9) && (hi[p] - m0 < 0.5 - 1e-9);
+				if (uni) c |= (CLS_UNIFORM_X << p);
+				img[p] = uni ? m0 : 0.0;
 			}
-			if (uni) {
-				c |= CLS_UNIFORM_X | CLS_UNIFORM_Y | CLS_UNIFORM_Z;
-				for (int p = 0; p < 3; ++p) sh[p] = ((bx.b[p] * img[0]) + bx.b[3 + p] * img[1]) + bx.b[6 + p] * img[2]; // B^T img, as the reference sums it
-			}
+			// B^T img over the lattice directions with a common index, summed as the reference sums it (x + 0.0 = x: with all three common
+			// this IS the reference's translation, which is what the pair sweep needs -- it uses a skewed tile pair's shift only then; the
+			// Jacobi walk, values only, takes the partial sums too and rounds the remaining indices per pair)
+			for (int p = 0; p < 3; ++p) sh[p] = ((bx.b[p] * img[0]) + bx.b[3 + p] * img[1]) + bx.b[6 + p] * img[2];
 		}
 		tp_shift[t] = make_double4(sh[0], sh[1], sh[2], 0.0);
 	}

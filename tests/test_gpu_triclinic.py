@@ -28,9 +28,10 @@ def test_8000_atom_triclinic_box_matches_reference_and_uses_the_classes(tmp_path
     # the classes are at work in this skewed cell: tile pairs beyond the damping range are not stored, the stored ones share one periodic image
     ps = S.pair_stats()
     assert ps["tile_pairs_far"] > 0.3 * ps["tile_pairs"], ps
-    # (3 non-uniform dimensions per pair = no common image.  In a skewed cell it is all three dimensions or none, which at 5 tiles per cell
-    # edge only neighbouring tiles reach -- the stored tile pairs; a far tile pair always straddles a half-cell boundary in some dimension)
+    # (3 non-uniform directions per pair = no common image index at all.  In a skewed cell a common index is per LATTICE direction; at 5 tiles
+    # per cell edge a far tile pair always straddles a half-cell boundary in some direction, but not in all three)
     assert ps["nonuniform_dims_x_pairs_stored"] < 3 * ps["pairs_stored"], ps
+    assert ps["nonuniform_dims_x_pairs_far"] < 2.5 * ps["pairs_far"], ps
     e_cls, mu_cls = r["energy"], mu.copy()
     S.close()
     # the same box with every tile pair "near" (all tensors stored, no image shortcut): same numbers to rounding
