@@ -246,7 +246,7 @@ __device__ __forceinline__ void pan_walk(const Box &bx, const double2 *__restric
 	}
 }
 
-template <int PIPE, int NI>
+template <int PIPE, int NI, bool ORTHO>
 __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
                                             const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab, double *__restrict__ part,
                                             double *__restrict__ gslot, const int tpA, const int tpB, const int flags, const int J,
@@ -263,7 +263,7 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	const int nonuni = (~um) & 7;
 	const int nu = __popc(nonuni);
 	unsigned packed = 0x24; // x y z
-	switch (bx.ortho ? nonuni : 7) { // (a skewed cell keeps its order: the walk is instantiated per mask there)
+	switch (ORTHO ? nonuni : 7) { // (a skewed cell keeps its order: the walk is instantiated per mask there)
 	case 2: packed = 0x21; break; // y | x z
 	case 4: packed = 0x12; break; // z | x y
 	case 5: packed = 0x18; break; // x z | y
@@ -301,7 +301,7 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 		const double4 sh = tp_shift[tps[k]];
 		// (skewed cell: the shift is the whole vector of THIS member's common directions -- zero where it has none; a direction common for the
 		// member but not for the panel is rounded per pair all the same and comes out as index 0)
-		const bool whole = !bx.ortho;
+		const bool whole = !ORTHO;
 		const double sx = (whole || (um & 1)) ? sh.x : 0.0, sy = (whole || (um & 2)) ? sh.y : 0.0, sz = (whole || (um & 4)) ? sh.z : 0.0;
 		q[k][0] = xp[0][a4] - pick(sx, sy, sz, p0);
 		q[k][1] = xp[1][a4] - pick(sx, sy, sz, p1);
@@ -318,7 +318,7 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	PanAcc<NI> A = {};
 #define MPMC_PWALK(F, N) pan_walk<F, N, NI, PIPE, false>(bx, s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
 #define MPMC_PWALK_TRI(F, M) pan_walk<F, M, NI, PIPE, true>(bx, s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
-	if (!bx.ortho && nu > 0) { // skewed cell: the far-field walk per mask of directions without a common index; the (few) stored ones take all three
+	if (!ORTHO && nu > 0) { // skewed cell: the far-field walk per mask of directions without a common index; the (few) stored ones take all three
 		if (far) {
 			switch (nonuni) {
 			case 1: MPMC_PWALK_TRI(true, 1); break;
@@ -330,6 +330,9 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 			default: MPMC_PWALK_TRI(true, 7); break;
 			}
 		} else MPMC_PWALK_TRI(false, 7);
+	} else if (!ORTHO) { // (every direction has a common index: plain differences of the pre-shifted positions)
+		if (far) MPMC_PWALK(true, 0);
+		else MPMC_PWALK(false, 0);
 	} else if (far) {
 		switch (nu) {
 		case 0: MPMC_PWALK(true, 0); break;
@@ -388,7 +391,9 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	gslot[3 * lane + p2] = g[2];
 }
 
-template <int PIPE>
+// (two instantiations: the orthorhombic one reads three diagonal elements of the cell and its inverse, which keeps most of the Box out of
+// its scalar registers; the other holds the walks of skewed cells)
+template <int PIPE, bool ORTHO>
 __global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev at, Box bx, const double *__restrict__ mu,
                                                                         const int2 *__restrict__ tile_pairs, const double4 *__restrict__ tp_shift,
                                                                         const int4 *__restrict__ panels, const double2 *__restrict__ ab,
@@ -412,8 +417,8 @@ __global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev
 		if (trace && threadIdx.x == 0) trace[4 * (size_t)blockIdx.x + 1] = 0; // no work: the reader drops entries whose end stamp is 0
 		return;
 	}
-	if (tpB >= 0) panel_block<PIPE, 2>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
-	else panel_block<PIPE, 1>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
+	if (tpB >= 0) panel_block<PIPE, 2, ORTHO>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
+	else panel_block<PIPE, 1, ORTHO>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
 	if (trace && threadIdx.x == 0) { // (wave 0 is the last one to leave a workgroup: it folds the partial sums)
 		long long *o = trace + 4 * (size_t)blockIdx.x;
 		o[0] = t_start;
@@ -520,7 +525,8 @@ void launch_dipole_iter_panel(hipStream_t st, const AtomsDev &at, const Box &bx,
                               const int *converged, long long *trace, int replicas) {
 	if (n_entries <= 0) return;
 	dim3 grid(n_entries, replicas > 1 ? replicas : 1), block(kTile * kPanelWaves); // (replicas: measurement only -- the same work blockIdx.y times)
-	hipLaunchKernelGGL((k_dipole_iter_panel<4>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace);
+	if (bx.ortho) hipLaunchKernelGGL((k_dipole_iter_panel<4, true>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace);
+	else hipLaunchKernelGGL((k_dipole_iter_panel<4, false>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace);
 }
 
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,
