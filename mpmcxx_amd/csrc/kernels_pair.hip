@@ -184,7 +184,9 @@ __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, con
 }
 
 // blocks: { J, I0 } -- the workgroup's waves take the tile pairs (I0 + w, J), w = 0..3, as far as I0 + w <= J
-template <bool FIELD, bool INTRA>
+// (ORTHO: the orthorhombic instantiation reads the diagonals of the cell and its inverse only, which keeps the rest of the Box out of its
+// scalar registers -- spilled SGPRs are v_writelane / v_readlane on the VALU)
+template <bool FIELD, bool INTRA, bool ORTHO>
 __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Box bx, PairSweepParams pp, const int2 *__restrict__ blocks,
                                                                  const int *__restrict__ cls, const double4 *__restrict__ tp_shift,
                                                                  const double2 *__restrict__ erf_tab, double *__restrict__ block_part,
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 	Ai.mol = mi.x;
 	Ai.fl = mi.y;
 	int um = (pp.have_shift && !pad) ? ((cl / CLS_UNIFORM_X) & 7) : 0; // (the padded tile's pairs take the general image path: one variant)
-	if (!bx.ortho && um != 7) um = 0; // a skewed cell's translation mixes the components: one common image for all three indices, or the full form
+	if (!ORTHO && um != 7) um = 0; // a skewed cell's translation mixes the components: one common image for all three indices, or the full form
 	double shx = 0.0, shy = 0.0, shz = 0.0; // B img of the tile pair's common image, per uniform dimension (wave-uniform: scalar loads)
 	if (pp.have_shift) {
 		const double4 sh = tp_shift[tp];
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 #define MPMC_SWEEP_UM(MODE)                                                        \
 	switch (um) {                                                                  \
 	case 0:                                                                        \
-		if (!bx.ortho) {                                                           \
+		if (!ORTHO) {                                                              \
 			if (pad) sweep_walk<0, FIELD, MODE, true, true>(MPMC_SWEEP_ARGS);      \
 			else sweep_walk<0, FIELD, MODE, false, true>(MPMC_SWEEP_ARGS);         \
 		} else if (pad) sweep_walk<0, FIELD, MODE, true>(MPMC_SWEEP_ARGS);         \
@@ -347,7 +349,11 @@ void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const 
 	pp.nt = at.n_pad / kTile;
 	pp.have_shift = tp_shift ? 1 : 0;
 	dim3 grid(n_blocks), block(64 * kSweepWaves);
-#define MPMC_PS(F, N) hipLaunchKernelGGL((k_pair_sweep<F, N>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab)
+#define MPMC_PS(F, N)                                                                                                                                 \
+	do {                                                                                                                                          \
+		if (bx.ortho) hipLaunchKernelGGL((k_pair_sweep<F, N, true>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab); \
+		else hipLaunchKernelGGL((k_pair_sweep<F, N, false>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab);     \
+	} while (0)
 	if (fp.do_field == 1) {
 		if (intra) MPMC_PS(true, true);
 		else MPMC_PS(true, false);
