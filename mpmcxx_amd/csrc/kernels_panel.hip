@@ -368,12 +368,20 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	const int nt_pad3 = at.n_pad * 3;
 	double g[3];
 #pragma unroll
-	for (int d = 0; d < 3; ++d) g[d] = ((s_G[0][d][lane] + s_G[1][d][lane]) + s_G[2][d][lane]) + s_G[3][d][lane];
+	for (int d = 0; d < 3; ++d) {
+		g[d] = s_G[0][d][lane];
+#pragma unroll
+		for (int v = 1; v < kPanelWaves; ++v) g[d] += s_G[v][d][lane];
+	}
 #pragma unroll
 	for (int k = 0; k < NI; ++k) {
 		double f[3];
 #pragma unroll
-		for (int d = 0; d < 3; ++d) f[d] = ((s_F[0][k][d][lane] + s_F[1][k][d][lane]) + s_F[2][k][d][lane]) + s_F[3][k][d][lane];
+		for (int d = 0; d < 3; ++d) {
+			f[d] = s_F[0][k][d][lane];
+#pragma unroll
+			for (int v = 1; v < kPanelWaves; ++v) f[d] += s_F[v][k][d][lane];
+		}
 		if (NI == 1 && diag) { // both sides are the same 64 atoms: one slot [J][J atoms] = F + G, nothing on the j-side
 #pragma unroll
 			for (int d = 0; d < 3; ++d) {
