@@ -18,9 +18,18 @@ Extra objects on the JSON line:
                   duration that rocprofv3 --kernel-trace reports for a serial run (profiles/).  The duration the same kernel shows
                   INSIDE the timed region (beads overlap on 32 streams, so it is stretched by the neighbours) is kept under
                   "in_timed_region".  `consistent` = avg_launch_ms x launches per step <= ms_per_step.
+  other_configs -- BASELINE configs[1..3] on this GPU, measured in a short pass after the timed region (one system at a time and 32 jittered
+                  copies in flight), each with the fp64 roofline entry of its pair kernel.
   cpu_baseline -- ONE evaluation of bead 0 of the same ensemble on one core of this host: by the reference's own object code (kind
                   "reference", oracle/_ref/ref_harness, the default wherever that binary was built) or by the C port of the oracle
                   (kind "port"); `parity_rel_err` = |E_gpu(bead 0) - E_cpu(bead 0)| / |E_cpu|.
+
+Launching.  `python3 bench.py --gpus N` runs by itself: when no launcher's environment is present (WORLD_SIZE unset) and N > 1, this
+process -- before it imports torch or touches HIP -- starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+(never an exec), i.e. N fresh ranks, one per GPU, and relays rank 0's JSON line and the exit code.  Under a launcher (the driver's
+`python -m torch.distributed.run ... bench.py --gpus N`) it is one of the ranks.  `--launch inprocess` keeps ONE process that drives the N
+devices through mpmc_pi_allreduce (bead b on device b mod N, one host thread per device, ncclCommInitAll communicator) -- the shape of the
+reference's OpenMP build (PathIntegral.cpp:772-779).
 """
 from __future__ import annotations
 
@@ -146,8 +155,103 @@ def cpu_baseline(kind: str, atoms, basis, opts, workdir: str, gpu_bead0):
     return out
 
 
+def other_configs(headline_beads, headline_value, local_rank: int, workdir: str):
+    """BASELINE configs[1..3] on this GPU, measured right behind the timed region of the headline: one system
+    evaluated back to back ("alone": what System::mc sees, MonteCarlo.cpp:47) and 32 copies with jittered positions in flight
+    (energy.pi_potential_local), plus the fp64 roofline entry of the configuration's pair kernel (back-to-back launches between one pair
+    of HIP events on the kernel's stream).  A couple of seconds in all; tools/config_rates.py is the same loop with more repetitions."""
+    from mpmcxx_amd import energy, gen_box, pqr
+
+    out = []
+    for label, name in (("configs[1]: 1 000-atom LJ box (rd_only), 1 GPU", "lj1000"), ("configs[2]: 10 000-atom LJ + Ewald box (kmax 7), 1 GPU", "ion10k_es"),
+                        ("configs[3]: 10 000-atom LJ + Ewald + Thole box (10 Jacobi iterations), 1 GPU", "ion10k_polar")):
+        inp, _ = gen_box.materialize(name, workdir)
+        atoms, basis, opts = pqr.load_case(inp)
+        S = energy.System(atoms, basis, opts, device=local_rank)
+        e = S.energy()
+        S.energy()
+        reps = 400 if name == "lj1000" else (60 if name == "ion10k_es" else 15)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            S.energy()
+        alone = (time.perf_counter() - t0) / reps
+        r = S.observables
+        entry = {"workload": label, "energy_K": e, "evals_per_s_alone": 1.0 / alone, "ms_per_eval_alone": alone * 1e3, "reps_alone": reps}
+        roof = None
+        if name == "lj1000":
+            # the whole evaluation is ONE launch (k_pair_fused<TAIL>: no classes, every pair takes the full minimum image); its duration is
+            # the evaluation's wall time -- dispatch, 64-step latency chain and the polled result included: a latency regime, not a roofline one
+            npairs = atoms["pos"].shape[0] * (atoms["pos"].shape[0] - 1) // 2
+            fl = (FLOP_SWEEP_BASE + 3 * FLOP_SWEEP_PER_NU) * npairs + 10.0 * float(r["n_lj_in_cutoff"])
+            roof = {"kernel": "k_pair_fused<TAIL> (single launch)", "algorithmic_flops": fl, "avg_launch_ms": alone * 1e3,
+                    "clock": "wall time of the evaluation (one launch + dispatch + the host's poll of the posted result)", "pairs": npairs,
+                    "pairs_in_cutoff": int(r["n_lj_in_cutoff"])}
+        else:
+            ps = S.pair_stats()
+            try:
+                ms = S.time_kernel("pair", 30)
+                cut = float(r["n_es_in_cutoff"])
+                polar = name == "ion10k_polar"
+                fl = (FLOP_SWEEP_BASE * ps["pairs_swept"] + FLOP_SWEEP_PER_NU * ps["nonuniform_dims_x_pairs_swept"]
+                      + (FLOP_SWEEP_CUTOFF if polar else FLOP_SWEEP_CUTOFF - 20.0) * cut + (FLOP_SWEEP_STORE * ps["pairs_stored"] if polar else 0.0))
+                roof = {"kernel": "k_pair_sweep" if S.last_pair_kernel() == "sweep" else "k_pair_fused", "algorithmic_flops": fl, "avg_launch_ms": ms,
+                        "clock": "30 launches back to back between ONE pair of HIP events on the kernel's stream (kernel alone on the GPU)",
+                        "pairs": ps["pairs"], "pairs_in_cutoff": int(cut)}
+            except energy.MpmcError:
+                roof = None
+        if roof:
+            ach = roof["algorithmic_flops"] / (roof["avg_launch_ms"] * 1e-3) / 1e12
+            roof.update({"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS})
+        entry["roofline"] = roof
+        S.close()
+        if name == "ion10k_polar" and headline_beads >= 32 and headline_value:
+            entry["evals_per_s_in_flight"] = headline_value  # the headline IS this configuration with 32 beads in flight
+            entry["in_flight"] = "the headline value of this line (32 bead-displaced copies of this box)"
+        else:
+            copies = []
+            for b in range(32):
+                a = dict(atoms)
+                a["pos"] = atoms["pos"] + np.random.default_rng([17, b]).normal(scale=0.05, size=atoms["pos"].shape)
+                copies.append(energy.System(a, basis, opts, device=local_rank))
+            energy.pi_potential_local(copies)
+            steps = 20 if name == "lj1000" else (6 if name == "ion10k_es" else 2)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                energy.pi_potential_local(copies)
+            many = (time.perf_counter() - t0) / (steps * 32)
+            for c in copies:
+                c.close()
+            entry["evals_per_s_in_flight"] = 1.0 / many
+            entry["in_flight"] = f"32 copies with jittered positions, all enqueued before the first wait ({steps} steps)"
+        out.append(entry)
+    return out
+
+
+def self_launch(args) -> int:
+    """`python3 bench.py --gpus N` started bare: N fresh ranks as CHILD processes of this one (which has not imported torch and has not
+    touched HIP, and never replaces itself).  The ranks inherit stdout, so rank 0's JSON line is this command's JSON line; the exit
+    code is the launcher's (non-zero if any rank failed).  The reference is started as one command too (`mpmcxx -P n input.in`,
+    src/args_etc.h:216-293)."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC between the ranks of one node (see main())
+    env["MPMC_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench.py] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=os.getcwd())
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--launch", choices=["ranks", "inprocess"], default="ranks",
+                    help="ranks: one process per GPU (started by this command itself when no launcher did); inprocess: ONE process drives the "
+                         "--gpus devices through mpmc_pi_allreduce (one host thread per device, ncclCommInitAll)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -162,8 +266,10 @@ def main():
     ap.add_argument("--combine-impl", choices=["cabi", "torch"], default="cabi",
                     help="cabi: ncclAllGather inside libmpmc_energy.so (mpmc_pi_gather_beads; falls back to torch if RCCL cannot be initialised "
                          "below Python, recorded in config.combine_impl); torch: torch.distributed")
-    ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="diagnostic: leave the per-kernel HIP events off in the timed region")
+    ap.add_argument("--events-in-timed-region", action="store_true",
+                    help="diagnostic (rounds 1-3 behaviour): per-launch HIP events on one bead's stream INSIDE the timed region; by default the timed "
+                         "region carries no instrumentation and the in-flight kernel durations come from a separate short pass behind it")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs[1..3] pass (other_configs)")
     ap.add_argument("--no-extra-passes", action="store_true", help="diagnostic: skip the isolated-kernel and PCIe-inclusive passes after the timed region")
     ap.add_argument("--host-positions", action="store_true",
                     help="re-upload every bead's positions from host buffers inside each timed step (the PCIe-inclusive rate; the default run "
@@ -177,6 +283,10 @@ def main():
     ap.add_argument("--configure", action="append", default=[], metavar="KEY=VALUE",
                     help="measurement switch for every context of this run (mpmc_debug_configure, e.g. side_stream=0 pair_kernel=1); repeatable")
     args = ap.parse_args()
+
+    inprocess = args.launch == "inprocess" and args.gpus > 1
+    if args.gpus > 1 and not inprocess and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # (before torch / HIP: the parent only starts the ranks and relays their exit code)
 
     # RCCL and CUDA-tensor sharing between the processes of one node go through dmabuf IPC on this pool: the host driver does not support
     # the legacy IPC mode, and without this variable the first multi-process collective fails with "hipIpcGetMemHandle: invalid argument".
@@ -194,14 +304,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if inprocess:
+        if world != 1:
+            raise SystemExit("--launch inprocess is ONE process: start it without a launcher")
+    elif world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the energy path has no CPU fallback)")
     if args.force_device is not None:
         local_rank = args.force_device
+    # devices this process drives: its own (one rank per GPU) or all of them (--launch inprocess: bead b on devices[b mod N])
+    n_dev = args.gpus if inprocess else 1
+    devices = [local_rank] * n_dev if (not inprocess or args.force_device is not None) else list(range(n_dev))
+    if inprocess and max(devices) >= energy.device_count():
+        raise SystemExit(f"--launch inprocess --gpus {args.gpus}: only {energy.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
@@ -252,11 +368,12 @@ def main():
             combine_impl = "libmpmc_energy.so: mpmc_pi_gather_beads (ncclAllGather, communicator from mpmc_comm_init_rank)"
 
     P = args.beads
-    if P % world:
+    n_gpus = world * n_dev
+    if P % n_gpus:
         raise SystemExit("--beads must be a multiple of --gpus")
     rehearsal = int(args.beads_per_gpu_rehearsal)
     if rehearsal:
-        if world != 1:
+        if n_gpus != 1:
             raise SystemExit("--beads-per-gpu-rehearsal is a one-GPU run")
         P = rehearsal
     workdir = tempfile.mkdtemp(prefix="mpmc_bench_")
@@ -267,10 +384,10 @@ def main():
 
     mine = pi.beads_of_rank(P, rank, world)
     beads = []
-    for b in mine:
+    for k, b in enumerate(mine):
         a = dict(atoms)
         a["pos"] = bead_positions(atoms["pos"], b)
-        beads.append(energy.System(a, basis, opts, device=local_rank))
+        beads.append(energy.System(a, basis, opts, device=devices[k % n_dev]))
 
     host_pos = [np.ascontiguousarray(bead_positions(atoms["pos"], b)) for b in mine]
     state = {"host_positions": bool(args.host_positions), "per": None}
@@ -293,14 +410,27 @@ def main():
 
     coll_dev = dev if args.dist_backend == "nccl" else "cpu"
 
-    def step():
-        return pi.pi_calculate_potential(local_eval, P, rank, world, mode=args.combine, device=coll_dev, comm=comm)
+    if inprocess:
+        if args.host_positions or args.concurrency != "async":
+            raise SystemExit("--launch inprocess runs the default step only (resident positions, all beads enqueued before the first wait)")
+        combine_impl = "libmpmc_energy.so: mpmc_pi_allreduce (one host thread per device, ncclAllGather on an ncclCommInitAll communicator)"
+
+        def step():
+            # SimulationControl::PI_calculate_potential in ONE call of the C ABI: evaluation on every device, per-bead values gathered over
+            # RCCL, the reference's ordered sum s = 0..P-1 (PathIntegral.cpp:786-801), then / P (mpmc_pi_finish)
+            sums, per, failed = energy.pi_allreduce(beads)
+            state["per"] = per
+            return energy.pi_finish(sums, P)
+    else:
+        def step():
+            return pi.pi_calculate_potential(local_eval, P, rank, world, mode=args.combine, device=coll_dev, comm=comm)
 
     def fence():
-        torch.cuda.synchronize()
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def timed(k):
         fence()
@@ -315,17 +445,6 @@ def main():
             d = float(t.item())
         return d, vv, oo
 
-    for _ in range(args.warmup):
-        v, obs = step()
-    # per-kernel HIP events on ONE bead's stream only: an event pair around every launch costs that stream about 5 us of back-to-back
-    # dispatch (measured: 8 % of the whole-job rate when all 32 beads carry them, 14 % with one bead at a time), so the other
-    # beads run uninstrumented and the instrumented one supplies the launch durations of the timed region
-    for k, s in enumerate(beads):
-        s.set_profiling((k == 0) and not args.no_kernel_timing)
-        s.timings(reset=True)
-    dt, v, obs = timed(args.steps)
-    gpu_bead0 = dict(state["per"][0]) if (rank == 0 and state["per"]) else None
-
     def collect(systems):
         agg = {}
         for s in systems:
@@ -335,7 +454,23 @@ def main():
                 a["launches"] += tv["launches"]
         return agg
 
-    agg = collect(beads)  # per-kernel device time from HIP events over the timed region (instrumented bead)
+    for _ in range(args.warmup):
+        v, obs = step()
+    # The timed region carries NO instrumentation (round 4): per-launch HIP events cost the stream that carries them about 5 us of
+    # back-to-back dispatch per launch, and with few beads in flight the instrumented bead is the tail of every step.
+    events_in_region = bool(args.events_in_timed_region)
+    for k, s in enumerate(beads):
+        s.set_profiling(events_in_region and k == 0)
+        s.timings(reset=True)
+    dt, v, obs = timed(args.steps)
+    gpu_bead0 = dict(state["per"][0]) if (rank == 0 and state["per"]) else None
+    if not events_in_region and not args.no_extra_passes:
+        # what the kernels look like with the other beads in flight: a SEPARATE short pass behind the timed region, events on bead 0's stream
+        beads[0].set_profiling(True)
+        for _ in range(2):
+            step()
+        fence()
+    agg = collect(beads)  # per-kernel device time from HIP events with all local beads in flight (instrumented bead)
     for s in beads:
         s.set_profiling(False)
     iters = int(beads[0].observables.get("polar_iterations", 0)) if beads else 0
@@ -344,7 +479,7 @@ def main():
 
     # ---- PCIe-inclusive rate: the same step with every bead's positions handed over in host memory (short extra pass, all ranks) ----
     pcie = None
-    if not args.no_extra_passes and not args.host_positions and world == 1:  # (multi-rank runs report the headline only: no extra collectives)
+    if not args.no_extra_passes and not args.host_positions and n_gpus == 1:  # (multi-rank runs report the headline only: no extra collectives)
         state["host_positions"] = True
         step()
         k_pcie = max(2, min(args.steps, 5))
@@ -359,7 +494,7 @@ def main():
     iso = None
     back_to_back = {}  # kernel class -> ms per launch, 100 launches back to back between ONE pair of HIP events
     pairs = beads[0].pair_stats() if beads else {}
-    if rank == 0 and not args.no_extra_passes and world == 1:  # (with several ranks nobody is kept waiting in a barrier: in-region durations only)
+    if rank == 0 and not args.no_extra_passes and n_gpus == 1:  # (with several ranks nobody is kept waiting in a barrier: in-region durations only)
         energy.configure("side_stream", 0)  # one stream: every kernel alone on the GPU
         try:
             a = dict(atoms)
@@ -386,13 +521,18 @@ def main():
     if world > 1:
         dist.barrier()
 
+    others = None
+    if rank == 0 and n_gpus == 1 and not args.no_extra_passes and not args.no_other_configs and not rehearsal and args.natoms == 10000:
+        others = other_configs(P, P * args.steps / dt, local_rank, workdir)
+
     try:  # per-launch PMC figures of the committed profiling passes (rocprofv3 cannot run inside this process): HBM bytes, executed flops
         pmc = {}
-        for rnd in ("r01", "r02", "r03"):
+        for rnd in ("r01", "r02", "r03", "r04"):
             pth = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
             if os.path.exists(pth):
                 with open(pth) as f:
-                    pmc.update(json.load(f))
+                    for kname, rec in json.load(f).items():
+                        pmc[kname] = dict(rec, source=f"profiles/{rnd}_traffic.json (committed rocprofv3 --pmc passes of the builder, NOT counters of this run)")
     except (OSError, ValueError):
         pmc = {}
     K = 709 if int(opts.get("ewald_kmax", 7)) == 7 else None
@@ -434,6 +574,9 @@ def main():
             t = pmc.get(kernel)
             if t and t.get("natoms") == n:
                 e["traffic"] = t.get("hbm_bytes_per_launch")
+                e["traffic_source"] = t.get("source")
+                e["replayed_from_committed_pmc_pass"] = ["traffic", "pmc", "frac_by_trace_clock", "frac_executed", "algorithmic_flops_per_valu_slot",
+                                                         "ceiling_frac_of_this_instruction_stream"]
                 e["pmc"] = t
                 if t.get("trace_avg_launch_ms"):
                     e["frac_by_trace_clock"] = flops / (t["trace_avg_launch_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
@@ -480,11 +623,13 @@ def main():
                                                                         "pair counts are exact atom pairs per tile-pair class (mpmc_debug_pair_stats)"}
         roof["share_of_device_time_alone"] = share[dom] / max(sum((src.get(k) or 0.0) * (iters if k in ("dipole_iter", "reduce") else 1) for k in src), 1e-30)
         # whole-step view, which overlap cannot distort: algorithmic flops of one evaluation x evaluations per second per GPU
-        roof["whole_step"] = {"algorithmic_flops_per_eval": flops_eval, "achieved": flops_eval * value / world / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": flops_eval * value / world / 1e12 / FP64_VALU_PEAK_TFLOPS,
+        roof["whole_step"] = {"algorithmic_flops_per_eval": flops_eval, "achieved": flops_eval * value / n_gpus / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": flops_eval * value / n_gpus / 1e12 / FP64_VALU_PEAK_TFLOPS,
                               "what": "pair sweep + iterations x Jacobi contraction + reciprocal space, x evaluations/s per GPU"}
         # secondary: the same kernels inside the timed region (other beads' kernels share the GPU) and the other big kernel
         roof["in_timed_region"] = {"kernel_ms": in_region,
+                                   "measured": ("INSIDE the timed region (--events-in-timed-region)" if events_in_region else
+                                                "in a separate 2-step pass BEHIND the timed region (the timed region carries no events)"),
                                    "note": f"{args.concurrency}: {n_local} beads in flight on this GPU, HIP events on one bead's stream; a launch here "
                                            "shares the CUs with other beads' kernels, so its duration is stretched -- not a kernel time"}
         other = {}
@@ -500,14 +645,17 @@ def main():
 
         out = {
             "metric": "energy-evals/sec (10k-atom LJ+Ewald+polar box); 1/2/4/8-GPU scaling",
-            "value": value, "unit": "energy-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "energy-evals/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{P}-bead path-integral ensemble of the {n}-atom polarizable box (BASELINE configs[3] x configs[4]): "
                                    f"LJ+LRC, Ewald kmax {opts['ewald_kmax']}, Thole exponential damping, {iters} Jacobi iterations, polar_ewald",
-                       "natoms": n, "beads": P, "beads_per_gpu": P // world, "polar_solver": solver_used, "combine": args.combine,
-                       "parallelism": f"beads sharded round-robin over {world} GPU(s); one {'all_gather' if args.combine == 'gather' else 'all_reduce'} of 4 fp64 per bead per step",
+                       "natoms": n, "beads": P, "beads_per_gpu": P // n_gpus, "polar_solver": solver_used, "combine": args.combine,
+                       "parallelism": f"beads sharded round-robin over {n_gpus} GPU(s); one {'all_gather' if args.combine == 'gather' else 'all_reduce'} of 4 fp64 per bead per step",
                        "dist_backend": (args.dist_backend if world > 1 else "none (one rank)"), "world_size": world, "combine_impl": combine_impl,
+                       "launch": ("inprocess: one process, one host thread per device" if inprocess else
+                                  ("ranks started by bench.py itself (child torch.distributed.run)" if os.environ.get("MPMC_BENCH_SELF_LAUNCHED") else
+                                   ("ranks started by an external launcher" if world > 1 else "one process"))),
                        "rccl_version": rccl_ver, "configure": args.configure},
             "V_mean_K": v, "obs_rd_es_pol_vdw": [float(x) for x in obs],
             "kernel_ms": in_region,
@@ -518,6 +666,9 @@ def main():
             out["config"]["rehearsal"] = (f"{rehearsal} beads in flight on ONE GPU: the per-GPU load of a {args.beads // rehearsal}-GPU run of the "
                                           f"{args.beads}-bead ensemble, without the 4-double collective; value x {args.beads // rehearsal} is what that "
                                           "run can reach at most.  NOT the headline workload")
+        out["instrumented_in_timed_region"] = events_in_region
+        if others is not None:
+            out["other_configs"] = others
         if pcie is not None:
             out["pcie_inclusive_value"] = pcie["value"]
             out["pcie_inclusive"] = pcie
@@ -527,13 +678,18 @@ def main():
     my_info = {"rank": rank, "local_rank": local_rank, "device": dev, "device_name": torch.cuda.get_device_name(local_rank), "pid": os.getpid(),
                "beads": mine, "comm_n_ranks": (comm.n_ranks if comm is not None else None)}
     infos = [my_info]
+    if inprocess:  # one process: one entry per device it drove; the communicator is the library's own (ncclCommInitAll inside mpmc_pi_allreduce)
+        n_devs_seen, comm_size = energy.pi_allreduce_info(beads)
+        infos = [{"rank": g, "local_rank": d, "device": f"cuda:{d}", "device_name": torch.cuda.get_device_name(d), "pid": os.getpid(),
+                  "beads": [b for k, b in enumerate(mine) if k % n_dev == g], "comm_n_ranks": comm_size, "distinct_devices": n_devs_seen}
+                 for g, d in enumerate(devices)]
     if world > 1:
         infos = [None] * world
         dist.all_gather_object(infos, my_info)
     if rank == 0:
         out["config"]["ranks"] = infos
         cpu = None
-        if world == 1 and args.cpu_baseline != "none":
+        if n_gpus == 1 and args.cpu_baseline != "none":
             cpu = cpu_baseline(args.cpu_baseline, {**atoms, "pos": bead_positions(atoms["pos"], 0)}, basis, opts, workdir, gpu_bead0)
         if cpu is not None:
             out["cpu_baseline"] = cpu

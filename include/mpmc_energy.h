@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MPMC_ABI_VERSION 4
+#define MPMC_ABI_VERSION 5
 
 /* ---- status codes -------------------------------------------------------------------------------------- */
 #define MPMC_OK 0
@@ -270,6 +270,9 @@ int mpmc_pi_gather_beads(mpmc_comm *comm, const double *local, int n_local, int 
  * process-wide ncclCommInitAll communicator of the devices involved, and returns the UN-normalised ordered sums over beads 0..n-1
  * (identical on every device: an all-reduce with a fixed summation order).  mpmc_pi_finish divides by P. */
 int mpmc_pi_allreduce(mpmc_ctx **beads, int n_beads, double sums4[4], mpmc_result *per_bead, int *any_iterator_failed);
+/* (ABI 5) what mpmc_pi_allreduce uses for these beads: the number of distinct devices they live on and the size of the process-wide
+ * communicator of those devices (0 before the first mpmc_pi_allreduce on them) -- a host program's proof that RCCL saw G ranks. */
+int mpmc_pi_allreduce_info(mpmc_ctx **beads, int n_beads, int *n_devices, int *comm_n_ranks);
 
 /* ---- Gibbs ensemble: the two boxes of SimulationControl::Gibbs_mc -------------------------------------------------------
  * Reference: final_energy[0] = systems[0]->energy(); final_energy[1] = systems[1]->energy(); (src/SimulationControl.Gibbs.cpp:179-180),

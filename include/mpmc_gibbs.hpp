@@ -311,12 +311,29 @@ private:
 	// waited for, results taken in box order.  The reference's pairs() refreshes every Molecule::com on the way (update_com, src/System.cpp:1347-1378).
 	void evaluate_both(double e[2]) {
 		energy_calls += 2;
-		systems[0]->energy_async();
-		systems[1]->energy_async();
-		for (int i = 0; i < 2; i++) {
-			e[i] = systems[i]->energy_wait();
-			com[i].resize(n_molecules(i));
-			for (int m = 0; m < n_molecules(i); m++) update_COM(i, m, com[i][m]);
+		// a throw between the first enqueue and the last wait must not leave a box with an evaluation in flight: the next move would
+		// change that box's cell or atoms under it.  Whatever was enqueued and not yet waited for is drained before the throw travels on.
+		bool in_flight[2] = {false, false};
+		try {
+			for (int i = 0; i < 2; i++) {
+				systems[i]->energy_async();
+				in_flight[i] = true;
+			}
+			for (int i = 0; i < 2; i++) {
+				in_flight[i] = false; // (energy_wait closes the evaluation whether it returns or throws)
+				e[i] = systems[i]->energy_wait();
+				com[i].resize(n_molecules(i));
+				for (int m = 0; m < n_molecules(i); m++) update_COM(i, m, com[i][m]);
+			}
+		} catch (...) {
+			for (int i = 0; i < 2; i++)
+				if (in_flight[i]) {
+					try {
+						(void)systems[i]->energy_wait();
+					} catch (...) {
+					}
+				}
+			throw;
 		}
 	}
 

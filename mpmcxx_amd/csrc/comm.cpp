@@ -13,7 +13,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -315,25 +318,71 @@ extern "C" int mpmc_pi_gather_beads(mpmc_comm *cm, const double *local, int n_lo
 }
 
 // ---- one process, G devices: PI_calculate_potential end to end --------------------------------------------------------------------
-// process-wide communicators of mpmc_pi_allreduce, one per set of devices
+// One host thread per device, kept for the life of the process (the reference's OpenMP team, PathIntegral.cpp:772-779): creating and
+// joining G threads inside every step would put ~0.1-0.2 ms of thread start-up in front of a 4 ms step at G = 8.
+namespace {
+struct DevWorker {
+	std::thread th;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::function<void()> job;
+	bool busy = false, stop = false;
+	void loop() {
+		std::unique_lock<std::mutex> lk(mu);
+		for (;;) {
+			cv.wait(lk, [this] { return busy || stop; });
+			if (stop) return;
+			lk.unlock();
+			job();
+			lk.lock();
+			busy = false;
+			cv.notify_all();
+		}
+	}
+	void post(std::function<void()> f) {
+		std::lock_guard<std::mutex> lk(mu);
+		job = std::move(f);
+		busy = true;
+		cv.notify_all();
+	}
+	void wait() {
+		std::unique_lock<std::mutex> lk(mu);
+		cv.wait(lk, [this] { return !busy; });
+	}
+};
+// the process-wide communicator of one set of devices and the host threads that serve devices 1 .. G-1 (device 0: the caller's thread)
+struct AutoGroup {
+	mpmc_comm *cm = nullptr;
+	std::vector<std::unique_ptr<DevWorker>> workers;
+	std::mutex step_mu; // one PI step at a time per set of devices
+};
+} // namespace
 static std::mutex g_auto_mu;
-static std::map<std::vector<int>, mpmc_comm *> g_auto_comms;
+static std::map<std::vector<int>, std::unique_ptr<AutoGroup>> g_auto_groups;
 // A communicator that is still alive when the process ends takes RCCL's own teardown down with it (seen: "double free or corruption" at
 // interpreter exit).  The handler is registered when the first one is made -- after RCCL was loaded, so it runs BEFORE RCCL's and HIP's
 // static destructors.
 static void destroy_auto_comms() {
 	std::lock_guard<std::mutex> lk(g_auto_mu);
-	for (auto &kv : g_auto_comms) mpmc_comm_destroy(kv.second);
-	g_auto_comms.clear();
+	for (auto &kv : g_auto_groups) {
+		for (auto &w : kv.second->workers) {
+			{
+				std::lock_guard<std::mutex> wl(w->mu);
+				w->stop = true;
+				w->cv.notify_all();
+			}
+			if (w->th.joinable()) w->th.join();
+		}
+		mpmc_comm_destroy(kv.second->cm);
+	}
+	g_auto_groups.clear();
 }
 
-extern "C" int mpmc_pi_allreduce(mpmc_ctx **beads, int n_beads, double sums4[4], mpmc_result *per_bead, int *any_failed) {
-	if (!beads || n_beads <= 0 || !sums4) return MPMC_ERR_ARG;
-	for (int b = 0; b < n_beads; b++)
-		if (!beads[b]) return MPMC_ERR_ARG;
-	// the devices the beads live on, in order of first appearance; rank g of the communicator = g-th device
-	std::vector<int> devs, dev_of(n_beads), slot_of(n_beads);
-	std::vector<std::vector<int>> members;
+// devices of the beads in order of first appearance (rank g of the communicator = g-th device) and every bead's place
+static void group_beads(mpmc_ctx **beads, int n_beads, std::vector<int> &devs, std::vector<int> &dev_of, std::vector<int> &slot_of,
+                        std::vector<std::vector<int>> &members) {
+	dev_of.assign(n_beads, 0);
+	slot_of.assign(n_beads, 0);
 	for (int b = 0; b < n_beads; b++) {
 		int g = 0;
 		for (; g < (int)devs.size(); g++)
@@ -346,20 +395,57 @@ extern "C" int mpmc_pi_allreduce(mpmc_ctx **beads, int n_beads, double sums4[4],
 		slot_of[b] = (int)members[g].size();
 		members[g].push_back(b);
 	}
+}
+
+// size of the process-wide communicator mpmc_pi_allreduce uses for these beads (0: none made yet), and how many devices they are on
+extern "C" int mpmc_pi_allreduce_info(mpmc_ctx **beads, int n_beads, int *n_devices, int *comm_n_ranks) {
+	if (!beads || n_beads <= 0) return MPMC_ERR_ARG;
+	for (int b = 0; b < n_beads; b++)
+		if (!beads[b]) return MPMC_ERR_ARG;
+	std::vector<int> devs, dev_of, slot_of;
+	std::vector<std::vector<int>> members;
+	group_beads(beads, n_beads, devs, dev_of, slot_of, members);
+	if (n_devices) *n_devices = (int)devs.size();
+	if (comm_n_ranks) {
+		std::lock_guard<std::mutex> lk(g_auto_mu);
+		auto it = g_auto_groups.find(devs);
+		*comm_n_ranks = it == g_auto_groups.end() ? 0 : it->second->cm->n_ranks;
+	}
+	return MPMC_OK;
+}
+
+extern "C" int mpmc_pi_allreduce(mpmc_ctx **beads, int n_beads, double sums4[4], mpmc_result *per_bead, int *any_failed) {
+	if (!beads || n_beads <= 0 || !sums4) return MPMC_ERR_ARG;
+	for (int b = 0; b < n_beads; b++)
+		if (!beads[b]) return MPMC_ERR_ARG;
+	std::vector<int> devs, dev_of, slot_of;
+	std::vector<std::vector<int>> members;
+	group_beads(beads, n_beads, devs, dev_of, slot_of, members);
 	const int G = (int)devs.size();
-	mpmc_comm *cm = nullptr;
+	AutoGroup *grp = nullptr;
 	{
 		std::lock_guard<std::mutex> lk(g_auto_mu);
-		auto it = g_auto_comms.find(devs);
-		if (it == g_auto_comms.end()) {
+		auto it = g_auto_groups.find(devs);
+		if (it == g_auto_groups.end()) {
+			mpmc_comm *cm = nullptr;
 			int rc = mpmc_comm_init_all(&cm, G, devs.data());
 			if (rc != MPMC_OK) return fail(beads[0], rc, "mpmc_pi_allreduce: " + g_comm_error);
-			if (g_auto_comms.empty()) std::atexit(destroy_auto_comms);
-			g_auto_comms[devs] = cm;
+			if (g_auto_groups.empty()) std::atexit(destroy_auto_comms);
+			std::unique_ptr<AutoGroup> ng(new AutoGroup);
+			ng->cm = cm;
+			for (int g = 1; g < G; g++) {
+				ng->workers.emplace_back(new DevWorker);
+				DevWorker *w = ng->workers.back().get();
+				w->th = std::thread([w] { w->loop(); });
+			}
+			grp = ng.get();
+			g_auto_groups[devs] = std::move(ng);
 		} else {
-			cm = it->second;
+			grp = it->second.get();
 		}
 	}
+	mpmc_comm *cm = grp->cm;
+	std::lock_guard<std::mutex> step_lk(grp->step_mu);
 	// evaluate: one host thread per device enqueues that device's beads (all before the first wait) and waits for them --
 	// the reference's "#pragma omp parallel for" over the beads (PathIntegral.cpp:772-779), folded to one thread per GPU
 	std::vector<mpmc_result> res(n_beads);
@@ -373,13 +459,9 @@ extern "C" int mpmc_pi_allreduce(mpmc_ctx **beads, int n_beads, double sums4[4],
 		rcs[g] = mpmc_pi_potential_local(mine.data(), (int)mine.size(), s4, r.data(), &failed);
 		for (size_t k = 0; k < mine.size(); k++) res[members[g][k]] = r[k];
 	};
-	if (G == 1) {
-		work(0);
-	} else {
-		std::vector<std::thread> th;
-		for (int g = 0; g < G; g++) th.emplace_back(work, g);
-		for (auto &t : th) t.join();
-	}
+	for (int g = 1; g < G; g++) grp->workers[g - 1]->post([&work, g] { work(g); });
+	work(0);
+	for (int g = 1; g < G; g++) grp->workers[g - 1]->wait();
 	for (int g = 0; g < G; g++)
 		if (rcs[g] != MPMC_OK) return rcs[g];
 	// combine: every device contributes {rd, coulombic, polarization, vdw, iterator_failed} of its beads, padded to the largest share
@@ -400,8 +482,7 @@ extern "C" int mpmc_pi_allreduce(mpmc_ctx **beads, int n_beads, double sums4[4],
 	std::vector<double *> all(G, nullptr);
 	for (int g = 0; g < G; g++) loc[g] = send[g].data();
 	all[0] = gathered.data(); // every device receives the same bytes; the host reads them from the first
-	{
-		std::lock_guard<std::mutex> lk(g_auto_mu); // one collective at a time on a shared communicator
+	{ // (step_mu: one collective at a time on a shared communicator)
 		int rc = allgather_members(cm, loc, per * kStride, all);
 		if (rc != MPMC_OK) return fail(beads[0], rc, "mpmc_pi_allreduce: " + cm->err);
 	}

@@ -93,9 +93,9 @@ static double bisect_threshold(double rc, Pred pred) {
 
 // per-device result of the lane-rotation self-test (0 unknown, 1 ok): every symmetric kernel rotates its j-side accumulators with
 // v_mov_b32_dpp wave_rol:1; a device on which that does not deliver lane (l + 1) & 63 cannot run this library
-static int g_rot_ok[64] = {0};
+static std::atomic<int> g_rot_ok[64];
 static int rot_selftest(mpmc_ctx *c) {
-	if (c->device < 64 && g_rot_ok[c->device]) return MPMC_OK;
+	if (c->device < 64 && g_rot_ok[c->device].load(std::memory_order_acquire)) return MPMC_OK;
 	int *d = nullptr, h[64];
 	HIP_TRY(c, hipMalloc((void **)&d, 64 * sizeof(int)));
 	launch_rot_selftest(c->stream, d);
@@ -108,11 +108,12 @@ static int rot_selftest(mpmc_ctx *c) {
 			c->err = "lane-rotation self-test failed (v_mov_b32_dpp wave_rol:1): not a gfx950 device?";
 			return MPMC_ERR_INTERNAL;
 		}
-	if (c->device < 64) g_rot_ok[c->device] = 1;
+	if (c->device < 64) g_rot_ok[c->device].store(1, std::memory_order_release);
 	return MPMC_OK;
 }
 
 static mpmc_tuning g_tuning_default; // what contexts created from now on start from (mpmc_debug_configure with a null context)
+static std::mutex g_tuning_mu;       // ... written by mpmc_debug_configure(NULL, ...) and copied by mpmc_ctx_create on any thread
 
 // ---- lifetime --------------------------------------------------------------------------------------------
 extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
@@ -140,7 +141,10 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 		delete c;
 		return fail(nullptr, MPMC_ERR_HIP, "mpmc_ctx_create: hipStreamCreate failed");
 	}
-	c->tune = g_tuning_default;
+	{
+		std::lock_guard<std::mutex> lk(g_tuning_mu);
+		c->tune = g_tuning_default;
+	}
 	c->two_streams = (c->tune.stream_mode != 0);
 	const size_t P = (size_t)c->max_pad;
 	A(dev_alloc(c, &c->d_atoms_blob, P * kAtomRecordBytes)); // every per-atom array, one block (layout: atom_block_layout)
@@ -456,7 +460,7 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 	}
 	{ // tile pairs with an atom whose flags change lj_mix (sigma < 0, dispersion coefficients) are the generic pair kernel's (the sweep masks
 	  // everything else itself): their list, in tile-pair order
-		constexpr int kSpecial = AF_HAS_DISP | AF_NEG_SIGMA;
+		constexpr int kSpecial = kAtomFlagsMixing; // (pair_math.h: the same constant the sweep skips tile pairs by)
 		const int nt = c->n_tiles;
 		std::vector<char> special((size_t)nt, 0);
 		bool any = false;
@@ -477,6 +481,7 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 				c->cap_generic = (size_t)c->n_tile_pairs;
 			}
 			HIP_TRY(c, hipMemcpyAsync(c->d_generic_list, c->h_generic.data(), (size_t)c->n_generic * sizeof(int), hipMemcpyHostToDevice, c->stream));
+			HIP_TRY(c, hipStreamSynchronize(c->stream)); // pageable source that the next upload clears: wait, as the tile-pair and block tables do
 		}
 	}
 	// ONE copy: the device block has the layout of the staging block (the tails beyond n_pad travel along; nobody reads them)
@@ -839,6 +844,8 @@ extern "C" int mpmc_debug_pair_stats(mpmc_ctx *c, int64_t out[12]) {
 //   single_launch     recip_table     spatial_sort     order_carry     polar_delta     inline_move     trace_panel     tensor_budget_mb N
 extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) {
 	if (!key) return MPMC_ERR_ARG;
+	std::unique_lock<std::mutex> tuning_lk(g_tuning_mu, std::defer_lock);
+	if (!c) tuning_lk.lock();
 	mpmc_tuning &t = c ? c->tune : g_tuning_default;
 	const std::string k(key);
 	const int v = (int)value;
@@ -852,6 +859,10 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 	} else if (k == "pair_waves") {
 		if (v != 0 && v != 1 && v != 4) return MPMC_ERR_ARG;
 		t.pair_waves = v;
+	} else if (k == "fast_geometry") t.fast_geometry = on;
+	else if (k == "pair_split") {
+		if (v < -1 || v > 1) return MPMC_ERR_ARG;
+		t.pair_split = v;
 	} else if (k == "panels") t.use_panels = on;
 	else if (k == "uniform_images") t.no_uniform = !on;
 	else if (k == "tile_classes") t.no_classes = !on;

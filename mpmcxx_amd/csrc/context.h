@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +36,8 @@ struct mpmc_tuning {
 	int stream_mode = -1;   // "side_stream": -1 by table size (kOneStreamMaxPairs), 0 never fork the side stream, 1 always
 	int pair_kernel = 0;    // "pair_kernel": 0 the fast sweep (kernels_pair.hip) where it applies and the table is large, 1 never, 2 wherever it applies
 	int pair_waves = 0;     // "pair_waves": waves per tile pair of k_pair_fused, 0 by table size (kPairSplitMax), 1 | 4
+	bool fast_geometry = true; // "fast_geometry": fused minimum image in the pair sweep, the reference's form only inside a 1e-9 band around the cutoff (0: everywhere)
+	int pair_split = -1;    // "pair_split": two waves per tile pair in the fast sweep (half-length workgroups): -1 by default rule, 0 | 1
 	bool use_panels = true; // "panels": panel form of the Jacobi contraction (orthorhombic cells, stored tensors); 0: one tile pair per workgroup
 	bool no_uniform = false;   // "uniform_images" = 0: no tile-pair-wide periodic images
 	bool no_classes = false;   // "tile_classes" = 0: every tile pair is "near" (nothing skipped, every tensor stored)
@@ -98,7 +101,7 @@ struct mpmc_ctx {
 	int n_panel_entries = 0, seg_tiles = -1; // entries of the table / the tile count its layout was made for
 	bool panels_built = false;       // this evaluation's classes carry CLS_GROUPED bits and d_panels is valid
 	// the fast pair sweep (kernels_pair.hip): its erfc table, its work table { J, I0 } (depends on the tile count only) and the list of
-	// tile pairs it leaves to k_pair_fused (a tile with a frozen / chargeless / sigma- or epsilon-less atom: rebuilt with every upload)
+	// tile pairs it leaves to k_pair_fused (a tile with a kAtomFlagsMixing atom -- sigma < 0 or dispersion coefficients: rebuilt with every upload)
 	double2 *d_erf_tab = nullptr;
 	int2 *d_sweep_blocks = nullptr;
 	size_t cap_sweep_blocks = 0;

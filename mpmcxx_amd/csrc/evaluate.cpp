@@ -233,9 +233,14 @@ void mpmc::ext_params(const mpmc_ctx *c, FusedParams &fp, bool wolf_on) {
 	fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
 }
 
+// two waves per tile pair in the fast pair sweep (half-length workgroups): the default
+static inline bool sweep_split(const mpmc_ctx *c) { return c->tune.pair_split < 0 ? kSweepSplitDefault : c->tune.pair_split != 0; }
+
 // which pieces of energy() to run
 
 int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
+	// one evaluation per context at a time: a second enqueue would overwrite the scalar block and the result slots under the first
+	if (c->pending) return fail(c, MPMC_ERR_ARG, "an evaluation of this context is still in flight (mpmc_energy_wait first)");
 	// stale position-independent terms ride along with this evaluation (an insertion / removal makes them stale every time)
 	int rc = prepare(c, true);
 	if (rc != MPMC_OK) return rc;
@@ -395,7 +400,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		if (sweep) {
 			launch_pair_sweep(st, at, c->box, fp, c->n_molecules != c->n, c->d_sweep_blocks, c->n_sweep_blocks, c->d_cls,
 			                  (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->d_erf_tab, c->d_block_part, c->d_block_cnt, c->d_part,
-			                  compact ? c->d_ab : nullptr);
+			                  compact ? c->d_ab : nullptr, sweep_split(c), c->tune.fast_geometry);
 			if (c->n_generic > 0)
 				launch_pair_fused(st, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_generic, c->d_block_part, c->d_block_cnt, c->d_part,
 				                  compact ? c->d_ab : nullptr, c->d_generic_list);
@@ -612,7 +617,7 @@ extern "C" int mpmc_debug_time_pair(mpmc_ctx *c, int reps, double *ms_per_launch
 		if (c->last_pair_was_sweep) {
 			launch_pair_sweep(c->stream, at, c->box, fp, c->n_molecules != c->n, c->d_sweep_blocks, c->n_sweep_blocks, c->d_cls,
 			                  (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->d_erf_tab, c->d_block_part, c->d_block_cnt, c->d_part,
-			                  compact ? c->d_ab : nullptr);
+			                  compact ? c->d_ab : nullptr, sweep_split(c), c->tune.fast_geometry);
 			if (c->n_generic > 0)
 				launch_pair_fused(c->stream, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_generic, c->d_block_part, c->d_block_cnt, c->d_part,
 				                  compact ? c->d_ab : nullptr, c->d_generic_list);

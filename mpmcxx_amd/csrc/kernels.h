@@ -44,11 +44,11 @@ enum : int {
 	S_COUNT = 16
 };
 enum : int { C_LJ_IN = 0, C_ES_IN, C_INTRA, C_RDX, C_ESX, C_FROZEN, C_COUNT = 8 };
-// tile-pair classes written by k_classify (orthorhombic cells; 0 otherwise): lower bound of the minimum-image
-// distance between the two tiles' bounding boxes
+// tile-pair classes written by k_classify (any cell: DESIGN section 3 has the bound used for skewed cells): lower bound of the
+// minimum-image distance between the two tiles' bounding boxes
 enum : int {
 	CLS_BEYOND_CUTOFF = 1, // > cutoff: no pair of the tile pair passes any cutoff predicate
-	CLS_THOLE_FAR = 2,     // lambda*r > 40 for every pair: exponential damping is below 1e-13, T is the bare dipole tensor
+	CLS_THOLE_FAR = 2,     // lambda*r > kTholeFarX for every pair: T is the bare dipole tensor (see below for what that drops)
 	CLS_UNIFORM_X = 4,     // per dimension (x, y, z = 4, 8, 16): one periodic image index serves all 4096 pairs of the tile pair in
 	CLS_UNIFORM_Y = 8,     // that dimension (wrapped coordinates); tp_shift holds the lattice vector component B img
 	CLS_UNIFORM_Z = 16
@@ -142,30 +142,36 @@ constexpr int kPairSplitMax = 8192;
 void launch_pair_fused(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, const int2 *tile_pairs,
                        const int *cls, int n_tile_pairs, double *block_part /*[ntp][2]*/, int *block_cnt /*[ntp][2]*/, double *fpart, double2 *ab,
                        const int *tp_list = nullptr);
-// ---- the fast pair sweep (kernels_pair.hip): orthorhombic cells, Ewald electrostatics, tile pairs of "plain" atoms ----
+// ---- the fast pair sweep (kernels_pair.hip): any cell, Ewald electrostatics with alpha r_c inside the erfc table; every tile pair
+// except those with an atom that changes lj_mix (kAtomFlagsMixing: sigma < 0, dispersion coefficients) ----
 struct PairSweepParams {
 	double ewald_alpha, polar_damp, thole_far_x;
 	int store;      // write the Thole tensor store
 	int nt;         // tiles
 	int have_shift; // tp_shift / CLS_UNIFORM_* are valid
+	int split;      // two waves per tile pair (half the steps each), two tile pairs per workgroup
+	int fast;       // fused geometry with the tile pair's band around the cutoff thresholds (tp_shift.w); 0: the reference's form everywhere
 };
 // Tables with more tile pairs than this take the sweep by default.  Measured (profiles/r03_sweep_sizes.txt), k_pair_fused (four waves per
 // tile pair up to kPairSplitMax) against the sweep: one evaluation at a time +2 % at 3000 atoms (1128 tile pairs), -3 % at 5000 (3160),
 // -5 % at 7000, -9 % at 10 000; 32 beads in flight the sweep wins from 3000 atoms on (+4 % evaluations/s, +4.5 % at 5000, +9 % at 7000).
 constexpr int kSweepMinPairs = 2048;
+// two waves per tile pair (half the steps each; kernels_pair.hip): measured in round 4, see DESIGN section 3
+constexpr bool kSweepSplitDefault = true;
 // host: the device layout of the erfc table, 3 * 512 double2 = (c0,c1)[512], (c2,c3)[512], (c4,G)[512]  (erfc_table.cpp)
 constexpr int kErfTableDouble2 = 3 * 512;
 void erfc_table_device_layout(double2 *out /*[kErfTableDouble2]*/);
 // work table of the sweep: one workgroup per entry { J, I0 }, its four waves take the tile pairs (I0 .. I0+3, J); returns the
 // number of entries (out may be null: count only)
 int pair_sweep_blocks(int n_tiles, int2 *out);
-// whether the sweep can serve this evaluation (cell, switches, alpha r_c inside the erfc table); tile pairs with a special atom
-// (frozen, chargeless, sigma / epsilon zero or negative, dispersion coefficients) are skipped by it and must go through
-// launch_pair_fused with their list
+// whether the sweep can serve this evaluation (switches, alpha r_c inside the erfc table).  Frozen, chargeless, sigma- or epsilon-less
+// atoms are masked by the sweep itself (its MODE 2); only tile pairs with a kAtomFlagsMixing atom are skipped by it and must go
+// through launch_pair_fused with their list (context.cpp builds it with the same constant)
 bool pair_sweep_covers(const Box &bx, const FusedParams &fp, double ewald_alpha);
 void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, bool intra /*some molecule has more than one atom*/,
                        const int2 *blocks, int n_blocks, const int *cls, const double4 *tp_shift /*null: no uniform images*/,
-                       const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab);
+                       const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab, bool split = false,
+                       bool fast_geometry = false);
 void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt);
 // LJ (+ counts) of a small system in ONE launch: no tile classes, the last-arriving block folds the partials and writes the scalar
 // vector [S_COUNT doubles][C_COUNT int64][seq] into pinned host memory (seq last: a host polling that slot finds the results
@@ -184,13 +190,13 @@ void launch_tile_classes(hipStream_t st, const AtomsDev &at, const Box &bx, cons
                          double *tile_bounds /*[nt][12]*/, int *cls, double4 *tp_shift /*[ntp], may be null*/,
                          const double origin_f[3] /*fractional origin of the spatial sort: where the periodic wrap is cut*/,
                          double thole_far_x = kTholeFarX /*lambda r beyond which a tile pair is CLS_THOLE_FAR*/);
-// one Jacobi contraction over all tile pairs (class read per block): part[nt][n_pad][3].  Triclinic cells and the matrix-free solver;
-// orthorhombic cells with a tensor store take the panel form below
+// one Jacobi contraction over all tile pairs (class read per block): part[nt][n_pad][3].  The matrix-free solver (and panels = 0);
+// evaluations with a tensor store take the panel form below, in any cell
 void launch_dipole_iter_hybrid(hipStream_t st, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                                const int *cls, const double4 *tp_shift /*null: no uniform-image fast path*/, int n_tile_pairs,
                                const double2 *ab /*null: matrix-free, tensors inside the damping range rebuilt from the positions*/,
                                double *part, double polar_damp, const int *converged = nullptr);
-// ---- panel form of the contraction (kernels_panel.hip; orthorhombic cells): two tile pairs that share their j-tile per wave ----
+// ---- panel form of the contraction (kernels_panel.hip; any cell): two tile pairs that share their j-tile per workgroup ----
 int panel_segment_entries(int J); // entries the work table reserves for j-tile J; seg[J] = their running sum
 // the work table of the panel kernel: per j-tile its diagonal tile pair, panels of two tile pairs of equal class, odd singles
 void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg /*[n_tiles + 1]*/, int4 *panels);

@@ -30,13 +30,14 @@ namespace mpmc {
 
 constexpr int kSweepWaves = 4;
 constexpr int kSpecialAtom = AF_FROZEN | AF_NULL_RD | AF_HAS_DISP | AF_NEG_SIGMA | AF_ZERO_SIGMA | AF_ZERO_Q; // (what pair_flags / lj_mix look at)
-constexpr int kUnmaskable = AF_HAS_DISP | AF_NEG_SIGMA; // these change the MIXING (lj_mix), not just the masks: the generic kernel keeps them
+constexpr int kUnmaskable = kAtomFlagsMixing; // (pair_math.h) these change the MIXING (lj_mix), not just the masks: the generic kernel keeps them
 constexpr double kTwoOverSqrtPi = 2.0 * kOneOverSqrtPi;
 
 __device__ __forceinline__ int sweep_tp_index(int I, int J, int nt) { return I * nt - (I * (I - 1)) / 2 + (J - I); }
 
 struct SweepI { // the i-atom a lane owns
 	double x, y, z, q, hs, e2; // position, charge, sigma / 2, 2 sqrt(epsilon)
+	double xs, ys, zs;         // position minus the tile pair's common image translation (used per uniform dimension)
 	int mol, fl;
 };
 struct SweepAcc {
@@ -49,29 +50,11 @@ struct SweepAcc {
 template <int UM, bool FIELD, int MODE, bool PAD, bool TRI>
 __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zq, const double2 *__restrict__ s_se,
                                            const int2 *__restrict__ s_mf, const double2 *__restrict__ s_tab, const int jl, const int lane,
-                                           const SweepI &I, const double shx, const double shy, const double shz, const Box &bx,
-                                           const PairSweepParams &pp, const bool half, const bool i_real, const bool store,
+                                           const SweepI &I, const double shx, const double shy, const double shz, const double t_lo,
+                                           const double t_hi, const Box &bx, const PairSweepParams &pp, const bool half, const bool i_real, const bool store,
                                            double2 *__restrict__ ab_row /*this step's 64 slots of the tensor store (wave-uniform)*/, SweepAcc &A, int &n_lj,
                                            int &n_es) {
 	const double2 xy = s_xy[jl], zq = s_zq[jl];
-	const double dx = I.x - xy.x, dy = I.y - xy.y, dz = I.z - zq.x;
-	// minimum image (src/System.cpp:1228-1246), diagonal cell: d - B rint(R d); with a tile-pair-wide image index B rint(R d) is shx
-	// general cell (TRI): the translation B^T img mixes the dimensions, so a tile pair has one image for all three (UM = 7, k_classify) or
-	// every pair takes the reference's full form rint(R d), B^T img
-	double ox, oy, oz, ri2;
-	if (TRI && UM == 0) {
-		ri2 = min_image_sq<false>(bx, dx, dy, dz, ox, oy, oz);
-	} else {
-		if (UM & 1) ox = dx - shx;
-		else ox = dx - bx.b[0] * rint(bx.r[0] * dx);
-		if (UM & 2) oy = dy - shy;
-		else oy = dy - bx.b[4] * rint(bx.r[4] * dy);
-		if (UM & 4) oz = dz - shz;
-		else oz = dz - bx.b[8] * rint(bx.r[8] * dz);
-		ri2 = ((ox * ox) + oy * oy) + oz * oz;
-	}
-	const double ir = fast_rsqrt_1(ri2);
-	const double r = ri2 * ir;
 	int2 mfj = make_int2(0, 0);
 	if (MODE >= 1 || PAD) mfj = s_mf[jl]; // molecule id, flags (padding slots: negative ids, AF_PAD)
 	// lanes that form a real pair at this step: all of them, except in tile pairs with padding slots (PAD: the last tile) and in the
@@ -79,6 +62,59 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 	bool ok = true;
 	if (PAD) ok = i_real && (mfj.x >= 0);
 	if (half) ok = ok && (lane < 32);
+	// minimum image (src/System.cpp:1228-1246), diagonal cell: d - B rint(R d); with a tile-pair-wide image index B rint(R d) is shx
+	// general cell (TRI): the translation B^T img mixes the dimensions, so a tile pair has one image for all three (UM = 7, k_classify) or
+	// every pair takes the reference's full form rint(R d), B^T img
+	double ox, oy, oz, ri2;
+	bool in_cut_lj, in_cut_es; // the reference's two cutoff predicates: rimg - 1e-12 < rc (lj :934), !(rimg > rc) (coulombic_real :1490, real_term :2917)
+	auto exact_geometry = [&]() { // the reference's operands in the reference's order, unfused: ri2 decides pair inclusion bit for bit
+		const double dx = I.x - xy.x, dy = I.y - xy.y, dz = I.z - zq.x;
+		if (TRI && UM == 0) {
+			ri2 = min_image_sq<false>(bx, dx, dy, dz, ox, oy, oz);
+		} else {
+			if (UM & 1) ox = dx - shx;
+			else ox = dx - bx.b[0] * rint(bx.r[0] * dx);
+			if (UM & 2) oy = dy - shy;
+			else oy = dy - bx.b[4] * rint(bx.r[4] * dy);
+			if (UM & 4) oz = dz - shz;
+			else oz = dz - bx.b[8] * rint(bx.r[8] * dz);
+			ri2 = ((ox * ox) + oy * oy) + oz * oz;
+		}
+		in_cut_lj = (ri2 <= bx.t_lj);
+		in_cut_es = (ri2 <= bx.t_es);
+	};
+	if (TRI) { // (skewed cells keep the reference's form throughout)
+		exact_geometry();
+	} else {
+		// FAST form (round 4): the i-atom carries the tile pair's common image already (I.xs = x_i - shx per uniform dimension, once per
+		// wave), the remaining dimensions and the squared distance are fused: 6 instead of 11 instructions with three uniform dimensions.
+		// Its ri2 differs from the reference's by a few ulp of the COORDINATES (relative 1e-14 here), which can only change a cutoff
+		// predicate inside the band t_lo .. t_hi = t_es (1 - 1e-9) .. t_lj (1 + 1e-9) around the thresholds (k_classify checks per tile
+		// pair that the coordinates are small enough for that and widens the band to "everything" if not: tp_shift.w).  The two compares the predicates need anyway
+		// are taken against the band's edges: inside t_lo both predicates hold, beyond t_hi neither does, and a step with a lane in
+		// between (about one pair in 1e9) redoes its geometry the reference's way -- pair inclusion stays bit-exact.
+		if (UM & 1) ox = I.xs - xy.x;
+		else {
+			const double dx = I.x - xy.x;
+			ox = fma(-bx.b[0], rint(bx.r[0] * dx), dx);
+		}
+		if (UM & 2) oy = I.ys - xy.y;
+		else {
+			const double dy = I.y - xy.y;
+			oy = fma(-bx.b[4], rint(bx.r[4] * dy), dy);
+		}
+		if (UM & 4) oz = I.zs - zq.x;
+		else {
+			const double dz = I.z - zq.x;
+			oz = fma(-bx.b[8], rint(bx.r[8] * dz), dz);
+		}
+		ri2 = fma(oz, oz, fma(oy, oy, ox * ox));
+		const bool inside = (ri2 <= t_lo), maybe = (ri2 <= t_hi);
+		in_cut_lj = in_cut_es = inside;
+		if (__any(ok && maybe && !inside)) exact_geometry();
+	}
+	const double ir = fast_rsqrt_1(ri2);
+	const double r = ri2 * ir;
 	// pair_exclusions (src/System.cpp:1035-1197) for what this grade of tile pair can hold:
 	//   frozen pair (both frozen): no LJ, no Coulomb, no field -- only the Thole tensor;   excl_rd / excl_es: same molecule, or an atom without
 	//   sigma / epsilon (rd) resp. without charge (es);   no_field: both charges zero (real_term :2916).  MODE 0 / 1 know none / only "same molecule".
@@ -115,8 +151,8 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 
 	// the inclusion predicates, and the counts of the pairs they admit: wave-level masks and popcounts (scalar unit), taken OUTSIDE the
 	// divergent region.  t_es <= t_lj (pair_math.h Box), so the Coulomb pairs are a subset of the LJ shell.
-	const bool in_lj = ok && !frozen && (ri2 <= bx.t_lj); // rimg - 1e-12 < rc  (lj :934)
-	const bool in_es = ok && !frozen && (ri2 <= bx.t_es); // (implies in_lj)  !(rimg > rc)  (coulombic_real :1490, real_term :2917)
+	const bool in_lj = ok && !frozen && in_cut_lj; // rimg - 1e-12 < rc  (lj :934)
+	const bool in_es = ok && !frozen && in_cut_es; // (implies in_lj)  !(rimg > rc)  (coulombic_real :1490, real_term :2917)
 	const bool lj_on = in_lj && !excl_rd, es_on = in_es && !excl_es;
 	n_lj += __popcll(__builtin_amdgcn_ballot_w64(lj_on));
 	n_es += __popcll(__builtin_amdgcn_ballot_w64(es_on));
@@ -165,15 +201,15 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 template <int UM, bool FIELD, int MODE, bool PAD, bool TRI = false>
 __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zq, const double2 *__restrict__ s_se,
                                         const int2 *__restrict__ s_mf, const double2 *__restrict__ s_tab, const int lane, const SweepI &I,
-                                        const double shx, const double shy, const double shz, const Box &bx, const PairSweepParams &pp,
-                                        const bool diag, const bool i_real, const bool store,
+                                        const double shx, const double shy, const double shz, const double t_lo, const double t_hi,
+                                        const Box &bx, const PairSweepParams &pp, const bool tail_half, const int s_begin, const int s_end, const bool i_real, const bool store,
                                         double2 *__restrict__ ab_tile, SweepAcc &A, int &n_lj, int &n_es) {
-	// diagonal tile pair: s = 1..32, the last one with lanes 0..31 only (each pair once); off-diagonal: s = 0..63
-	const int s0 = diag ? 1 : 0, n = diag ? 32 : 64;
-	for (int k = 0; k < n; ++k) {
-		const int s = s0 + k;
-		const bool last = (k == n - 1);
-		sweep_step<UM, FIELD, MODE, PAD, TRI>(s_xy, s_zq, s_se, s_mf, s_tab, lane + s, lane, I, shx, shy, shz, bx, pp, diag && last, i_real, store,
+	// diagonal tile pair: s = 1..32, the last one with lanes 0..31 only (each pair once); off-diagonal: s = 0..63.  A wave walks the
+	// steps [s_begin, s_end) of that sequence: all of them, or one half of them when two waves share a tile pair (pp.split);
+	// tail_half: this wave's last step is the diagonal tile pair's closing half step
+	for (int s = s_begin; s < s_end; ++s) {
+		const bool last = (s == s_end - 1);
+		sweep_step<UM, FIELD, MODE, PAD, TRI>(s_xy, s_zq, s_se, s_mf, s_tab, lane + s, lane, I, shx, shy, shz, t_lo, t_hi, bx, pp, tail_half && last, i_real, store,
 		                                  ab_tile + s * kTile, A, n_lj, n_es);
 		if (FIELD && !last) {
 			A.gx = rot_from_next(A.gx);
@@ -186,7 +222,7 @@ __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, con
 // blocks: { J, I0 } -- the workgroup's waves take the tile pairs (I0 + w, J), w = 0..3, as far as I0 + w <= J
 // (ORTHO: the orthorhombic instantiation reads the diagonals of the cell and its inverse only, which keeps the rest of the Box out of its
 // scalar registers -- spilled SGPRs are v_writelane / v_readlane on the VALU)
-template <bool FIELD, bool INTRA, bool ORTHO>
+template <bool FIELD, bool INTRA, bool ORTHO, bool SPLIT>
 __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Box bx, PairSweepParams pp, const int2 *__restrict__ blocks,
                                                                  const int *__restrict__ cls, const double4 *__restrict__ tp_shift,
                                                                  const double2 *__restrict__ erf_tab, double *__restrict__ block_part,
@@ -197,8 +233,13 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 	__shared__ int2 s_mf[2 * kTile];
 	__shared__ int s_jflags[3];
 	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int2 blk = blocks[blockIdx.x];
-	const int J = __builtin_amdgcn_readfirstlane(blk.x), I = __builtin_amdgcn_readfirstlane(blk.y) + w;
+	// pp.split: the workgroup takes TWO tile pairs (I0, J), (I0 + 1, J) and two waves share each -- wave w walks half (w >> 1) of the
+	// steps of tile pair (w & 1); the halves meet in LDS behind the walk.  Half-length workgroups: a lone launch drains on a tail half as
+	// long (CUs busy 77 % -> ~90 % of the launch at 10 000 atoms).  The table stays { J, I0 in steps of 4 }: two workgroups per entry.
+	constexpr bool split = SPLIT;
+	const int2 blk = blocks[split ? (blockIdx.x >> 1) : blockIdx.x];
+	const int pw = split ? (w & 1) : w, half = split ? (w >> 1) : 0;
+	const int J = __builtin_amdgcn_readfirstlane(blk.x), I = __builtin_amdgcn_readfirstlane(blk.y) + (split ? 2 * (int)(blockIdx.x & 1) : 0) + pw;
 	const int j0 = J * kTile;
 #pragma unroll
 	for (int k = 0; k < (3 * MPMC_ERFTAB_PIECES) / (64 * kSweepWaves); ++k) s_tab[threadIdx.x + k * 64 * kSweepWaves] = erf_tab[threadIdx.x + k * 64 * kSweepWaves];
@@ -219,17 +260,19 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 		}
 	}
 	__syncthreads();
-	if (I > J) return; // (a j-tile's last workgroup may have fewer than four tile pairs)
+	if (!split && I > J) return; // (a j-tile's last workgroup may have fewer tile pairs than waves; with pp.split every wave stays for the barriers)
+	const bool have_tp = (I <= J);
 	const int nt = pp.nt;
-	const int tp = sweep_tp_index(I, J, nt);
-	const int i = I * kTile + lane;
+	const int tp = have_tp ? sweep_tp_index(I, J, nt) : 0;
+	const int i = (have_tp ? I : J) * kTile + lane;
 	const double4 pi = at.xyzq[i];
 	const double2 li = at.lj[i];
 	const int2 mi = at.mf[i];
 	const bool i_real = !(mi.y & AF_PAD);
 	// a tile pair with an atom whose flags change the MIXING (sigma < 0, dispersion coefficients) belongs to the generic kernel (the host
 	// launches it on exactly these: same predicate); any other special atom (frozen, chargeless, sigma- or epsilon-less) selects the masked grade
-	if (__builtin_amdgcn_readfirstlane(s_jflags[0]) || __any(i_real && (mi.y & kUnmaskable) != 0)) return;
+	const bool generic_tp = __builtin_amdgcn_readfirstlane(s_jflags[0]) || __any(i_real && (mi.y & kUnmaskable) != 0);
+	if (!split && generic_tp) return;
 	const bool special = __builtin_amdgcn_readfirstlane(s_jflags[2]) || __any(i_real && (mi.y & kSpecialAtom) != 0);
 	const bool pad = __builtin_amdgcn_readfirstlane(s_jflags[1]) || __any(!i_real);
 	const bool diag = (I == J);
@@ -239,7 +282,9 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 	const int nt_pad3 = at.n_pad * 3;
 	// (a tile pair beyond the cutoff whose tensors are stored all the same -- a cutoff shorter than the damping range -- takes the
 	// ordinary walk: no pair of it passes a cutoff predicate, by the class's construction)
-	if (beyond && !store) { // nothing to do: publish zeros so that the fixed-shape reductions stay valid
+	const bool nothing = beyond && !store; // nothing to do: publish zeros so that the fixed-shape reductions stay valid
+	const bool live = have_tp && !generic_tp; // this wave's tile pair is the sweep's
+	if (live && nothing && half == 0) {
 		if (FIELD) {
 			double *oi = fpart + (size_t)J * nt_pad3 + 3 * (size_t)i;
 			double *oj = fpart + (size_t)I * nt_pad3 + 3 * (size_t)(j0 + lane);
@@ -252,24 +297,34 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 			block_cnt[2 * (size_t)tp] = 0;
 			block_cnt[2 * (size_t)tp + 1] = 0;
 		}
-		return;
 	}
-	SweepI Ai;
-	Ai.x = pi.x, Ai.y = pi.y, Ai.z = pi.z, Ai.q = pi.w;
-	Ai.hs = 0.5 * li.x, Ai.e2 = 2.0 * li.y;
-	Ai.mol = mi.x;
-	Ai.fl = mi.y;
-	int um = (pp.have_shift && !pad) ? ((cl / CLS_UNIFORM_X) & 7) : 0; // (the padded tile's pairs take the general image path: one variant)
-	if (!ORTHO && um != 7) um = 0; // a skewed cell's translation mixes the components: one common image for all three indices, or the full form
-	double shx = 0.0, shy = 0.0, shz = 0.0; // B img of the tile pair's common image, per uniform dimension (wave-uniform: scalar loads)
-	if (pp.have_shift) {
-		const double4 sh = tp_shift[tp];
-		shx = sh.x, shy = sh.y, shz = sh.z;
-	}
+	if (!split && nothing) return;
+	const bool walk = live && !nothing;
 	SweepAcc A = {};
 	int n_lj = 0, n_es = 0;
-	double2 *ab_tile = store ? ab + (size_t)tp * (kTile * kTile) : nullptr;
-#define MPMC_SWEEP_ARGS s_xy, s_zq, s_se, s_mf, s_tab, lane, Ai, shx, shy, shz, bx, pp, diag, i_real, store, ab_tile, A, n_lj, n_es
+	// steps of this wave: s = 0..63 (diagonal tile pair: 1..32), or one half of them
+	const int n_steps = diag ? 32 : 64, s_first = diag ? 1 : 0;
+	const int s_begin = s_first + (split ? half * (n_steps / 2) : 0), s_end = s_first + (split ? (half + 1) * (n_steps / 2) : n_steps);
+	const bool tail_half = diag && (s_end == 33);
+	if (walk) {
+		SweepI Ai;
+		Ai.x = pi.x, Ai.y = pi.y, Ai.z = pi.z, Ai.q = pi.w;
+		Ai.hs = 0.5 * li.x, Ai.e2 = 2.0 * li.y;
+		Ai.mol = mi.x;
+		Ai.fl = mi.y;
+		int um = (pp.have_shift && !pad) ? ((cl / CLS_UNIFORM_X) & 7) : 0; // (the padded tile's pairs take the general image path: one variant)
+		if (!ORTHO && um != 7) um = 0; // a skewed cell's translation mixes the components: one common image for all three indices, or the full form
+		double shx = 0.0, shy = 0.0, shz = 0.0; // B img of the tile pair's common image, per uniform dimension (wave-uniform: scalar loads)
+		double band = 1e30;                     // relative half-width of the fast geometry's band around the cutoff thresholds (1e30: everything)
+		if (pp.have_shift) {
+			const double4 sh = tp_shift[tp];
+			shx = sh.x, shy = sh.y, shz = sh.z;
+			if (pp.fast) band = sh.w;
+		}
+		const double t_lo = bx.t_es - bx.t_es * band, t_hi = bx.t_lj + bx.t_lj * band;
+		Ai.xs = Ai.x - shx, Ai.ys = Ai.y - shy, Ai.zs = Ai.z - shz;
+		double2 *ab_tile = store ? ab + (size_t)tp * (kTile * kTile) : nullptr;
+#define MPMC_SWEEP_ARGS s_xy, s_zq, s_se, s_mf, s_tab, lane, Ai, shx, shy, shz, t_lo, t_hi, bx, pp, tail_half, s_begin, s_end, i_real, store, ab_tile, A, n_lj, n_es
 #define MPMC_SWEEP_UM(MODE)                                                        \
 	switch (um) {                                                                  \
 	case 0:                                                                        \
@@ -287,21 +342,58 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 	case 6: sweep_walk<6, FIELD, MODE, false>(MPMC_SWEEP_ARGS); break;             \
 	default: sweep_walk<7, FIELD, MODE, false>(MPMC_SWEEP_ARGS); break;            \
 	}
-	if (special) {
-		MPMC_SWEEP_UM(2)
-	} else {
-		MPMC_SWEEP_UM((INTRA ? 1 : 0))
-	}
+		if (special) {
+			MPMC_SWEEP_UM(2)
+		} else {
+			MPMC_SWEEP_UM((INTRA ? 1 : 0))
+		}
 #undef MPMC_SWEEP_UM
 #undef MPMC_SWEEP_ARGS
+	}
+	// the j-atom whose accumulator this lane ended up holding: after step s (no rotation behind the last one) lane l pairs with (l + s) & 63
+	const int jown = (lane + s_end - 1) & 63;
+	double e_lj = A.e_lj, e_re = A.e_re;
+	if (split) {
+		// the two halves of a tile pair meet in LDS (the erfc table's space: nobody reads it behind the first barrier): the wave of the second
+		// half leaves its i-side sums per lane, its j-side sums per j-atom, its energies per lane and its counts; the wave of the first half
+		// adds them to its own -- first half + second half, a fixed order -- and writes the tile pair's outputs as the unsplit kernel does
+		double *xch = reinterpret_cast<double *>(s_tab) + (size_t)pw * (9 * kTile);
+		__syncthreads();
+		if (half == 1 && walk) {
+			xch[0 * kTile + lane] = A.ex;
+			xch[1 * kTile + lane] = A.ey;
+			xch[2 * kTile + lane] = A.ez;
+			xch[3 * kTile + jown] = A.gx;
+			xch[4 * kTile + jown] = A.gy;
+			xch[5 * kTile + jown] = A.gz;
+			xch[6 * kTile + lane] = A.e_lj;
+			xch[7 * kTile + lane] = A.e_re;
+			if (lane == 0) {
+				reinterpret_cast<int *>(xch + 8 * kTile)[0] = n_lj;
+				reinterpret_cast<int *>(xch + 8 * kTile)[1] = n_es;
+			}
+		}
+		__syncthreads();
+		if (half == 1 || !walk) return;
+		A.ex += xch[0 * kTile + lane];
+		A.ey += xch[1 * kTile + lane];
+		A.ez += xch[2 * kTile + lane];
+		A.gx += xch[3 * kTile + jown];
+		A.gy += xch[4 * kTile + jown];
+		A.gz += xch[5 * kTile + jown];
+		e_lj += xch[6 * kTile + lane];
+		e_re += xch[7 * kTile + lane];
+		n_lj += reinterpret_cast<const int *>(xch + 8 * kTile)[0];
+		n_es += reinterpret_cast<const int *>(xch + 8 * kTile)[1];
+	}
 
 	if (FIELD) {
-		const int jown = (lane + (diag ? 32 : 63)) & 63; // the j-atom whose accumulator this lane ended up holding
-		if (diag) { // both sides are the same 64 atoms: one slot [I][I atoms]; atom a's j-side sum sits in lane (a + 32) & 63 = a ^ 32
+		if (diag) { // both sides are the same 64 atoms: one slot [I][I atoms]; atom a's j-side sum sits in the lane with jown = a
 			double *o = fpart + (size_t)I * nt_pad3 + 3 * (size_t)i;
-			o[0] = A.ex + __shfl(A.gx, lane ^ 32, 64);
-			o[1] = A.ey + __shfl(A.gy, lane ^ 32, 64);
-			o[2] = A.ez + __shfl(A.gz, lane ^ 32, 64);
+			const int src = (2 * lane - jown) & 63; // jown(src) = lane  (jown = lane + c  =>  src = lane - c)
+			o[0] = A.ex + __shfl(A.gx, src, 64);
+			o[1] = A.ey + __shfl(A.gy, src, 64);
+			o[2] = A.ez + __shfl(A.gz, src, 64);
 		} else {
 			double *oi = fpart + (size_t)J * nt_pad3 + 3 * (size_t)i; // i-atoms, contribution of tile J
 			oi[0] = A.ex;
@@ -313,7 +405,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 			oj[2] = A.gz;
 		}
 	}
-	const double e_lj = wave_sum(A.e_lj), e_re = wave_sum(A.e_re);
+	e_lj = wave_sum(e_lj), e_re = wave_sum(e_re);
 	if (lane == 0) {
 		block_part[2 * (size_t)tp] = e_lj;
 		block_part[2 * (size_t)tp + 1] = e_re;
@@ -340,19 +432,27 @@ bool pair_sweep_covers(const Box &bx, const FusedParams &fp, double ewald_alpha)
 }
 
 void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, bool intra, const int2 *blocks, int n_blocks,
-                       const int *cls, const double4 *tp_shift, const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab) {
+                       const int *cls, const double4 *tp_shift, const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab,
+                       bool split, bool fast_geometry) {
 	PairSweepParams pp;
+	pp.split = split ? 1 : 0;
 	pp.ewald_alpha = fp.ewald_alpha;
 	pp.polar_damp = fp.polar_damp;
 	pp.thole_far_x = fp.thole_far_x;
 	pp.store = (fp.do_thole && ab) ? 1 : 0;
 	pp.nt = at.n_pad / kTile;
 	pp.have_shift = tp_shift ? 1 : 0;
-	dim3 grid(n_blocks), block(64 * kSweepWaves);
+	pp.fast = fast_geometry ? 1 : 0; // (the per-tile-pair band comes from k_classify: tp_shift.w)
+	dim3 grid(split ? 2 * n_blocks : n_blocks), block(64 * kSweepWaves);
 #define MPMC_PS(F, N)                                                                                                                                 \
 	do {                                                                                                                                          \
-		if (bx.ortho) hipLaunchKernelGGL((k_pair_sweep<F, N, true>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab); \
-		else hipLaunchKernelGGL((k_pair_sweep<F, N, false>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab);     \
+		if (bx.ortho) {                                                                                                                           \
+			if (split) hipLaunchKernelGGL((k_pair_sweep<F, N, true, true>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab); \
+			else hipLaunchKernelGGL((k_pair_sweep<F, N, true, false>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab);    \
+		} else {                                                                                                                                  \
+			if (split) hipLaunchKernelGGL((k_pair_sweep<F, N, false, true>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab); \
+			else hipLaunchKernelGGL((k_pair_sweep<F, N, false, false>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab);   \
+		}                                                                                                                                         \
 	} while (0)
 	if (fp.do_field == 1) {
 		if (intra) MPMC_PS(true, true);

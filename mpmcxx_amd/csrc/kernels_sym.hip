@@ -571,12 +571,25 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 			ok = ok && (ihi >= ilo) && (jhi >= jlo);
 		}
 		double sh[3] = {0, 0, 0};
+		double band = 1e30; // see below: relative half-width of the band in which the pair sweep's fused geometry defers to the reference's form
 		if (bx.ortho) {
+			double cmax = 0.0;
 			for (int d = 0; d < 3; ++d) {
 				const double m0 = rint(bx.r[4 * d] * lo[d]), m1 = rint(bx.r[4 * d] * hi[d]);
 				if ((m0 == m1) && ok) c |= (CLS_UNIFORM_X << d);
 				sh[d] = bx.b[4 * d] * m0;
+				const double ilo = tb[12 * (size_t)IJ.x + 6 + d], ihi = tb[12 * (size_t)IJ.x + 9 + d];
+				const double jlo = tb[12 * (size_t)IJ.y + 6 + d], jhi = tb[12 * (size_t)IJ.y + 9 + d];
+				cmax = fmax(cmax, fmax(fabs(ilo), fabs(ihi)) + fmax(fabs(jlo), fabs(jhi)) + fabs(sh[d]) + fabs(bx.b[4 * d]));
 			}
+			// The pair sweep's fused geometry (kernels_pair.hip: i-atom pre-shifted by the common image, fma) forms the same displacement
+			// from the same operands in another order: each component differs from the reference's by at most ~4 ulp of the largest
+			// magnitude it subtracts (<= cmax), the squared distance by 2 r sqrt(3) 4 eps cmax + 4 eps r^2, i.e. relative to the cutoff
+			// threshold t ~ r^2 by  err = 14 eps cmax / sqrt(t) + 4 eps  (eps = 2^-52).  A band of 1e-9 is a hundred times that for
+			// coordinates up to ~3e4 cutoffs from the origin; beyond, the band is "everything" and the sweep takes the reference's form.
+			const double tmin = fmin(bx.t_lj, bx.t_es);
+			const double err = (tmin > 0.0) ? (14.0 * cmax / sqrt(tmin) + 4.0) * 2.220446049250313e-16 : 1.0;
+			if (ok && err * 100.0 < 1e-9) band = 1e-9;
 		} else {
 			double img[3]; // (lo, hi: extreme differences of the raw fractional coordinate p)
 			for (int p = 0; p < 3; ++p) {
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(256) void k_classify(const double *__restrict__ tb,
 			// Jacobi walk, values only, takes the partial sums too and rounds the remaining indices per pair)
 			for (int p = 0; p < 3; ++p) sh[p] = ((bx.b[p] * img[0]) + bx.b[3 + p] * img[1]) + bx.b[6 + p] * img[2];
 		}
-		tp_shift[t] = make_double4(sh[0], sh[1], sh[2], 0.0);
+		tp_shift[t] = make_double4(sh[0], sh[1], sh[2], band);
 	}
 	cls[t] = c;
 }

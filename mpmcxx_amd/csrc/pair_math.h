@@ -38,6 +38,10 @@ enum : int {
 	AF_ZERO_ALPHA = 64,// polarizability == 0
 	AF_PAD = 128       // padding slot beyond n (never a real atom)
 };
+// Atoms whose flags change the MIXING of lj_mix (sigma < 0: attractive only; dispersion coefficients), not just the masks of
+// pair_exclusions: a tile pair that contains one is left to k_pair_fused.  ONE definition for the host list (context.cpp: upload_atoms)
+// and the sweep's skip test (kernels_pair.hip) -- a tile pair must be served by exactly one of the two kernels.
+constexpr int kAtomFlagsMixing = AF_HAS_DISP | AF_NEG_SIGMA;
 
 // box constants, passed by value to kernels
 struct Box {

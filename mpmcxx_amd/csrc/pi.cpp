@@ -10,13 +10,26 @@ using namespace mpmc;
 // independent evaluation on its own context and streams; all of them are enqueued before the first wait, so one bead's pair sweep
 // fills the launch ramps and tails of another bead's dipole iterations (a lockstep form that shared launches between the beads was
 // measured in round 1 -- 650 against 737 evaluations/s -- and removed in round 3).
+// An error in the middle of the loop must not leave evaluations in flight that nobody waits for: the caller's next step would write a
+// bead's buffers under a running evaluation.  Beads [first, last) are waited for, their results dropped; the first error stays the answer.
+static void pi_drain(mpmc_ctx **beads, int first, int last) {
+	for (int b = first; b < last; b++)
+		if (beads[b] && beads[b]->pending) {
+			mpmc_result dropped;
+			(void)mpmc_energy_wait(beads[b], &dropped);
+		}
+}
+
 static int pi_wait_all(mpmc_ctx **beads, int n_local, double sums4[4], mpmc_result *per_bead, int *any_failed) {
 	sums4[0] = sums4[1] = sums4[2] = sums4[3] = 0;
 	int failed = 0;
 	for (int b = 0; b < n_local; b++) {
 		mpmc_result r;
 		int rc = mpmc_energy_wait(beads[b], &r);
-		if (rc != MPMC_OK) return rc;
+		if (rc != MPMC_OK) {
+			pi_drain(beads, b + 1, n_local);
+			return rc;
+		}
 		sums4[0] += r.rd_energy; // ordered accumulation, PathIntegral.cpp:791-796
 		sums4[1] += r.coulombic_energy;
 		sums4[2] += r.polarization_energy;
@@ -34,9 +47,11 @@ extern "C" int mpmc_last_batch_size(mpmc_ctx *c) { return c ? 1 : 0; }
 extern "C" int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sums4[4], mpmc_result *per_bead, int *any_failed) {
 	if (!beads || n_local < 0 || !sums4) return MPMC_ERR_ARG;
 	for (int b = 0; b < n_local; b++) {
-		if (!beads[b]) return MPMC_ERR_ARG;
-		int rc = enqueue(beads[b], full_mask(beads[b]));
-		if (rc != MPMC_OK) return rc;
+		int rc = beads[b] ? enqueue(beads[b], full_mask(beads[b])) : MPMC_ERR_ARG;
+		if (rc != MPMC_OK) {
+			pi_drain(beads, 0, b);
+			return rc;
+		}
 	}
 	return pi_wait_all(beads, n_local, sums4, per_bead, any_failed);
 }
@@ -50,10 +65,12 @@ extern "C" int mpmc_pi_potential_local_host(mpmc_ctx **beads, int n_local, const
 	if (!beads || n_local < 0 || !sums4 || !pos) return MPMC_ERR_ARG;
 	for (int b = 0; b < n_local; b++) {
 		mpmc_ctx *c = beads[b];
-		if (!c || !pos[b]) return MPMC_ERR_ARG;
-		int rc = mpmc_update_positions(c, 0, c->n, pos[b]);
-		if (rc != MPMC_OK) return rc;
-		if ((rc = enqueue(c, full_mask(c))) != MPMC_OK) return rc;
+		int rc = (c && pos[b]) ? mpmc_update_positions(c, 0, c->n, pos[b]) : MPMC_ERR_ARG;
+		if (rc == MPMC_OK) rc = enqueue(c, full_mask(c));
+		if (rc != MPMC_OK) {
+			pi_drain(beads, 0, b);
+			return rc;
+		}
 	}
 	return pi_wait_all(beads, n_local, sums4, per_bead, any_failed);
 }

@@ -142,6 +142,7 @@ def lib():
     L.mpmc_comm_allgather_f64.argtypes = [vp, dp, C.c_int64, dp]
     L.mpmc_pi_gather_beads.argtypes = [vp, dp, C.c_int, C.c_int, dp]
     L.mpmc_pi_allreduce.argtypes = [C.POINTER(vp), C.c_int, dp, C.POINTER(Result), C.POINTER(C.c_int)]
+    L.mpmc_pi_allreduce_info.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mpmc_debug_configure.argtypes = [vp, C.c_char_p, C.c_double]
     L.mpmc_debug_last_pair_kernel.argtypes = [vp]
     L.mpmc_debug_last_trial_was_full.argtypes = [vp]
@@ -486,6 +487,17 @@ def pi_allreduce(beads: Sequence[System]):
     for b, r in zip(beads, per):
         b.observables = r
     return sums, per, bool(failed.value)
+
+
+def pi_allreduce_info(beads: Sequence[System]):
+    """(number of distinct devices the beads live on, size of the process-wide RCCL communicator pi_allreduce made for them; 0 = not yet)."""
+    n = len(beads)
+    arr = (C.c_void_p * max(n, 1))(*[b.handle for b in beads])
+    nd, nr = C.c_int(0), C.c_int(0)
+    rc = lib().mpmc_pi_allreduce_info(arr, n, C.byref(nd), C.byref(nr))
+    if rc != MPMC_OK:
+        raise MpmcError(rc, "mpmc_pi_allreduce_info")
+    return nd.value, nr.value
 
 
 def rccl_version() -> int:

@@ -241,6 +241,68 @@ double orc_lj(const orc_system *s, orc_result *out) {
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * lj() with EXACT sums (CPU only; a measuring stick, not a restatement).  The per-pair fp64 terms are the reference's own
+ * (same expressions as orc_lj above); what differs is the accumulation: the reference adds every pair's `rd + lrc` onto ONE
+ * accumulator in list order (System.Energy.cpp:1011), which at 10 000 atoms means 5*10^7 additions of terms a fraction of an ulp
+ * of a -5*10^6 K sum wide -- a rounding drift that grows with N.  Here every sum is carried in long double with Neumaier
+ * compensation (error << 1 ulp of the fp64 result), so that "HIP path vs exact" and "reference vs exact" can be told apart.
+ * out7 = { sum of rd terms, sum of pair lrc terms, sum of self lrc terms, their total (= what lj() returns, summed exactly),
+ *          list-order fp64 `potential` as the reference accumulates it, list-order lj_pairs, list-order lrc_pair }
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { long double s, c; } orc_ksum;
+static void ksum_add(orc_ksum *k, double x) {
+	long double t = k->s + (long double)x;
+	if (fabsl(k->s) >= fabsl((long double)x)) k->c += (k->s - t) + (long double)x;
+	else k->c += ((long double)x - t) + k->s;
+	k->s = t;
+}
+void orc_lj_exact(const orc_system *s, double out7[7]) {
+	const double cutoff = s->cutoff;
+	orc_ksum k_rd = {0, 0}, k_lrc = {0, 0}, k_self = {0, 0};
+	double potential = 0, lj_pairs = 0, lrc_pair = 0;
+	for (int i = 0; i < s->n; i++) {
+		for (int j = i + 1; j < s->n; j++) {
+			pair_par pp;
+			double dimg[3], r;
+			pair_params(s, i, j, &pp);
+			double rimg = 0;
+			if (!pp.frozen || s->polarization) rimg = orc_minimum_image(s, i, j, dimg, &r);
+			double lrc = 0, rd = 0;
+			if (s->rd_lrc && pp.epsilon != 0 && pp.sigma != 0 && !pp.frozen) lrc = lrc_term(pp.sigma, pp.epsilon, cutoff, s->volume);
+			if ((rimg - ORC_SMALL_DR < cutoff) && !pp.rd_excluded && !pp.frozen) {
+				double sor = fabs(pp.sigma) / rimg;
+				double sor6 = sor * sor * sor;
+				sor6 *= sor6;
+				double sor12 = sor6 * sor6;
+				double term12 = pp.attractive_only ? 0 : sor12;
+				rd += 4.0 * pp.epsilon * (term12 - sor6);
+				if (s->feynman_hibbs) rd += lj_fh_corr(s, i, j, pp.epsilon, rimg, term12, sor6);
+			}
+			ksum_add(&k_rd, rd);
+			ksum_add(&k_lrc, lrc);
+			potential += rd + lrc;
+			lj_pairs += rd;
+			lrc_pair += lrc;
+		}
+	}
+	if (s->rd_lrc)
+		for (int i = 0; i < s->n; i++) {
+			double t = 0;
+			if (s->sigma[i] != 0 && s->epsilon[i] != 0 && !s->frozen[i]) t = lrc_term(s->sigma[i], s->epsilon[i], cutoff, s->volume);
+			ksum_add(&k_self, t);
+			potential += t;
+		}
+	const long double rd_x = k_rd.s + k_rd.c, lrc_x = k_lrc.s + k_lrc.c, self_x = k_self.s + k_self.c;
+	out7[0] = (double)rd_x;
+	out7[1] = (double)lrc_x;
+	out7[2] = (double)self_x;
+	out7[3] = (double)(rd_x + lrc_x + self_x);
+	out7[4] = potential;
+	out7[5] = lj_pairs;
+	out7[6] = lrc_pair;
+}
+
+/* ---------------------------------------------------------------------------------------------
  * coulombic_real, System.Energy.cpp:1466-1517
  * ------------------------------------------------------------------------------------------- */
 double orc_coulombic_real(const orc_system *s, orc_result *out) {

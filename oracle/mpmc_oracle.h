@@ -63,6 +63,8 @@ int orc_energy(const orc_system *s, orc_result *out, double *ef_static, double *
 
 /* component entry points (same names as the reference's public members, System.h:346-402) */
 double orc_lj(const orc_system *s, orc_result *out);
+/* lj() with exactly rounded sums (long double + Neumaier) next to the reference's list-order sums; see mpmc_oracle.c.  CPU only. */
+void orc_lj_exact(const orc_system *s, double out7[7]);
 double orc_coulombic_real(const orc_system *s, orc_result *out);
 double orc_coulombic_reciprocal(const orc_system *s);
 double orc_coulombic_self(const orc_system *s);

@@ -88,6 +88,8 @@ def lib():
         L.orc_energy.restype = C.c_int
         L.orc_lj.argtypes = [C.POINTER(OrcSystem), C.POINTER(OrcResult)]
         L.orc_lj.restype = C.c_double
+        L.orc_lj_exact.argtypes = [C.POINTER(OrcSystem), dp]
+        L.orc_lj_exact.restype = None
         L.orc_coulombic_real.argtypes = [C.POINTER(OrcSystem), C.POINTER(OrcResult)]
         L.orc_coulombic_real.restype = C.c_double
         L.orc_coulombic_reciprocal.argtypes = [C.POINTER(OrcSystem)]
@@ -189,6 +191,14 @@ class OracleSystem:
         if want_atoms:
             out.update(ef_static=E, mu=mu, ef_induced=F)
         return out
+
+    def lj_exact(self):
+        """lj() with exactly rounded sums next to the reference's list-order sums (orc_lj_exact): the measuring stick that separates the
+        HIP path's error from the reference's own accumulation drift (System.Energy.cpp:1011)."""
+        o = np.zeros(7)
+        lib().orc_lj_exact(C.byref(self.s), _dp(o))
+        return {"lj_pairs_exact": o[0], "lrc_pair_exact": o[1], "lrc_self_exact": o[2], "rd_exact": o[3],
+                "rd_list_order": o[4], "lj_pairs_list_order": o[5], "lrc_pair_list_order": o[6]}
 
     def time_sample(self, stride: int):
         """(estimated seconds per stage of one full evaluation [7], wall seconds spent)"""

@@ -10,9 +10,16 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- FIRST: see below
 
 import util
 from mpmcxx_amd import energy
+
+# Load order matters in a process that holds two ROCm installations (this image: /opt/rocm and the copy PyTorch bundles).  The library
+# dlopens "librccl.so.1" at first use and shares whatever copy is loaded already; if it comes first and torch is imported afterwards
+# (the two-device tests below do that), the process ends up with two librocm_smi64 and aborts in THEIR static destructors at exit
+# ("double free or corruption", backtrace in amd::smi's std::map destructor; round 4, gpurun_out/r04_gdb.log).  A full test run imports
+# torch during collection, which is why only partial runs showed it.  A host program has one ROCm; bench.py imports torch first.
 
 pytestmark = pytest.mark.gpu
 
