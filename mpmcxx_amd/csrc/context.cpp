@@ -860,6 +860,7 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 		if (v != 0 && v != 1 && v != 4) return MPMC_ERR_ARG;
 		t.pair_waves = v;
 	} else if (k == "fast_geometry") t.fast_geometry = on;
+	else if (k == "dense_symmetric") t.dense_symmetric = on;
 	else if (k == "pair_split") {
 		if (v < -1 || v > 1) return MPMC_ERR_ARG;
 		t.pair_split = v;

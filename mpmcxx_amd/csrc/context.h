@@ -36,6 +36,7 @@ struct mpmc_tuning {
 	int stream_mode = -1;   // "side_stream": -1 by table size (kOneStreamMaxPairs), 0 never fork the side stream, 1 always
 	int pair_kernel = 0;    // "pair_kernel": 0 the fast sweep (kernels_pair.hip) where it applies and the table is large, 1 never, 2 wherever it applies
 	int pair_waves = 0;     // "pair_waves": waves per tile pair of k_pair_fused, 0 by table size (kPairSplitMax), 1 | 4
+	bool dense_symmetric = true; // "dense_symmetric": the dense solver reads the upper block triangle of A only (0: rounds 1-3, the whole matrix)
 	bool fast_geometry = true; // "fast_geometry": fused minimum image in the pair sweep, the reference's form only inside a 1e-9 band around the cutoff (0: everywhere)
 	int pair_split = -1;    // "pair_split": two waves per tile pair in the fast sweep (half-length workgroups): -1 by default rule, 0 | 1
 	bool use_panels = true; // "panels": panel form of the Jacobi contraction (orthorhombic cells, stored tensors); 0: one tile pair per workgroup

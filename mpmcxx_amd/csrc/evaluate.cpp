@@ -234,6 +234,9 @@ void mpmc::ext_params(const mpmc_ctx *c, FusedParams &fp, bool wolf_on) {
 }
 
 // two waves per tile pair in the fast pair sweep (half-length workgroups): the default
+// (half-length workgroups shorten the tail a LONE launch drains on: 150 -> 141 us at 10 000 atoms; with 32 evaluations in flight other
+// kernels fill that tail anyway and the doubled table staging costs ~0.4 % of the job rate.  The choice changes the order of a tile
+// pair's sums, so it is NOT made per call: an evaluation gives the same bits alone and inside an ensemble)
 static inline bool sweep_split(const mpmc_ctx *c) { return c->tune.pair_split < 0 ? kSweepSplitDefault : c->tune.pair_split != 0; }
 
 // which pieces of energy() to run
@@ -432,10 +435,11 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		const int want_rrms = (o.polar_rrms || o.polar_precision > 0) ? 1 : 0;
 		const double allowed = by_precision ? o.polar_precision * o.polar_precision * kDebye2SKA * kDebye2SKA : 0.0;
 		const bool dense = (c->solver_used == MPMC_SOLVER_DENSE) && !o.polar_gs;
-		const int iter_slots = dense ? kDenseChunks : c->n_tiles;
+		const bool dense_sym = dense && c->tune.dense_symmetric;
+		const int iter_slots = (dense && !dense_sym) ? kDenseChunks : c->n_tiles;
 		if (dense) { // thole_amatrix into device memory, once per evaluation (the positions changed)
 			ProfScope p(c, MPMC_K_TENSOR);
-			launch_dense_build(st, at, c->box, o.polar_damp, c->d_adense);
+			launch_dense_build(st, at, c->box, o.polar_damp, c->d_adense, dense_sym);
 		}
 		// Precision-terminated Jacobi solves: are_we_done_yet (:3215-3239) runs on the device (ctl = {broke, converged-at, ticket}); the host
 		// enqueues kCheckEvery iterations at a time and reads the verdict once per batch -- the iterations enqueued behind the one that
@@ -494,7 +498,8 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			}
 			if (dense) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
-				launch_dense_matvec(st, c->d_adense, c->n_pad, c->d_mu[c->mu_cur], kDenseChunks, c->d_part);
+				if (dense_sym) launch_dense_symv(st, c->d_adense, c->n_pad, c->d_mu[c->mu_cur], c->d_tile_pairs, c->n_tile_pairs, c->d_part);
+				else launch_dense_matvec(st, c->d_adense, c->n_pad, c->d_mu[c->mu_cur], kDenseChunks, c->d_part);
 			} else if (compact) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
 				if (c->panels_built) // every tile pair through the panel table: two per wave where classes allow

@@ -213,7 +213,9 @@ void launch_rot_selftest(hipStream_t st, int *out);
 
 // ---- dense solver (kernels_dense.hip): the reference's 3N x 3N layout, contraction on the fp64 matrix cores ------------------------
 // a: (3 n_pad)^2 doubles, slot order, diagonal 3x3 blocks and padded slots zero
-void launch_dense_build(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, double *a);
+void launch_dense_build(hipStream_t st, const AtomsDev &at, const Box &bx, double polar_damp, double *a, bool upper_only = false);
+// the symmetric form (default): tile pairs I <= J only, both products per 16 x 16 block; part[source tile][n_pad][3] like the other solvers
+void launch_dense_symv(hipStream_t st, const double *a, int n_pad, const double *x, const int2 *tile_pairs, int n_tile_pairs, double *part);
 // part[chunk][n_pad][3] = - (rows of the chunk of A) . x  (A symmetric); k_dipole_update sums the chunks
 void launch_dense_matvec(hipStream_t st, const double *a, int n_pad, const double *x, int n_chunks, double *part);
 

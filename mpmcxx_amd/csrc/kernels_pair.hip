@@ -46,73 +46,13 @@ struct SweepAcc {
 	double gx, gy, gz; // field on the j-atom this lane is paired with (rotates)
 };
 
-// one step: lane l against j = slot jl of the (doubled) j-tile image
-template <int UM, bool FIELD, int MODE, bool PAD, bool TRI>
-__device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zq, const double2 *__restrict__ s_se,
-                                           const int2 *__restrict__ s_mf, const double2 *__restrict__ s_tab, const int jl, const int lane,
-                                           const SweepI &I, const double shx, const double shy, const double shz, const double t_lo,
-                                           const double t_hi, const Box &bx, const PairSweepParams &pp, const bool half, const bool i_real, const bool store,
-                                           double2 *__restrict__ ab_row /*this step's 64 slots of the tensor store (wave-uniform)*/, SweepAcc &A, int &n_lj,
-                                           int &n_es) {
-	const double2 xy = s_xy[jl], zq = s_zq[jl];
-	int2 mfj = make_int2(0, 0);
-	if (MODE >= 1 || PAD) mfj = s_mf[jl]; // molecule id, flags (padding slots: negative ids, AF_PAD)
-	// lanes that form a real pair at this step: all of them, except in tile pairs with padding slots (PAD: the last tile) and in the
-	// closing half step of a diagonal tile pair (half, wave-uniform: the compiler peels that step)
-	bool ok = true;
-	if (PAD) ok = i_real && (mfj.x >= 0);
-	if (half) ok = ok && (lane < 32);
-	// minimum image (src/System.cpp:1228-1246), diagonal cell: d - B rint(R d); with a tile-pair-wide image index B rint(R d) is shx
-	// general cell (TRI): the translation B^T img mixes the dimensions, so a tile pair has one image for all three (UM = 7, k_classify) or
-	// every pair takes the reference's full form rint(R d), B^T img
-	double ox, oy, oz, ri2;
-	bool in_cut_lj, in_cut_es; // the reference's two cutoff predicates: rimg - 1e-12 < rc (lj :934), !(rimg > rc) (coulombic_real :1490, real_term :2917)
-	auto exact_geometry = [&]() { // the reference's operands in the reference's order, unfused: ri2 decides pair inclusion bit for bit
-		const double dx = I.x - xy.x, dy = I.y - xy.y, dz = I.z - zq.x;
-		if (TRI && UM == 0) {
-			ri2 = min_image_sq<false>(bx, dx, dy, dz, ox, oy, oz);
-		} else {
-			if (UM & 1) ox = dx - shx;
-			else ox = dx - bx.b[0] * rint(bx.r[0] * dx);
-			if (UM & 2) oy = dy - shy;
-			else oy = dy - bx.b[4] * rint(bx.r[4] * dy);
-			if (UM & 4) oz = dz - shz;
-			else oz = dz - bx.b[8] * rint(bx.r[8] * dz);
-			ri2 = ((ox * ox) + oy * oy) + oz * oz;
-		}
-		in_cut_lj = (ri2 <= bx.t_lj);
-		in_cut_es = (ri2 <= bx.t_es);
-	};
-	if (TRI) { // (skewed cells keep the reference's form throughout)
-		exact_geometry();
-	} else {
-		// FAST form (round 4): the i-atom carries the tile pair's common image already (I.xs = x_i - shx per uniform dimension, once per
-		// wave), the remaining dimensions and the squared distance are fused: 6 instead of 11 instructions with three uniform dimensions.
-		// Its ri2 differs from the reference's by a few ulp of the COORDINATES (relative 1e-14 here), which can only change a cutoff
-		// predicate inside the band t_lo .. t_hi = t_es (1 - 1e-9) .. t_lj (1 + 1e-9) around the thresholds (k_classify checks per tile
-		// pair that the coordinates are small enough for that and widens the band to "everything" if not: tp_shift.w).  The two compares the predicates need anyway
-		// are taken against the band's edges: inside t_lo both predicates hold, beyond t_hi neither does, and a step with a lane in
-		// between (about one pair in 1e9) redoes its geometry the reference's way -- pair inclusion stays bit-exact.
-		if (UM & 1) ox = I.xs - xy.x;
-		else {
-			const double dx = I.x - xy.x;
-			ox = fma(-bx.b[0], rint(bx.r[0] * dx), dx);
-		}
-		if (UM & 2) oy = I.ys - xy.y;
-		else {
-			const double dy = I.y - xy.y;
-			oy = fma(-bx.b[4], rint(bx.r[4] * dy), dy);
-		}
-		if (UM & 4) oz = I.zs - zq.x;
-		else {
-			const double dz = I.z - zq.x;
-			oz = fma(-bx.b[8], rint(bx.r[8] * dz), dz);
-		}
-		ri2 = fma(oz, oz, fma(oy, oy, ox * ox));
-		const bool inside = (ri2 <= t_lo), maybe = (ri2 <= t_hi);
-		in_cut_lj = in_cut_es = inside;
-		if (__any(ok && maybe && !inside)) exact_geometry();
-	}
+// what follows the geometry of a step: exclusions, the Thole tensor store, the inclusion predicates and their counts, LJ / Coulomb / field
+template <bool FIELD, int MODE, bool PAD>
+__device__ __forceinline__ void sweep_finish(const double2 *__restrict__ s_se, const double2 *__restrict__ s_tab, const int jl, const int lane,
+                                             const SweepI &I, const double2 zq, const int2 mfj, const bool ok, const double ox, const double oy,
+                                             const double oz, const double ri2, const unsigned long long m_cut_lj, const unsigned long long m_cut_es, const Box &bx,
+                                             const PairSweepParams &pp, const bool half, const bool store, double2 *__restrict__ ab_row, SweepAcc &A,
+                                             int &n_lj, int &n_es) {
 	const double ir = fast_rsqrt_1(ri2);
 	const double r = ri2 * ir;
 	// pair_exclusions (src/System.cpp:1035-1197) for what this grade of tile pair can hold:
@@ -151,11 +91,15 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 
 	// the inclusion predicates, and the counts of the pairs they admit: wave-level masks and popcounts (scalar unit), taken OUTSIDE the
 	// divergent region.  t_es <= t_lj (pair_math.h Box), so the Coulomb pairs are a subset of the LJ shell.
-	const bool in_lj = ok && !frozen && in_cut_lj; // rimg - 1e-12 < rc  (lj :934)
-	const bool in_es = ok && !frozen && in_cut_es; // (implies in_lj)  !(rimg > rc)  (coulombic_real :1490, real_term :2917)
-	const bool lj_on = in_lj && !excl_rd, es_on = in_es && !excl_es;
-	n_lj += __popcll(__builtin_amdgcn_ballot_w64(lj_on));
-	n_es += __popcll(__builtin_amdgcn_ballot_w64(es_on));
+	// (m_cut_*: the cutoff predicates of the real pairs of this step as wave masks, from sweep_step; masks combine on the scalar unit, and in
+	// MODE 0 -- no exclusions -- they ARE the masks of the admitted pairs)
+	const unsigned long long m_in_lj = m_cut_lj & ~__builtin_amdgcn_ballot_w64(frozen); // rimg - 1e-12 < rc  (lj :934)
+	const unsigned long long m_in_es = m_cut_es & ~__builtin_amdgcn_ballot_w64(frozen); // (implies in_lj)  !(rimg > rc)  (coulombic_real :1490, real_term :2917)
+	const unsigned long long m_lj_on = m_in_lj & ~__builtin_amdgcn_ballot_w64(excl_rd), m_es_on = m_in_es & ~__builtin_amdgcn_ballot_w64(excl_es);
+	n_lj += __popcll(m_lj_on);
+	n_es += __popcll(m_es_on);
+	const bool in_lj = __builtin_amdgcn_inverse_ballot_w64(m_in_lj), in_es = __builtin_amdgcn_inverse_ballot_w64(m_in_es);
+	const bool lj_on = __builtin_amdgcn_inverse_ballot_w64(m_lj_on), es_on = __builtin_amdgcn_inverse_ballot_w64(m_es_on);
 	asm volatile("" : "+s"(n_lj), "+s"(n_es)); // (the sums are wanted HERE, in scalar registers: sunk behind the divergent region the masks make a round trip through VGPRs)
 	if (in_lj) {
 		const double2 se = s_se[jl];
@@ -198,6 +142,82 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 	}
 }
 
+// one step: lane l against j = slot jl of the (doubled) j-tile image
+template <int UM, bool FIELD, int MODE, bool PAD, bool TRI>
+__device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zq, const double2 *__restrict__ s_se,
+                                           const int2 *__restrict__ s_mf, const double2 *__restrict__ s_tab, const int jl, const int lane,
+                                           const SweepI &I, const double shx, const double shy, const double shz, const double t_lo,
+                                           const double t_hi, const Box &bx, const PairSweepParams &pp, const bool half, const bool i_real, const bool store,
+                                           double2 *__restrict__ ab_row /*this step's 64 slots of the tensor store (wave-uniform)*/, SweepAcc &A, int &n_lj,
+                                           int &n_es) {
+	const double2 xy = s_xy[jl], zq = s_zq[jl];
+	int2 mfj = make_int2(0, 0);
+	if (MODE >= 1 || PAD) mfj = s_mf[jl]; // molecule id, flags (padding slots: negative ids, AF_PAD)
+	// lanes that form a real pair at this step: all of them, except in tile pairs with padding slots (PAD: the last tile) and in the
+	// closing half step of a diagonal tile pair (half, wave-uniform: sweep_walk spells that step out)
+	bool ok = true;
+	if (PAD) ok = i_real && (mfj.x >= 0);
+	if (half) ok = ok && (lane < 32);
+	// minimum image (src/System.cpp:1228-1246), diagonal cell: d - B rint(R d); with a tile-pair-wide image index B rint(R d) is shx
+	// general cell (TRI): the translation B^T img mixes the dimensions, so a tile pair has one image for all three (UM = 7, k_classify) or
+	// every pair takes the reference's full form rint(R d), B^T img
+	double ox, oy, oz, ri2;
+	// the reference's two cutoff predicates -- rimg - 1e-12 < rc (lj :934), !(rimg > rc) (coulombic_real :1490, real_term :2917) -- of the
+	// real pairs of this step, as WAVE MASKS in scalar registers (two predicates that were merged behind a branch as per-lane booleans would travel
+	// through vector registers; a mask is a scalar value and merges for free)
+	unsigned long long m_lj, m_es;
+	auto exact_geometry = [&]() { // the reference's operands in the reference's order, unfused: ri2 decides pair inclusion bit for bit
+		const double dx = I.x - xy.x, dy = I.y - xy.y, dz = I.z - zq.x;
+		if (TRI && UM == 0) {
+			ri2 = min_image_sq<false>(bx, dx, dy, dz, ox, oy, oz);
+		} else {
+			if (UM & 1) ox = dx - shx;
+			else ox = dx - bx.b[0] * rint(bx.r[0] * dx);
+			if (UM & 2) oy = dy - shy;
+			else oy = dy - bx.b[4] * rint(bx.r[4] * dy);
+			if (UM & 4) oz = dz - shz;
+			else oz = dz - bx.b[8] * rint(bx.r[8] * dz);
+			ri2 = ((ox * ox) + oy * oy) + oz * oz;
+		}
+		m_lj = __builtin_amdgcn_ballot_w64(ok && ri2 <= bx.t_lj);
+		m_es = __builtin_amdgcn_ballot_w64(ok && ri2 <= bx.t_es);
+	};
+	if (TRI) { // (skewed cells keep the reference's form throughout)
+		exact_geometry();
+	} else {
+		// FAST form (round 4): the i-atom carries the tile pair's common image already (I.xs = x_i - shx per uniform dimension, once per
+		// wave), the remaining dimensions and the squared distance are fused: 6 instead of 11 instructions with three uniform dimensions.
+		// Its ri2 differs from the reference's by a few ulp of the COORDINATES (relative 1e-14 here), which can only change a cutoff
+		// predicate inside the band t_lo .. t_hi = t_es (1 - 1e-9) .. t_lj (1 + 1e-9) around the thresholds (k_classify checks per tile
+		// pair that the coordinates are small enough for that and widens the band to "everything" if not: tp_shift.w).  The two compares
+		// the predicates need anyway are taken against the band's edges: inside t_lo both predicates hold, beyond t_hi neither does, and a
+		// step with a lane in between (about one pair in 1e9) redoes its geometry the reference's way -- pair inclusion stays bit-exact.
+		if (UM & 1) ox = I.xs - xy.x;
+		else {
+			const double dx = I.x - xy.x;
+			ox = fma(-bx.b[0], rint(bx.r[0] * dx), dx);
+		}
+		if (UM & 2) oy = I.ys - xy.y;
+		else {
+			const double dy = I.y - xy.y;
+			oy = fma(-bx.b[4], rint(bx.r[4] * dy), dy);
+		}
+		if (UM & 4) oz = I.zs - zq.x;
+		else {
+			const double dz = I.z - zq.x;
+			oz = fma(-bx.b[8], rint(bx.r[8] * dz), dz);
+		}
+		ri2 = fma(oz, oz, fma(oy, oy, ox * ox));
+		m_lj = m_es = __builtin_amdgcn_ballot_w64(ok && ri2 <= t_lo);
+		// (t_lo < t_hi: some lane lies in between exactly when the two masks differ)
+		if (__builtin_expect(__builtin_amdgcn_ballot_w64(ok && ri2 <= t_hi) != m_lj, 0)) {
+			asm volatile("" ::: "memory"); // (a real branch: the compiler must not run the reference's form speculatively and select)
+			exact_geometry();
+		}
+	}
+	sweep_finish<FIELD, MODE, PAD>(s_se, s_tab, jl, lane, I, zq, mfj, ok, ox, oy, oz, ri2, m_lj, m_es, bx, pp, half, store, ab_row, A, n_lj, n_es);
+}
+
 template <int UM, bool FIELD, int MODE, bool PAD, bool TRI = false>
 __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, const double2 *__restrict__ s_zq, const double2 *__restrict__ s_se,
                                         const int2 *__restrict__ s_mf, const double2 *__restrict__ s_tab, const int lane, const SweepI &I,
@@ -207,16 +227,19 @@ __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, con
 	// diagonal tile pair: s = 1..32, the last one with lanes 0..31 only (each pair once); off-diagonal: s = 0..63.  A wave walks the
 	// steps [s_begin, s_end) of that sequence: all of them, or one half of them when two waves share a tile pair (pp.split);
 	// tail_half: this wave's last step is the diagonal tile pair's closing half step
-	for (int s = s_begin; s < s_end; ++s) {
-		const bool last = (s == s_end - 1);
-		sweep_step<UM, FIELD, MODE, PAD, TRI>(s_xy, s_zq, s_se, s_mf, s_tab, lane + s, lane, I, shx, shy, shz, t_lo, t_hi, bx, pp, tail_half && last, i_real, store,
+	// (the closing step is spelled out: inside the loop "half" is a compile-time false and costs nothing)
+	for (int s = s_begin; s < s_end - 1; ++s) {
+		sweep_step<UM, FIELD, MODE, PAD, TRI>(s_xy, s_zq, s_se, s_mf, s_tab, lane + s, lane, I, shx, shy, shz, t_lo, t_hi, bx, pp, false, i_real, store,
 		                                  ab_tile + s * kTile, A, n_lj, n_es);
-		if (FIELD && !last) {
+		if (FIELD) {
 			A.gx = rot_from_next(A.gx);
 			A.gy = rot_from_next(A.gy);
 			A.gz = rot_from_next(A.gz);
 		}
 	}
+	const int s = s_end - 1;
+	sweep_step<UM, FIELD, MODE, PAD, TRI>(s_xy, s_zq, s_se, s_mf, s_tab, lane + s, lane, I, shx, shy, shz, t_lo, t_hi, bx, pp, tail_half, i_real, store,
+	                                  ab_tile + s * kTile, A, n_lj, n_es);
 }
 
 // blocks: { J, I0 } -- the workgroup's waves take the tile pairs (I0 + w, J), w = 0..3, as far as I0 + w <= J

@@ -142,7 +142,8 @@ def lib():
     L.mpmc_comm_allgather_f64.argtypes = [vp, dp, C.c_int64, dp]
     L.mpmc_pi_gather_beads.argtypes = [vp, dp, C.c_int, C.c_int, dp]
     L.mpmc_pi_allreduce.argtypes = [C.POINTER(vp), C.c_int, dp, C.POINTER(Result), C.POINTER(C.c_int)]
-    L.mpmc_pi_allreduce_info.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    if hasattr(L, "mpmc_pi_allreduce_info") or not os.environ.get("MPMC_ENERGY_LIB"):  # (an older build under the A/B override lacks the ABI-5 entry)
+        L.mpmc_pi_allreduce_info.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mpmc_debug_configure.argtypes = [vp, C.c_char_p, C.c_double]
     L.mpmc_debug_last_pair_kernel.argtypes = [vp]
     L.mpmc_debug_last_trial_was_full.argtypes = [vp]

@@ -142,3 +142,49 @@ def test_run_to_run_determinism_of_the_sweep(force_sweep):
     assert S.last_pair_kernel() == "sweep"
     assert e[0] == e[1] == e[2] == e[3]
     S.close()
+
+
+def _pairs_on_the_cutoff(offset=0.0):
+    """ion1000_polar with 24 atoms moved so that 24 pairs sit AT the cutoff: r = r_c (1 + delta) for delta from 0 to +-1e-9, i.e. inside the
+    band in which the sweep's fused geometry defers to the reference's form (kernels_pair.hip: sweep_step), and just outside it."""
+    atoms, basis, opts = util.load_fixture("ion1000_polar")
+    pos = atoms["pos"].copy()
+    rc = 0.5 * basis[0, 0]
+    rng = np.random.default_rng(42)
+    deltas = [0.0, 1e-16, -1e-16, 3e-16, -3e-16, 1e-15, -1e-15, 1e-14, -1e-14, 1e-13, -1e-13, 6e-13, -6e-13, 1e-12, -1e-12, 1e-11, -1e-11,
+              1e-10, -1e-10, 5e-10, -5e-10, 9e-10, 2e-9, -2e-9]
+    for k, d in enumerate(deltas):
+        i, j = 40 * k, 40 * k + 17
+        u = rng.normal(size=3)
+        u /= np.linalg.norm(u)
+        pos[j] = pos[i] + u * rc * (1.0 + d)
+    return dict(atoms, pos=pos + offset), basis, opts
+
+
+@pytest.mark.parametrize("offset", [0.0, 777.125, 3.0e6])
+def test_pairs_on_the_cutoff_are_counted_like_the_reference(offset, force_sweep):
+    """pair inclusion is bit-exact with the fused geometry too: a step with a pair inside the 1e-9 band around the cutoff thresholds redoes
+    its geometry in the reference's operation order; coordinates far from the origin (3e6 A: the band becomes "everything")."""
+    from oracle import OracleSystem
+
+    atoms, basis, opts = _pairs_on_the_cutoff(offset)
+    ref = OracleSystem(atoms, basis, opts).energy()
+    res = {}
+    for fast in (1, 0):
+        energy.configure("fast_geometry", fast)
+        try:
+            S = energy.System(atoms, basis, opts)
+        finally:
+            energy.configure("fast_geometry", 1)
+        S.energy()
+        assert S.last_pair_kernel() == "sweep"
+        res[fast] = dict(S.observables)
+        S.close()
+    for fast in (1, 0):
+        r = res[fast]
+        assert int(r["n_lj_in_cutoff"]) == int(ref["n_lj_in_cutoff"]) and int(r["n_es_in_cutoff"]) == int(ref["n_es_in_cutoff"]), (fast, offset)
+        tol = 1e-9 if offset < 1e6 else 1e-7  # (3e6 A from the origin the coordinates themselves carry 5e-10 A)
+        for k in ("rd_energy", "coulombic_energy", "polarization_energy", "energy"):
+            assert abs(r[k] - ref[k]) <= tol * max(abs(ref[k]), 1e-3 * abs(ref["energy"])), (fast, offset, k, r[k], ref[k])
+    for k in ("lj_pairs", "es_real", "polarization_energy"):
+        assert abs(res[1][k] - res[0][k]) <= 1e-13 * max(abs(res[0][k]), 1e-3 * abs(res[0]["energy"])), (offset, k)

@@ -167,6 +167,25 @@ def test_every_dipole_solver_reproduces_the_reference(name, solver):
     S.close()
 
 
+@pytest.mark.parametrize("name", ["ion216_polar", "ion1000_polar", "ion216_triclinic"])
+def test_dense_solver_symmetric_and_whole_matrix_forms_agree(name):
+    """round 4: the dense contraction reads the upper block triangle of A and forms both products per block; rounds 1-3 read all of A."""
+    atoms, basis, opts = util.load_fixture(name)
+    res = {}
+    for sym in (1, 0):
+        energy.configure("dense_symmetric", sym)
+        try:
+            S = energy.System(atoms, basis, dict(opts, solver="dense"))
+        finally:
+            energy.configure("dense_symmetric", 1)
+        S.energy()
+        res[sym] = (dict(S.observables), S.dipoles())
+        S.close()
+    assert abs(res[1][0]["polarization_energy"] - res[0][0]["polarization_energy"]) <= 1e-12 * abs(res[0][0]["polarization_energy"])
+    for a, b in zip(res[1][1], res[0][1]):
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+
+
 def test_run_to_run_determinism():
     S, *_ = make("ion1000_polar")
     vals = [S.energy() for _ in range(3)]
