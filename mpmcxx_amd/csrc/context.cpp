@@ -861,6 +861,10 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 		t.pair_waves = v;
 	} else if (k == "fast_geometry") t.fast_geometry = on;
 	else if (k == "dense_symmetric") t.dense_symmetric = on;
+	else if (k == "side_after_sweep") t.side_after_sweep = on;
+	else if (k == "poll_long") t.poll_long = on;
+	else if (k == "poll_retire") t.poll_retire = on;
+	else if (k == "tail_fused") t.tail_fused = on;
 	else if (k == "pair_split") {
 		if (v < -1 || v > 1) return MPMC_ERR_ARG;
 		t.pair_split = v;

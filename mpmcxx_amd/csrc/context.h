@@ -36,6 +36,10 @@ struct mpmc_tuning {
 	int stream_mode = -1;   // "side_stream": -1 by table size (kOneStreamMaxPairs), 0 never fork the side stream, 1 always
 	int pair_kernel = 0;    // "pair_kernel": 0 the fast sweep (kernels_pair.hip) where it applies and the table is large, 1 never, 2 wherever it applies
 	int pair_waves = 0;     // "pair_waves": waves per tile pair of k_pair_fused, 0 by table size (kPairSplitMax), 1 | 4
+	bool side_after_sweep = true; // "side_after_sweep": two streams: the side stream's kernels are enqueued behind the pair sweep's launch (0: in front, rounds 1-3)
+	bool poll_retire = true;      // "poll_retire": a polled-for evaluation queries its streams afterwards so that the runtime retires the finished commands
+	bool poll_long = true;        // "poll_long": evaluations of large tables are polled for before the wait synchronises the stream (0: rounds 1-3)
+	bool tail_fused = true;       // "tail_fused": polarization energy and the fold of the pair partials in one launch (0: the fold forks the side stream)
 	bool dense_symmetric = true; // "dense_symmetric": the dense solver reads the upper block triangle of A only (0: rounds 1-3, the whole matrix)
 	bool fast_geometry = true; // "fast_geometry": fused minimum image in the pair sweep, the reference's form only inside a 1e-9 band around the cutoff (0: everywhere)
 	int pair_split = -1;    // "pair_split": two waves per tile pair in the fast sweep (half-length workgroups): -1 by default rule, 0 | 1
@@ -152,6 +156,7 @@ struct mpmc_ctx {
 	double h_static[3] = {0, 0, 0}; // lrc_pair, lrc_self, es_self
 	int *d_counter = nullptr;       // ticket counter of the single-launch small-system kernels (zero between launches)
 	bool scal_clean = false;        // d_scal is all zeros (the post kernel of the last evaluation left it so): no clear needed in front of this one
+	int poll_budget_us = 1000;      // ... for at most this long before the wait falls back to hipStreamSynchronize
 	bool spin_on_post = false;      // the pending evaluation ends in k_post_results and is short: wait_and_fill polls the launch number first
 	bool last_was_single = false;   // the pending evaluation wrote h_scal from the device: nothing to copy back
 	double single_seq = 0;          // launch number the single-launch kernel posts behind its results (host polls h_scal[S_COUNT + C_COUNT])

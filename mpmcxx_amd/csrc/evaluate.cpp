@@ -300,8 +300,10 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	c->two_streams = (c->tune.stream_mode == 1) || (c->tune.stream_mode < 0 && c->n_tile_pairs > kOneStreamMaxPairs);
 	const bool side_fork = c->two_streams && (need_sf || need_intra);
 	bool panel_side = false; // the panel table of the Jacobi contraction is being built on the side stream
-	if (side_work) {
-		hipStream_t s2 = side_fork ? fork_side(c) : st;
+	// (two streams: enqueued BEHIND the pair sweep -- the main stream's critical path (classes, sweep) reaches the device first; one
+	// evaluation at a time the host used to be ~15 us late with the sweep because nine API calls of side work stood in front of it)
+	int side_rc = MPMC_OK;
+	auto enqueue_side_work = [&](hipStream_t s2) {
 		if (need_intra) {
 			ProfScope p(c, MPMC_K_PAIR, s2);
 			launch_intra_terms(s2, at, c->d_slot_of, c->ewald_alpha, c->d_scal);
@@ -313,7 +315,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				if (rcp.lvec && o.ewald_kmax <= kRecipTabMaxK && need_part > c->cap_sf_part) {
 					dev_free(c, &c->d_sf_part, c->cap_sf_part);
 					c->cap_sf_part = 0;
-					if ((rc = dev_alloc(c, &c->d_sf_part, need_part)) != MPMC_OK) return rc;
+					if ((side_rc = dev_alloc(c, &c->d_sf_part, need_part)) != MPMC_OK) return;
 					c->cap_sf_part = need_part;
 				}
 				launch_recip_sf(s2, at, c->box, rcp, o.ewald_kmax, c->d_sf_part);
@@ -324,6 +326,11 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			ProfScope p(c, MPMC_K_FIELD, s2);
 			launch_field_recip(s2, at, c->box, rcp, o.ewald_kmax, c->d_e_recip_part);
 		}
+	};
+	const bool side_deferred = side_work && side_fork && (mask & (RUN_PAIR | RUN_FIELD | RUN_STORE)) != 0 && c->tune.side_after_sweep;
+	if (side_work && !side_deferred) {
+		enqueue_side_work(side_fork ? fork_side(c) : st);
+		if (side_rc != MPMC_OK) return side_rc;
 	}
 
 	// ---- pairwise pass: one symmetric sweep (energies + counts, static-field partials, Thole tensor store) ----------
@@ -382,14 +389,16 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				}
 			}
 			// the table is needed by the first Jacobi launch only: it is made beside the pair sweep (side stream, joined after the sweep)
-			hipStream_t sp = c->two_streams ? fork_side(c) : st;
 			panel_side = c->two_streams;
-			{
-				ProfScope pc(c, MPMC_K_CLASSES, sp);
-				launch_build_panels(sp, c->d_cls, c->n_tiles, c->d_seg, c->d_panels);
+			if (!panel_side) {
+				ProfScope pc(c, MPMC_K_CLASSES, st);
+				launch_build_panels(st, c->d_cls, c->n_tiles, c->d_seg, c->d_panels);
 			}
 			c->panels_built = true;
 		}
+		// the side stream starts behind the classes (what it reads of the main stream's work: positions, classes); its kernels are
+		// enqueued after the sweep's launch call
+		hipStream_t s_side = (side_deferred || panel_side) ? fork_side(c) : st;
 		c->last_fp = fp;
 		c->last_fp_valid = !fp.store_only;
 		ProfScope p(c, MPMC_K_PAIR);
@@ -410,11 +419,24 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		} else if (!(fp.store_only && !compact)) // (a store-only pass without a store to fill has nothing to do beyond the classes)
 			launch_pair_fused(st, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_part,
 			                  compact ? c->d_ab : nullptr);
+		if (side_deferred) {
+			enqueue_side_work(s_side);
+			if (side_rc != MPMC_OK) return side_rc;
+		}
+		if (panel_side) {
+			ProfScope pc(c, MPMC_K_CLASSES, s_side);
+			launch_build_panels(s_side, c->d_cls, c->n_tiles, c->d_seg, c->d_panels);
+		}
 	}
 	if ((side_work && side_fork) || panel_side) join_side(c);
+	// the scalar totals of the sweep are only read back at the very end.  Polarizable evaluations on two streams fold them in the launch
+	// that closes the evaluation (second block of the polarization-energy kernel: launch_polar_energy_and_pairs) -- rounds 2-3 forked the
+	// side stream for it, which put an event record in front of the static field and a join in front of the posted results (~10 us of
+	// barrier packets on the main stream, one evaluation at a time)
+	const bool reduce_in_tail = (mask & RUN_PAIR) && (mask & RUN_SOLVE) && c->two_streams && c->tune.tail_fused;
 	bool reduce_forked = false;
-	if (mask & RUN_PAIR) { // the scalar totals of the sweep are only read back at the very end: fold them beside the field / dipole work
-		reduce_forked = c->two_streams && (mask & RUN_FIELD) != 0;
+	if ((mask & RUN_PAIR) && !reduce_in_tail) {
+		reduce_forked = c->two_streams && (mask & RUN_FIELD) != 0; // (tail_fused = 0: the rounds 2-3 arrangement)
 		hipStream_t s3 = reduce_forked ? fork_side(c) : st;
 		ProfScope p(c, MPMC_K_REDUCE, s3);
 		launch_reduce_pairs(s3, c->d_block_part, c->d_block_cnt, c->n_tile_pairs, c->d_scal, c->d_cnt);
@@ -553,7 +575,10 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		c->iters = it;
 		{
 			ProfScope p(c, MPMC_K_REDUCE);
-			launch_polar_energy(st, at, c->d_mu[c->mu_cur], c->d_e_static, want_rrms ? c->d_rrms : nullptr, c->d_scal);
+			if (reduce_in_tail)
+				launch_polar_energy_and_pairs(st, at, c->d_mu[c->mu_cur], c->d_e_static, want_rrms ? c->d_rrms : nullptr, c->d_block_part, c->d_block_cnt,
+				                              c->n_tile_pairs, c->d_scal, c->d_cnt);
+			else launch_polar_energy(st, at, c->d_mu[c->mu_cur], c->d_e_static, want_rrms ? c->d_rrms : nullptr, c->d_scal);
 		}
 		c->have_polar = true;
 	}
@@ -567,7 +592,10 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	c->scal_clean = true;
 	// short evaluations are polled for (a few us against ~10-15 for the synchronisation); long ones, and profiled ones (the event
 	// harvest needs an idle stream), are waited for the ordinary way
-	c->spin_on_post = (c->n_tile_pairs <= kOneStreamMaxPairs) && c->ev_used.empty();
+	// (round 4: long evaluations are polled for as well, with a budget of a few of their own durations -- one evaluation at a time the
+	// posted launch number is seen ~10 us before hipStreamSynchronize returns; an ensemble's first wait outlasts the budget and synchronises)
+	c->spin_on_post = c->ev_used.empty() && (c->tune.poll_long || c->n_tile_pairs <= kOneStreamMaxPairs);
+	c->poll_budget_us = (c->n_tile_pairs <= kOneStreamMaxPairs) ? 1000 : 4000;
 	c->pending = true;
 	return MPMC_OK;
 }
@@ -657,11 +685,17 @@ int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 		// microseconds before the driver's own completion path would; past the budget, or if anything is off, fall back to the sync
 		volatile const double *flag = c->h_scal + S_COUNT + C_COUNT;
 		const double want = c->single_seq;
-		seen = poll_posted(c, [&] { return *flag == want; }, std::chrono::microseconds(c->last_was_single ? 200 : 1000));
+		seen = poll_posted(c, [&] { return *flag == want; }, std::chrono::microseconds(c->last_was_single ? 200 : c->poll_budget_us));
 	}
 	if (!seen) {
 		c->n_stream_syncs++;
 		HIP_TRY(c, hipStreamSynchronize(c->sync_stream ? c->sync_stream : c->stream));
+	} else if (c->tune.poll_retire) {
+		// the results are in, but the runtime has not been told: a stream that is never synchronised keeps its finished commands, and
+		// the next asynchronous copy on it pays for the backlog (measured with positions handed over in host memory: 900 against 966
+		// evaluations/s).  A query is enough to let it retire them.
+		(void)hipStreamQuery(c->stream);
+		if (c->two_streams) (void)hipStreamQuery(c->stream2);
 	}
 	c->sync_stream = nullptr;
 	c->pending = false;

@@ -157,7 +157,7 @@ struct PairSweepParams {
 // -5 % at 7000, -9 % at 10 000; 32 beads in flight the sweep wins from 3000 atoms on (+4 % evaluations/s, +4.5 % at 5000, +9 % at 7000).
 constexpr int kSweepMinPairs = 2048;
 // two waves per tile pair (half the steps each; kernels_pair.hip): measured in round 4, see DESIGN section 3
-constexpr bool kSweepSplitDefault = true;
+constexpr bool kSweepSplitDefault = false;
 // host: the device layout of the erfc table, 3 * 512 double2 = (c0,c1)[512], (c2,c3)[512], (c4,G)[512]  (erfc_table.cpp)
 constexpr int kErfTableDouble2 = 3 * 512;
 void erfc_table_device_layout(double2 *out /*[kErfTableDouble2]*/);
@@ -173,6 +173,9 @@ void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const 
                        const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab, bool split = false,
                        bool fast_geometry = false);
 void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt);
+// polarizable evaluations: launch_polar_energy and launch_reduce_pairs as the two blocks of one launch (the tail of the evaluation)
+void launch_polar_energy_and_pairs(hipStream_t st, const AtomsDev &at, const double *mu, const double *e_static, const double *rrms_atom,
+                                   const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt);
 // LJ (+ counts) of a small system in ONE launch: no tile classes, the last-arriving block folds the partials and writes the scalar
 // vector [S_COUNT doubles][C_COUNT int64][seq] into pinned host memory (seq last: a host polling that slot finds the results
 // complete); `counter` is a zeroed int the kernel leaves zeroed

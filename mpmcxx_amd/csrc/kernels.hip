@@ -35,8 +35,8 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh) {
 // ------------------------------------------------------------------------------------------------------
 // fixed-order final reduction of the per-tile-pair partials of k_pair_fused: {lj, es_real} and {n_lj, n_es}
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reduce_pairs(const double *__restrict__ block_part, const int *__restrict__ block_cnt, int nb,
-                                                      double *__restrict__ scal, long long *__restrict__ cnt) {
+__device__ __forceinline__ void reduce_pairs_block(const double *__restrict__ block_part, const int *__restrict__ block_cnt, int nb,
+                                                   double *__restrict__ scal, long long *__restrict__ cnt) {
 	__shared__ double sh[4];
 	__shared__ long long shc[256];
 	double s0 = 0, s1 = 0;
@@ -64,6 +64,10 @@ __global__ __launch_bounds__(256) void k_reduce_pairs(const double *__restrict__
 		}
 		if (threadIdx.x == 0) cnt[k ? C_ES_IN : C_LJ_IN] = shc[0];
 	}
+}
+__global__ __launch_bounds__(256) void k_reduce_pairs(const double *__restrict__ block_part, const int *__restrict__ block_cnt, int nb,
+                                                      double *__restrict__ scal, long long *__restrict__ cnt) {
+	reduce_pairs_block(block_part, block_cnt, nb, scal, cnt);
 }
 
 // position-independent pair flags (reference pair_exclusions :1035-1067): one wave per tile pair, broadcast j loop
@@ -623,6 +627,16 @@ __global__ __launch_bounds__(256) void k_polar_energy(AtomsDev at, const double 
 	polar_energy_block(at, mu, e_static, rrms_atom, scal);
 }
 
+// the tail of a polarizable evaluation in ONE launch: block 0 the polarization energy, block 1 the fold of the pair sweep's partials (both
+// single-block, fixed-order sums; the fold used to run on the side stream, whose fork and join each cost the main stream a barrier packet)
+__global__ __launch_bounds__(256) void k_polar_energy_and_pairs(AtomsDev at, const double *__restrict__ mu, const double *__restrict__ e_static,
+                                                                const double *__restrict__ rrms_atom, const double *__restrict__ block_part,
+                                                                const int *__restrict__ block_cnt, int nb, double *__restrict__ scal,
+                                                                long long *__restrict__ cnt) {
+	if (blockIdx.x == 0) polar_energy_block(at, mu, e_static, rrms_atom, scal);
+	else reduce_pairs_block(block_part, block_cnt, nb, scal, cnt);
+}
+
 void launch_dipole_update(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, int n_split, const double *mu_old,
                           double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr, int *ctl, int *host_flag, int it) {
 	hipLaunchKernelGGL(k_dipole_update, dim3(at.n_pad / kTile), dim3(kTile * kSlotGroups), 0, st, at, e_static, part, n_split, mu_old, mu_new,
@@ -633,6 +647,10 @@ void launch_dipole_reset(hipStream_t st, const AtomsDev &at, const double *e_sta
 }
 void launch_polar_energy(hipStream_t st, const AtomsDev &at, const double *mu, const double *e_static, const double *rrms_atom, double *scal) {
 	hipLaunchKernelGGL(k_polar_energy, dim3(1), dim3(256), 0, st, at, mu, e_static, rrms_atom, scal);
+}
+void launch_polar_energy_and_pairs(hipStream_t st, const AtomsDev &at, const double *mu, const double *e_static, const double *rrms_atom,
+                                   const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt) {
+	hipLaunchKernelGGL(k_polar_energy_and_pairs, dim3(2), dim3(256), 0, st, at, mu, e_static, rrms_atom, block_part, block_cnt, nb, scal, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------------

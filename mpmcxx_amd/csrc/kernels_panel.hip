@@ -459,33 +459,28 @@ __global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDe
 			mo[p] = mu_old[3 * (size_t)i + p];
 		}
 	}
-	// two plain strided walks (i-side slots, then j-side slots), eight slots of a group requested together so that their loads are in
-	// flight at once: the kernel is a latency chain otherwise (fewer workgroups than CUs; round 4: 7.3 -> see DESIGN).  The order of the
-	// sums is fixed by (g, t) alone -- ascending t within a group, as before: padding terms are exact zeros.
+	// two plain strided walks (i-side slots, then j-side slots) so that the loads of an unrolled group are independent and in flight
+	// together: the kernel is a latency chain otherwise (fewer workgroups than CUs).  The order of the sums is fixed by (g, t) alone.
+	// (Round 4 tried batches of eight predicated loads per group: more loads in flight, but the padding loads cost more than the latency
+	// they hide -- 8.5 against 7.4 us in rocprofv3's trace -- and was taken back.)
 	double f[3] = {0, 0, 0};
-	constexpr int kUpdBatch = 8;
-	auto walk = [&](const double *base, const size_t stride, const int n) {
-		for (int t0 = g; t0 < n; t0 += kUpdGroups * kUpdBatch) {
-			double v[kUpdBatch][3];
-#pragma unroll
-			for (int u = 0; u < kUpdBatch; ++u) {
-				const int t = t0 + u * kUpdGroups;
-				const double *q = base + (size_t)(t < n ? t : t0) * stride;
-				v[u][0] = q[0];
-				v[u][1] = q[1];
-				v[u][2] = q[2];
-			}
-#pragma unroll
-			for (int u = 0; u < kUpdBatch; ++u) {
-				const bool in = (t0 + u * kUpdGroups < n);
-				f[0] += in ? v[u][0] : 0.0;
-				f[1] += in ? v[u][1] : 0.0;
-				f[2] += in ? v[u][2] : 0.0;
-			}
-		}
-	};
-	walk(part + ((size_t)X * at.n_pad + i) * 3, (size_t)at.n_pad * 3, nF);
-	walk(gpart + ((size_t)wg0 * kTile + a) * 3, (size_t)kTile * 3, nG);
+	const double *pf = part + ((size_t)X * at.n_pad + i) * 3;
+	const size_t sf = (size_t)at.n_pad * 3;
+#pragma unroll 4
+	for (int t = g; t < nF; t += kUpdGroups) {
+		const double *q = pf + (size_t)t * sf;
+		f[0] += q[0];
+		f[1] += q[1];
+		f[2] += q[2];
+	}
+	const double *pg = gpart + ((size_t)wg0 * kTile + a) * 3;
+#pragma unroll 4
+	for (int t = g; t < nG; t += kUpdGroups) {
+		const double *q = pg + (size_t)t * (kTile * 3);
+		f[0] += q[0];
+		f[1] += q[1];
+		f[2] += q[2];
+	}
 	sh[g][a][0] = f[0];
 	sh[g][a][1] = f[1];
 	sh[g][a][2] = f[2];

@@ -40,7 +40,12 @@ from mpmcxx_amd import energy  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "ion216_polar"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-atoms, basis, opts = util.load_fixture(name)
+if name in util.LARGE:  # (the 10 000-atom boxes are regenerated, not committed)
+    import tempfile
+
+    atoms, basis, opts = util.load_generated(name, tempfile.mkdtemp())
+else:
+    atoms, basis, opts = util.load_fixture(name)
 S = energy.System(atoms, basis, opts)
 if len(sys.argv) > 3 and sys.argv[3] == "volume":  # us per volume move (NPT / Gibbs): set_box with scaled positions + full evaluation
     import numpy as np
