@@ -188,3 +188,28 @@ def test_pairs_on_the_cutoff_are_counted_like_the_reference(offset, force_sweep)
             assert abs(r[k] - ref[k]) <= tol * max(abs(ref[k]), 1e-3 * abs(ref["energy"])), (fast, offset, k, r[k], ref[k])
     for k in ("lj_pairs", "es_real", "polarization_energy"):
         assert abs(res[1][k] - res[0][k]) <= 1e-13 * max(abs(res[0][k]), 1e-3 * abs(res[0]["energy"])), (offset, k)
+
+
+@pytest.mark.parametrize("name", ["ion1000_polar", "water64_polar", "ion216_framework", "ion1000_triclinic", "ion216_frozen"])
+def test_two_waves_per_tile_pair_form(name, force_sweep):
+    """pair_split = 1 (round 4; off by default: it shortens a lone launch's tail and costs 0.7 % with 32 beads in flight): two waves share
+    a tile pair, half the steps each, and meet in LDS -- the reference's numbers, and the one-wave form's to rounding."""
+    g = util.golden(name)
+    atoms, basis, opts = util.load_fixture(name)
+    res = {}
+    for split in (1, 0):
+        energy.configure("pair_split", split)
+        try:
+            S = energy.System(atoms, basis, opts)
+        finally:
+            energy.configure("pair_split", -1)
+        S.energy()
+        assert S.last_pair_kernel() == "sweep"
+        res[split] = (dict(S.observables), S.dipoles())
+        S.close()
+    util.assert_counts(res[1][0], g, False, label=name)
+    util.assert_energies(res[1][0], g, False, label=name)
+    for k in ("lj_pairs", "es_real", "polarization_energy", "energy"):
+        assert abs(res[1][0][k] - res[0][0][k]) <= 1e-12 * max(abs(res[0][0][k]), 1e-3 * abs(res[0][0]["energy"])), (name, k)
+    for va, vb in zip(res[1][1], res[0][1]):
+        assert np.abs(va - vb).max() <= 1e-11 * np.abs(vb).max() + 1e-15, name

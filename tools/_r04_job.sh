@@ -1,9 +1,2 @@
-for rep in 1 2; do
-for spec in "retire:" "noretire:poll_retire=0" "nopoll:poll_long=0"; do
-  label="${spec%%:*}"; cfg="${spec#*:}"; flags=""; [ -n "$cfg" ] && flags="--configure $cfg"
-  for mode in "" "--host-positions"; do
-    v=$(timeout -k 10 300 python bench.py --steps 10 --warmup 3 --cpu-baseline none --no-extra-passes $flags $mode 2>/dev/null | python3 -c "import json,sys; print('%.1f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['value'])")
-    echo "rep$rep $label ${mode:-resident}: $v evals/s"
-  done
-done
-done
+bash tools/ab_libs.sh w4=mpmcxx_amd/.abl/lib_w4.so new=mpmcxx_amd/libmpmc_energy.so 2>&1 | tee gpurun_out/r04_abl_w4.txt
+for lib in mpmcxx_amd/.abl/lib_w4.so mpmcxx_amd/libmpmc_energy.so; do echo "== $lib"; MPMC_ENERGY_LIB=$lib python tools/host_step_profile.py 1 200; MPMC_ENERGY_LIB=$lib python tools/host_step_profile.py 4 50; done 2>&1 | tee -a gpurun_out/r04_abl_w4.txt

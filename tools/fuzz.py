@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import test_gpu_random as T
+if "split" in sys.argv:  # ... and its two-waves-per-tile-pair form (pair_split = 1; off by default since round 4)
+    sys.argv.remove("split")
+    from mpmcxx_amd import energy as _E2
+    _E2.configure("pair_split", 1)
 if "sweep" in sys.argv:  # force the fast pair sweep (kernels_pair.hip) onto these small tables, where the default is k_pair_fused
     sys.argv.remove("sweep")
     from mpmcxx_amd import energy as _E
