@@ -690,10 +690,11 @@ int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 	if (!seen) {
 		c->n_stream_syncs++;
 		HIP_TRY(c, hipStreamSynchronize(c->sync_stream ? c->sync_stream : c->stream));
-	} else if (c->tune.poll_retire) {
+	} else if (c->tune.poll_retire && c->n_tile_pairs > kOneStreamMaxPairs) {
 		// the results are in, but the runtime has not been told: a stream that is never synchronised keeps its finished commands, and
 		// the next asynchronous copy on it pays for the backlog (measured with positions handed over in host memory: 900 against 966
-		// evaluations/s).  A query is enough to let it retire them.
+		// evaluations/s).  A query is enough to let it retire them.  Long evaluations only: the query costs a few microseconds, which is
+		// a third of a 1000-atom LJ evaluation (23 -> 30 us when it ran behind every poll).
 		(void)hipStreamQuery(c->stream);
 		if (c->two_streams) (void)hipStreamQuery(c->stream2);
 	}
