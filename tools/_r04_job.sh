@@ -1,2 +1,3 @@
-bash tools/ab_libs.sh w4=mpmcxx_amd/.abl/lib_w4.so new=mpmcxx_amd/libmpmc_energy.so 2>&1 | tee gpurun_out/r04_abl_w4.txt
-for lib in mpmcxx_amd/.abl/lib_w4.so mpmcxx_amd/libmpmc_energy.so; do echo "== $lib"; MPMC_ENERGY_LIB=$lib python tools/host_step_profile.py 1 200; MPMC_ENERGY_LIB=$lib python tools/host_step_profile.py 4 50; done 2>&1 | tee -a gpurun_out/r04_abl_w4.txt
+bash tools/host_asan.sh run > gpurun_out/r04_host_asan.txt 2>&1; cat gpurun_out/r04_host_asan.txt | tail -5
+python tools/soak.py 2>&1 | tee gpurun_out/r04_soak.txt
+bash tools/fuzz_long.sh > gpurun_out/r04_fuzz_long.txt 2>&1; cat gpurun_out/r04_fuzz_long.txt | tail -30

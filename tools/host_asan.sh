@@ -24,7 +24,7 @@ else
 	export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=0:log_path=$root/gpurun_out/asan_report
 	export UBSAN_OPTIONS=print_stacktrace=1:log_path=$root/gpurun_out/ubsan_report
 	LD_PRELOAD=$(gcc -print-file-name=libasan.so) timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random.py tests/test_gpu_trial_moves.py \
-		tests/test_gpu_box_moves.py tests/test_gpu_edge_cases.py tests/test_gpu_round2_fixes.py tests/test_gpu_round3_fixes.py tests/test_gpu_pair_sweep.py tests/test_gpu_triclinic.py tests/test_gibbs.py -q -m gpu > gpurun_out/asan_tests.log 2>&1 || true
+		tests/test_gpu_box_moves.py tests/test_gpu_edge_cases.py tests/test_gpu_round2_fixes.py tests/test_gpu_round3_fixes.py tests/test_gpu_pair_sweep.py tests/test_gpu_triclinic.py tests/test_gibbs.py tests/test_gpu_parity_margin.py tests/test_gpu_config5.py -q -m gpu > gpurun_out/asan_tests.log 2>&1 || true
 	tail -n 3 gpurun_out/asan_tests.log
 	ls gpurun_out | grep san_report || echo "no sanitizer reports"
 fi

@@ -2,8 +2,9 @@ import os, sys, numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle")); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import util
 from mpmcxx_amd import energy
-for name, nb, steps in (("ion1000_polar", 16, 300), ("water64_polar", 32, 300)):
-    atoms, basis, opts = util.load_fixture(name)
+import tempfile
+for name, nb, steps in (("ion1000_polar", 16, 300), ("water64_polar", 32, 300), ("ion10k_polar", 8, 60)):  # (10 000 atoms: two streams, polled waits, fused tail)
+    atoms, basis, opts = util.load_generated(name, tempfile.mkdtemp()) if name in util.LARGE else util.load_fixture(name)
     beads = []
     for b in range(nb):
         a = dict(atoms); a["pos"] = atoms["pos"] + np.random.default_rng(b).normal(scale=0.03, size=atoms["pos"].shape)
