@@ -32,7 +32,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_code_object_is_gfx950():
     data = open(mbuild.build_library(), "rb").read()
     assert b"gfx950" in data
-    for kern in (b"k_pair_fused", b"k_pair_sweep", b"k_recip_sf", b"k_dipole_iter_hybrid", b"k_dipole_iter_panel", b"k_build_panels", b"k_delta_field", b"k_dense_matvec", b"k_gs_stage", b"k_classify", b"k_atom_terms"):
+    for kern in (b"k_pair_fused", b"k_pair_sweep", b"k_recip_sf", b"k_dipole_iter_hybrid", b"k_dipole_iter_panel", b"k_build_panels", b"k_delta_field", b"k_dense_matvec", b"k_dense_symv", b"k_polar_energy_and_pairs", b"k_gs_stage", b"k_classify", b"k_atom_terms"):
         assert kern in data, kern
 
 
