@@ -36,6 +36,8 @@ struct mpmc_tuning {
 	int stream_mode = -1;   // "side_stream": -1 by table size (kOneStreamMaxPairs), 0 never fork the side stream, 1 always
 	int pair_kernel = 0;    // "pair_kernel": 0 the fast sweep (kernels_pair.hip) where it applies and the table is large, 1 never, 2 wherever it applies
 	int pair_waves = 0;     // "pair_waves": waves per tile pair of k_pair_fused, 0 by table size (kPairSplitMax), 1 | 4
+	int sort_grid = -1;           // "sort_grid": -1 the aligned-grid spatial order where the table is large enough (round 4), 0 the nested count-based bisection of rounds 1-3
+	int sort_nx = 0, sort_ny = 0; // "sort_nx" / "sort_ny": > 0: the aligned grid with exactly this many x slabs / y strips (measurement)
 	bool side_after_sweep = true; // "side_after_sweep": two streams: the side stream's kernels are enqueued behind the pair sweep's launch (0: in front, rounds 1-3)
 	bool poll_retire = true;      // "poll_retire": a polled-for evaluation queries its streams afterwards so that the runtime retires the finished commands
 	bool poll_long = true;        // "poll_long": evaluations of large tables are polled for before the wait synchronises the stream (0: rounds 1-3)
