@@ -6,6 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import test_gpu_random as T
+if "grid" in sys.argv:  # the aligned-grid spatial order of large tables (round 4) forced onto these sizes: 4 x 2 columns, serpentine
+    sys.argv.remove("grid")
+    from mpmcxx_amd import energy as _E3
+    _E3.configure("sort_nx", 4)
+    _E3.configure("sort_ny", 2)
 if "split" in sys.argv:  # ... and its two-waves-per-tile-pair form (pair_split = 1; off by default since round 4)
     sys.argv.remove("split")
     from mpmcxx_amd import energy as _E2
