@@ -13,7 +13,8 @@ from mpmcxx_amd import energy, gen_box, pqr  # noqa: E402
 
 tri = [[79.8, 0.0, 0.0], [9.0, 77.0, 0.0], [-6.0, 11.0, 75.0]]
 ortho = [[79.8, 0.0, 0.0], [0.0, 77.0, 0.0], [0.0, 0.0, 75.0]]
-for label, basis in (("orthorhombic", ortho), ("triclinic", tri)):
+for label, basis, grid in (("orthorhombic", ortho, -1), ("triclinic", tri, -1), ("orthorhombic, bisection order", ortho, 0), ("triclinic, bisection order", tri, 0)):
+    energy.configure("sort_grid", grid)  # (-1: the aligned-grid spatial order of large tables, round 4; 0: the nested bisection of rounds 1-3)
     wd = tempfile.mkdtemp()
     gen_box.write_pqr(os.path.join(wd, "b.pqr"), gen_box.lattice_box_cell(8000, basis, 22))
     gen_box.write_input(os.path.join(wd, "b.in"), "b.pqr", basis, dict(gen_box.POLAR_OPTS))
@@ -32,6 +33,6 @@ for label, basis in (("orthorhombic", ortho), ("triclinic", tri)):
     t = S.timings(reset=True)
     st = S.pair_stats()
     cls = "  ".join(f"{k} {v['ms'] / max(v['launches'], 1):.4f}x{v['launches'] // reps}" for k, v in t.items() if v["launches"])
-    print(f"{label:>13s}: eval {wall * 1e3:.3f} ms  E {e:.10e} | {cls} | tile pairs {st.get('tile_pairs')} stored {st.get('tile_pairs_stored')} far {st.get('tile_pairs_far')} "
+    print(f"{label:>30s}: eval {wall * 1e3:.3f} ms  E {e:.10e} | {cls} | tile pairs {st.get('tile_pairs')} stored {st.get('tile_pairs_stored')} far {st.get('tile_pairs_far')} "
           f"non-uniform dims x pairs far {st.get('nonuniform_dims_x_pairs_far')}", flush=True)
     S.close()
