@@ -407,12 +407,17 @@ constexpr int kSlotGroups = 8;
 __device__ __forceinline__ void slot_sum_64(const double *__restrict__ part, int n_slots, int n_pad, int i, int a, int g,
                                             double (*sh)[kTile][3], double out[3]) {
 	double f[3] = {0, 0, 0};
+	// (slot addresses as a wave-uniform base -- the group index and the tile's first atom are scalars -- plus the lane's 32-bit offset: a
+	// per-lane 64-bit pointer costs more vector instructions than the sums themselves; same trick as k_dipole_update_panel, round 4)
+	const int gs = __builtin_amdgcn_readfirstlane(g);
+	const size_t tile0 = (size_t)__builtin_amdgcn_readfirstlane(i - a);
+	const unsigned lane3 = 3u * (unsigned)a;
 #pragma unroll 4
-	for (int t = g; t < n_slots; t += kSlotGroups) { // (unrolled: the loads of a group of four are in flight together; same order of sums)
-		const double *q = part + ((size_t)t * n_pad + i) * 3;
-		f[0] += q[0];
-		f[1] += q[1];
-		f[2] += q[2];
+	for (int t = gs; t < n_slots; t += kSlotGroups) { // (unrolled: the loads of a group of four are in flight together; same order of sums)
+		const double *__restrict__ q = part + ((size_t)t * n_pad + tile0) * 3;
+		f[0] += q[lane3];
+		f[1] += q[lane3 + 1];
+		f[2] += q[lane3 + 2];
 	}
 	sh[g][a][0] = f[0];
 	sh[g][a][1] = f[1];

@@ -447,7 +447,10 @@ __global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDe
                                                                          double allowed_sqerr, int *__restrict__ ctl, int *__restrict__ host_flag, int it) {
 	__shared__ double sh[kUpdGroups][kTile][3];
 	if (ctl && ctl[1] != 0) return; // converged in an earlier iteration (block-uniform)
-	const int a = threadIdx.x & 63, g = threadIdx.x >> 6;
+	// (the group index as a SCALAR: the slot addresses below are then a wave-uniform base in scalar registers plus the lane's 32-bit offset,
+	// i.e. no vector arithmetic per slot -- with a per-lane 64-bit pointer the kernel spent 2/3 of its 272 instructions per wave on addresses,
+	// 1.8 % of all the instructions of an evaluation)
+	const int a = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int X = blockIdx.x, i = X * kTile + a;
 	const int nF = nt - X, wg0 = seg[X], nG = seg[X + 1] - wg0;
 	// what the closing wave needs behind the barrier is requested now (it would be a second latency chain there)
@@ -464,22 +467,21 @@ __global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDe
 	// (Round 4 tried batches of eight predicated loads per group: more loads in flight, but the padding loads cost more than the latency
 	// they hide -- 8.5 against 7.4 us in rocprofv3's trace -- and was taken back.)
 	double f[3] = {0, 0, 0};
-	const double *pf = part + ((size_t)X * at.n_pad + i) * 3;
-	const size_t sf = (size_t)at.n_pad * 3;
+	const unsigned lane3 = 3u * (unsigned)a;
+	const size_t n_pad = (size_t)at.n_pad;
 #pragma unroll 4
 	for (int t = g; t < nF; t += kUpdGroups) {
-		const double *q = pf + (size_t)t * sf;
-		f[0] += q[0];
-		f[1] += q[1];
-		f[2] += q[2];
+		const double *__restrict__ q = part + ((size_t)(X + t) * n_pad + (size_t)X * kTile) * 3; // slot X + t, this tile's atoms: wave-uniform
+		f[0] += q[lane3];
+		f[1] += q[lane3 + 1];
+		f[2] += q[lane3 + 2];
 	}
-	const double *pg = gpart + ((size_t)wg0 * kTile + a) * 3;
 #pragma unroll 4
 	for (int t = g; t < nG; t += kUpdGroups) {
-		const double *q = pg + (size_t)t * (kTile * 3);
-		f[0] += q[0];
-		f[1] += q[1];
-		f[2] += q[2];
+		const double *__restrict__ q = gpart + (size_t)(wg0 + t) * (kTile * 3);
+		f[0] += q[lane3];
+		f[1] += q[lane3 + 1];
+		f[2] += q[lane3 + 2];
 	}
 	sh[g][a][0] = f[0];
 	sh[g][a][1] = f[1];
