@@ -40,7 +40,9 @@ def test_rccl_is_loaded_below_python():
 def test_pi_allreduce_on_one_device_equals_the_local_loop():
     beads = make_beads(4)
     s_local, per_local, f_local = energy.pi_potential_local(beads)
+    assert energy.pi_allreduce_info(beads)[0] == 1  # (one device; the communicator may exist already from an earlier test of this process)
     s_rccl, per_rccl, f_rccl = energy.pi_allreduce(beads)  # values travel device -> ncclAllGather (1 rank) -> host
+    assert energy.pi_allreduce_info(beads) == (1, 1)  # ABI 5: one device, the process-wide communicator of that device has one rank
     assert np.array_equal(s_local, s_rccl) and f_local == f_rccl
     assert [p["energy"] for p in per_local] == [p["energy"] for p in per_rccl]
     from oracle import pi_aggregate
