@@ -188,6 +188,12 @@ int mpmc_energy(mpmc_ctx *ctx, mpmc_result *out);
 /* asynchronous pair: enqueue on the context's stream / wait + fetch (lets a caller overlap beads) */
 int mpmc_energy_async(mpmc_ctx *ctx);
 int mpmc_energy_wait(mpmc_ctx *ctx, mpmc_result *out);
+/* (ABI 5) a scheduling hint for mpmc_energy_async: how many evaluations the caller keeps in flight together with this context's (the P
+ * beads of PI_calculate_potential, PathIntegral.cpp:772-779).  With four or more the evaluation runs on ONE stream -- other evaluations
+ * fill the device, and the side stream's fork and join only cost (+1 to 2 % evaluations/s with 8-32 in flight) --, alone it forks the
+ * side stream for the reciprocal-space work (1.5 % faster).  Never changes a result; mpmc_energy() resets it to 1, the mpmc_pi_* loops set it
+ * themselves. */
+int mpmc_hint_in_flight(mpmc_ctx *ctx, int n_evaluations);
 
 /* ---- trial moves: the device-side counterpart of the reference's per-pair cache ----------------------------------------
  * The reference re-evaluates only the pairs whose displacement changed (Pair::recalculate_energy, src/System.cpp:1211-1224,

@@ -162,8 +162,12 @@ public:
 	}
 	void energy_async() {
 		sync_state();
+		check(mpmc_hint_in_flight(ctx_, in_flight_hint_), "mpmc_hint_in_flight");
 		check(mpmc_energy_async(ctx_), "mpmc_energy_async");
 	}
+	// how many evaluations the caller keeps in flight together with this system's (a scheduling hint for energy_async: mpmc_hint_in_flight;
+	// kept here because the context is created lazily)
+	void hint_in_flight(int n) { in_flight_hint_ = n < 1 ? 1 : n; }
 	double energy_wait() {
 		mpmc_result r;
 		check(mpmc_energy_wait(ctx_, &r), "mpmc_energy_wait");
@@ -257,6 +261,7 @@ private:
 	observables_t obs_;
 	nodestats_t stats_;
 	mpmc_ctx *ctx_ = nullptr;
+	int in_flight_hint_ = 1;
 	int capacity_ = 0;
 	bool atoms_dirty_ = true, box_dirty_ = true;
 	int trial_first_ = 0;
@@ -513,7 +518,11 @@ public:
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(n_local < 4 ? n_local : 4) if (n_local > 1)
 #endif
-		for (int b = 0; b < n_local; b++) each_image_guarded(err_img, [&] { systems[b]->energy_async(); });
+		for (int b = 0; b < n_local; b++)
+			each_image_guarded(err_img, [&] {
+				systems[b]->hint_in_flight(n_local);
+				systems[b]->energy_async();
+			});
 		if (err_img) throw err_img;
 		std::vector<double> mine(4 * (size_t)n_local);
 		for (int b = 0; b < n_local; b++) {

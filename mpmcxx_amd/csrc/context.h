@@ -117,6 +117,7 @@ struct mpmc_ctx {
 	size_t cap_generic = 0;
 	int n_generic = 0;
 	std::vector<int> h_generic;
+	int inflight_hint = 1; // evaluations the caller keeps in flight together with this one (mpmc_hint_in_flight; the PI loops set their bead count)
 	bool last_pair_was_sweep = false; // (diagnostics: which kernel the last evaluation's pair pass ran)
 	FusedParams last_fp{};            // the pair pass's parameters in the last evaluation (mpmc_debug_time_pair replays it)
 	bool last_fp_valid = false;

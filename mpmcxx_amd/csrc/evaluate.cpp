@@ -89,6 +89,7 @@ static int build_k_tables(mpmc_ctx *c) {
 }
 
 constexpr int kDenseChunks = 16; // row chunks (= partial slots) of the dense matrix-vector product
+constexpr int kOneStreamMinInflight = 4; // evaluations in flight from which on an evaluation keeps to one stream
 constexpr int kCheckEvery = 4;         // precision-terminated Jacobi solve: host reads the device-side verdict once per this many iterations
 constexpr int kSingleLaunchTiles = 32; // <= 2048 atoms (528 tile pairs): LJ-only evaluations run as ONE launch
 
@@ -297,7 +298,11 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	const bool side_work = need_sf || need_intra;
 	// a fork/join costs ~20 us of dispatch latency: worth it next to reciprocal-space work, not for the O(N) atom terms alone -- and not
 	// for small tables at all (kOneStreamMaxPairs).  Decided here, once per evaluation: nothing is forked at this point.
-	c->two_streams = (c->tune.stream_mode == 1) || (c->tune.stream_mode < 0 && c->n_tile_pairs > kOneStreamMaxPairs);
+	// (round 4: ... and not when the caller keeps kOneStreamMinInflight or more evaluations in flight: other evaluations fill the device then,
+	// and the fork and join are pure cost -- 1018-1025 against 1006-1012 evaluations/s with 32 beads, 1021 against 1002 with 8; one
+	// evaluation at a time the fork is worth 1.5 %.  The choice of streams does not touch the arithmetic.)
+	c->two_streams = (c->tune.stream_mode == 1) ||
+	                 (c->tune.stream_mode < 0 && c->n_tile_pairs > kOneStreamMaxPairs && c->inflight_hint < kOneStreamMinInflight);
 	const bool side_fork = c->two_streams && (need_sf || need_intra);
 	bool panel_side = false; // the panel table of the Jacobi contraction is being built on the side stream
 	// (two streams: enqueued BEHIND the pair sweep -- the main stream's critical path (classes, sweep) reaches the device first; one
@@ -757,12 +762,18 @@ extern "C" int mpmc_energy_async(mpmc_ctx *c) {
 	if (!c) return MPMC_ERR_ARG;
 	return enqueue(c, full_mask(c));
 }
+extern "C" int mpmc_hint_in_flight(mpmc_ctx *c, int n) {
+	if (!c || n < 1) return MPMC_ERR_ARG;
+	c->inflight_hint = n;
+	return MPMC_OK;
+}
 extern "C" int mpmc_energy_wait(mpmc_ctx *c, mpmc_result *out) {
 	if (!c) return MPMC_ERR_ARG;
 	return wait_and_fill(c, out);
 }
 extern "C" int mpmc_energy(mpmc_ctx *c, mpmc_result *out) {
 	if (!c || !out) return MPMC_ERR_ARG;
+	c->inflight_hint = 1; // (a synchronous call: nothing else of this caller is in flight)
 	int rc = enqueue(c, full_mask(c));
 	if (rc != MPMC_OK) return rc;
 	return wait_and_fill(c, out);

@@ -47,6 +47,7 @@ extern "C" int mpmc_last_batch_size(mpmc_ctx *c) { return c ? 1 : 0; }
 extern "C" int mpmc_pi_potential_local(mpmc_ctx **beads, int n_local, double sums4[4], mpmc_result *per_bead, int *any_failed) {
 	if (!beads || n_local < 0 || !sums4) return MPMC_ERR_ARG;
 	for (int b = 0; b < n_local; b++) {
+		if (beads[b]) beads[b]->inflight_hint = n_local;
 		int rc = beads[b] ? enqueue(beads[b], full_mask(beads[b])) : MPMC_ERR_ARG;
 		if (rc != MPMC_OK) {
 			pi_drain(beads, 0, b);
@@ -66,7 +67,10 @@ extern "C" int mpmc_pi_potential_local_host(mpmc_ctx **beads, int n_local, const
 	for (int b = 0; b < n_local; b++) {
 		mpmc_ctx *c = beads[b];
 		int rc = (c && pos[b]) ? mpmc_update_positions(c, 0, c->n, pos[b]) : MPMC_ERR_ARG;
-		if (rc == MPMC_OK) rc = enqueue(c, full_mask(c));
+		if (rc == MPMC_OK) {
+			c->inflight_hint = n_local;
+			rc = enqueue(c, full_mask(c));
+		}
 		if (rc != MPMC_OK) {
 			pi_drain(beads, 0, b);
 			return rc;

@@ -141,6 +141,8 @@ def lib():
     L.mpmc_comm_last_error.restype = C.c_char_p
     L.mpmc_comm_allgather_f64.argtypes = [vp, dp, C.c_int64, dp]
     L.mpmc_pi_gather_beads.argtypes = [vp, dp, C.c_int, C.c_int, dp]
+    if hasattr(L, "mpmc_hint_in_flight") or not os.environ.get("MPMC_ENERGY_LIB"):
+        L.mpmc_hint_in_flight.argtypes = [vp, C.c_int]
     L.mpmc_pi_allreduce.argtypes = [C.POINTER(vp), C.c_int, dp, C.POINTER(Result), C.POINTER(C.c_int)]
     if hasattr(L, "mpmc_pi_allreduce_info") or not os.environ.get("MPMC_ENERGY_LIB"):  # (an older build under the A/B override lacks the ABI-5 entry)
         L.mpmc_pi_allreduce_info.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -294,6 +296,10 @@ class System:
         self._check(self._L.mpmc_energy(self._h, C.byref(r)))
         self.observables = r.as_dict()
         return r.energy
+
+    def hint_in_flight(self, n: int):
+        """scheduling hint for energy_async: how many evaluations the caller keeps in flight together with this one (mpmc_hint_in_flight)."""
+        self._check(self._L.mpmc_hint_in_flight(self._h, int(n)))
 
     def energy_async(self):
         self._check(self._L.mpmc_energy_async(self._h))

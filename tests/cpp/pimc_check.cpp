@@ -26,6 +26,7 @@ public:
 	void atoms_changed() {}
 	void move_atoms(int, int) {}
 	void energy_async() {}
+	void hint_in_flight(int) {}
 	double energy_wait() { return energy(); }
 	unsigned int countN() {
 		unsigned int c = 0;
