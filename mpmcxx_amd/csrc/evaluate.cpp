@@ -301,8 +301,11 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	// (round 4: ... and not when the caller keeps kOneStreamMinInflight or more evaluations in flight: other evaluations fill the device then,
 	// and the fork and join are pure cost -- 1018-1025 against 1006-1012 evaluations/s with 32 beads, 1021 against 1002 with 8; one
 	// evaluation at a time the fork is worth 1.5 %.  The choice of streams does not touch the arithmetic.)
+	// Only for evaluations with a dipole solve: there the side work is 5 % of the evaluation; a 10 000-atom LJ + Ewald evaluation (sweep 95 us,
+	// reciprocal space 25 us) loses 4 % in flight without the overlap (9365 against 9600-9960 evaluations/s).
 	c->two_streams = (c->tune.stream_mode == 1) ||
-	                 (c->tune.stream_mode < 0 && c->n_tile_pairs > kOneStreamMaxPairs && c->inflight_hint < kOneStreamMinInflight);
+	                 (c->tune.stream_mode < 0 && c->n_tile_pairs > kOneStreamMaxPairs &&
+	                  !((mask & RUN_SOLVE) && c->inflight_hint >= kOneStreamMinInflight));
 	const bool side_fork = c->two_streams && (need_sf || need_intra);
 	bool panel_side = false; // the panel table of the Jacobi contraction is being built on the side stream
 	// (two streams: enqueued BEHIND the pair sweep -- the main stream's critical path (classes, sweep) reaches the device first; one
