@@ -441,7 +441,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 	// that closes the evaluation (second block of the polarization-energy kernel: launch_polar_energy_and_pairs) -- rounds 2-3 forked the
 	// side stream for it, which put an event record in front of the static field and a join in front of the posted results (~10 us of
 	// barrier packets on the main stream, one evaluation at a time)
-	const bool reduce_in_tail = (mask & RUN_PAIR) && (mask & RUN_SOLVE) && c->two_streams && c->tune.tail_fused;
+	const bool reduce_in_tail = (mask & RUN_PAIR) && (mask & RUN_SOLVE) && c->tune.tail_fused; // (on one stream too: one launch fewer)
 	bool reduce_forked = false;
 	if ((mask & RUN_PAIR) && !reduce_in_tail) {
 		reduce_forked = c->two_streams && (mask & RUN_FIELD) != 0; // (tail_fused = 0: the rounds 2-3 arrangement)
