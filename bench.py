@@ -398,6 +398,8 @@ def main():
         hp = host_pos if state["host_positions"] else None
         if args.concurrency == "async":
             _, per, failed = energy.pi_potential_local(beads, host_positions=hp)
+            state["per"] = per
+            return per.table4()  # (the four combined terms straight from the library's result block: no per-bead dicts inside the step)
         else:
             per = []
             for k, s in enumerate(beads):

@@ -223,12 +223,24 @@ class System:
         if rc != MPMC_OK:
             raise MpmcError(rc, (L.mpmc_last_error(None) or b"").decode())
         self.n = n
-        self.observables: Dict[str, float] = {}
+        self._obs: Dict[str, float] = {}
+        self._obs_lazy = None  # (ctypes Result array, index): turned into a dict when somebody looks (the PI loops fill 32 of these per step)
         self.set_box(basis)
         self.set_options(options)
         self.set_atoms(atoms)
 
     # -- plumbing -------------------------------------------------------------------------------------------
+    @property
+    def observables(self) -> Dict[str, float]:
+        if self._obs_lazy is not None:
+            arr, i = self._obs_lazy
+            self._obs, self._obs_lazy = arr[i].as_dict(), None
+        return self._obs
+
+    @observables.setter
+    def observables(self, d):
+        self._obs, self._obs_lazy = d, None
+
     def _check(self, rc: int):
         if rc != MPMC_OK:
             raise MpmcError(rc, (self._L.mpmc_last_error(self._h) or b"").decode())
@@ -421,6 +433,41 @@ class System:
         return a.value, b.value
 
 
+class ResultList:
+    """per-bead results of a PI loop: the ctypes array the library filled, turned into dicts on access (a 30-field dict per bead and step
+    is 1 % of a 32-bead step when nobody reads it)."""
+
+    def __init__(self, arr, n: int):
+        self._arr, self._n = arr, n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._arr[k].as_dict() for k in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return self._arr[i].as_dict()
+
+    def __iter__(self):
+        return (self._arr[k].as_dict() for k in range(self._n))
+
+    def table4(self) -> np.ndarray:
+        """(n, 4) = {rd, coulombic, polarization, vdw} per bead -- what PI_calculate_potential combines (PathIntegral.cpp:763-766)."""
+        raw = np.frombuffer(self._arr, dtype=np.float64, count=self._n * (C.sizeof(Result) // 8)).reshape(self._n, C.sizeof(Result) // 8)
+        return np.ascontiguousarray(raw[:, 1:5])  # fields 1..4 of mpmc_result: rd_energy, coulombic_energy, polarization_energy, vdw_energy
+
+
+def _adopt(beads, res, n):
+    per = ResultList(res, n)
+    for i, b in enumerate(beads):
+        b._obs_lazy = (res, i)
+    return per
+
+
 def pi_potential_local(beads: Sequence[System], host_positions: Optional[Sequence[np.ndarray]] = None):
     """local leg of SimulationControl::PI_calculate_potential (reference PathIntegral.cpp:752-805):
     returns (sums4 = ordered sums of {rd, coulombic, polarization, vdw} over this rank's beads, per-bead results, failed).
@@ -445,10 +492,7 @@ def pi_potential_local(beads: Sequence[System], host_positions: Optional[Sequenc
         for b in beads:
             msg = L.mpmc_last_error(b.handle) or msg
         raise MpmcError(rc, msg.decode())
-    per = [res[i].as_dict() for i in range(n)]
-    for b, r in zip(beads, per):
-        b.observables = r
-    return sums, per, bool(failed.value)
+    return sums, _adopt(beads, res, n), bool(failed.value)
 
 
 def gibbs_energy(box_a: System, box_b: System):
@@ -490,10 +534,7 @@ def pi_allreduce(beads: Sequence[System]):
     rc = L.mpmc_pi_allreduce(arr, n, _dp(sums), res, C.byref(failed))
     if rc != MPMC_OK:
         raise MpmcError(rc, ((L.mpmc_last_error(beads[0].handle) if beads else b"") or L.mpmc_comm_last_error(None) or b"").decode())
-    per = [res[i].as_dict() for i in range(n)]
-    for b, r in zip(beads, per):
-        b.observables = r
-    return sums, per, bool(failed.value)
+    return sums, _adopt(beads, res, n), bool(failed.value)
 
 
 def pi_allreduce_info(beads: Sequence[System]):
