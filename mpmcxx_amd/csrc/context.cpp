@@ -134,16 +134,16 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 	mpmc_default_options(&c->opts);
 	int rc = MPMC_OK;
 	auto A = [&](int r) { if (rc == MPMC_OK) rc = r; };
+	{
+		std::lock_guard<std::mutex> lk(g_tuning_mu);
+		c->tune = g_tuning_default;
+	}
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-	    hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+	    (!c->tune.lazy_side_stream && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) ||
 	    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
 		delete c;
 		return fail(nullptr, MPMC_ERR_HIP, "mpmc_ctx_create: hipStreamCreate failed");
-	}
-	{
-		std::lock_guard<std::mutex> lk(g_tuning_mu);
-		c->tune = g_tuning_default;
 	}
 	c->two_streams = (c->tune.stream_mode != 0);
 	const size_t P = (size_t)c->max_pad;
@@ -581,7 +581,7 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 // the capacity is allocated on first use, so nothing else has to know.
 static int grow_capacity(mpmc_ctx *c, int n) {
 	(void)hipSetDevice(c->device);
-	(void)hipStreamSynchronize(c->stream2);
+	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 	(void)hipStreamSynchronize(c->stream);
 	mpmc_ctx *f = nullptr;
 	const int cap = n + n / 4 + kTile;
@@ -917,6 +917,7 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 	else if (k == "side_after_sweep") t.side_after_sweep = on;
 	else if (k == "poll_long") t.poll_long = on;
 	else if (k == "poll_retire") t.poll_retire = on;
+	else if (k == "lazy_side_stream") t.lazy_side_stream = on;
 	else if (k == "tail_fused") t.tail_fused = on;
 	else if (k == "pair_split") {
 		if (v < -1 || v > 1) return MPMC_ERR_ARG;

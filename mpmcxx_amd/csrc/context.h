@@ -39,6 +39,8 @@ struct mpmc_tuning {
 	int sort_grid = -1;           // "sort_grid": -1 the aligned-grid spatial order where the table is large enough (round 4), 0 the nested count-based bisection of rounds 1-3
 	int sort_nx = 0, sort_ny = 0; // "sort_nx" / "sort_ny": > 0: the aligned grid with exactly this many x slabs / y strips (measurement)
 	bool side_after_sweep = true; // "side_after_sweep": two streams: the side stream's kernels are enqueued behind the pair sweep's launch (0: in front, rounds 1-3)
+	bool lazy_side_stream = true; // "lazy_side_stream": the side stream is created when an evaluation first forks, not with the context -- the runtime deals
+	                              // hardware queues to streams in turn, and an ensemble that never forks then has its main streams on all four (+0.6 %)
 	bool poll_retire = true;      // "poll_retire": a polled-for evaluation queries its streams afterwards so that the runtime retires the finished commands
 	bool poll_long = true;        // "poll_long": evaluations of large tables are polled for before the wait synchronises the stream (0: rounds 1-3)
 	bool tail_fused = true;       // "tail_fused": polarization energy and the fold of the pair partials in one launch (0: the fold forks the side stream)
@@ -382,12 +384,17 @@ struct ProfScope { // HIP-event bracket on the stream the kernels are launched o
 // side stream: starts after everything enqueued so far on the main stream / main stream waits for the side stream
 inline hipStream_t fork_side(mpmc_ctx *c) {
 	if (!c->two_streams) return c->stream;
+	if (!c->stream2 && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { // (lazy_side_stream)
+		c->stream2 = nullptr;
+		c->two_streams = false;
+		return c->stream;
+	}
 	(void)hipEventRecord(c->ev_fork, c->stream);
 	(void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
 	return c->stream2;
 }
 inline void join_side(mpmc_ctx *c) {
-	if (!c->two_streams) return;
+	if (!c->two_streams || !c->stream2) return;
 	(void)hipEventRecord(c->ev_join, c->stream2);
 	(void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
 }

@@ -704,7 +704,7 @@ int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 		// evaluations/s).  A query is enough to let it retire them.  Long evaluations only: the query costs a few microseconds, which is
 		// a third of a 1000-atom LJ evaluation (23 -> 30 us when it ran behind every poll).
 		(void)hipStreamQuery(c->stream);
-		if (c->two_streams) (void)hipStreamQuery(c->stream2);
+		if (c->two_streams && c->stream2) (void)hipStreamQuery(c->stream2);
 	}
 	c->sync_stream = nullptr;
 	c->pending = false;

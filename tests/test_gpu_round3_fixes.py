@@ -81,7 +81,8 @@ def test_configure_rejects_unknown_keys_and_bad_values():
 
 
 @pytest.mark.parametrize("key,value", [("side_stream", 0), ("side_stream", 1), ("pair_waves", 1), ("pair_waves", 4), ("panels", 0), ("uniform_images", 0),
-                                       ("tile_classes", 0), ("recip_table", 0), ("spatial_sort", 0), ("polar_delta", 0), ("pair_kernel", 1), ("pair_kernel", 2)])
+                                       ("tile_classes", 0), ("recip_table", 0), ("spatial_sort", 0), ("polar_delta", 0), ("pair_kernel", 1), ("pair_kernel", 2),
+                                       ("lazy_side_stream", 0)])
 def test_every_switch_leaves_the_reference_numbers(key, value):
     """the measurement switches of mpmc_debug_configure select other kernels or orders, never other physics"""
     g = util.golden("ion1000_polar")
