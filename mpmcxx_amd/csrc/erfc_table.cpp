@@ -26,20 +26,36 @@ void erfc_table_device_layout(double2 *out) {
 } // namespace mpmc
 
 // measurement / test entry point (no device needed): erfc(x) and exp(-x^2) evaluated the way the kernel does, in host fp64
+// (one Horner pass for the interpolant p and its derivative; exp(-x^2) = -(sqrt(pi) / 2) erfc'(x))
 extern "C" int mpmc_debug_erfc_table(double x, double *erfc_out, double *gauss_out) {
 	if (!(x >= 0.0) || !(x < MPMC_ERFTAB_XMAX)) return 1;
 	const double xs = x * MPMC_ERFTAB_INV_H;
 	const int it = (int)xs;
 	const double dd = (xs - (double)it) - 0.5;
 	const double *c = kRows[it];
-	const double w = std::fma(std::fma(std::fma(std::fma(c[4], dd, c[3]), dd, c[2]), dd, c[1]), dd, c[0]);
-	const double d = dd * (1.0 / MPMC_ERFTAB_INV_H);
-	const double t = -(d * std::fma(2.0, x, -d));
-	const double e[MPMC_ERFTAB_EXP_DEG + 1] = {MPMC_ERFTAB_EXP_COEFFS};
-	double p = e[MPMC_ERFTAB_EXP_DEG];
-	for (int k = MPMC_ERFTAB_EXP_DEG - 1; k >= 0; --k) p = std::fma(p, t, e[k]);
-	const double G = c[5] * p;
-	if (gauss_out) *gauss_out = G;
-	if (erfc_out) *erfc_out = G * w;
+	double b = c[5], d1 = c[5];
+	for (int k = 4; k >= 1; --k) {
+		b = std::fma(b, dd, c[k]);
+		d1 = std::fma(d1, dd, b);
+	}
+	const double p = std::fma(b, dd, c[0]);
+	if (gauss_out) *gauss_out = (-0.5 * 1.7724538509055160273 * MPMC_ERFTAB_INV_H) * d1;
+	if (erfc_out) *erfc_out = p;
+	return 0;
+}
+
+// ... and the field factor of real_term (src/System.Energy.cpp:2919-2934), erfc(x) + 2 x / sqrt(pi) exp(-x^2) = p - (x / H) p'
+extern "C" int mpmc_debug_erfc_table_field(double x, double *factor_out) {
+	if (!(x >= 0.0) || !(x < MPMC_ERFTAB_XMAX) || !factor_out) return 1;
+	const double xs = x * MPMC_ERFTAB_INV_H;
+	const int it = (int)xs;
+	const double dd = (xs - (double)it) - 0.5;
+	const double *c = kRows[it];
+	double b = c[5], d1 = c[5];
+	for (int k = 4; k >= 1; --k) {
+		b = std::fma(b, dd, c[k]);
+		d1 = std::fma(d1, dd, b);
+	}
+	*factor_out = std::fma(-xs, d1, std::fma(b, dd, c[0]));
 	return 0;
 }

@@ -158,7 +158,7 @@ struct PairSweepParams {
 constexpr int kSweepMinPairs = 2048;
 // two waves per tile pair (half the steps each; kernels_pair.hip): measured in round 4, see DESIGN section 3
 constexpr bool kSweepSplitDefault = false;
-// host: the device layout of the erfc table, 3 * 512 double2 = (c0,c1)[512], (c2,c3)[512], (c4,G)[512]  (erfc_table.cpp)
+// host: the device layout of the erfc table, 3 * 512 double2 = (c0,c1)[512], (c2,c3)[512], (c4,c5)[512]  (erfc_table.cpp)
 constexpr int kErfTableDouble2 = 3 * 512;
 void erfc_table_device_layout(double2 *out /*[kErfTableDouble2]*/);
 // work table of the sweep: one workgroup per entry { J, I0 }, its four waves take the tile pairs (I0 .. I0+3, J); returns the

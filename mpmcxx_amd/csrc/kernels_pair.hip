@@ -7,9 +7,11 @@
 // kernel issues 160 VALU instructions per pair of which 97 are fp64 arithmetic (profiles/r02_pmc_stalls.txt), this one ~80:
 //
 //  * erfc and the Gaussian come from a TABLE in LDS instead of a degree-20 polynomial plus a range-reduced exp: 512 pieces of width
-//    1/128 in x = alpha r, per piece a degree-4 interpolant of erfcx(x) = exp(x^2) erfc(x) and G_k = exp(-x_k^2); exp(-x^2) =
-//    G_k exp(t) with |t| < 0.032 (degree 6).  Three ds_read_b128 gathers and 23 VALU instructions replace 57; relative error of erfc
-//    1.7e-14 over [0, 4) (tools/fit_erfc_table.py, tests/test_erfc_table.py).  The table is why a workgroup is four waves: they share it;
+//    1/128 in x = alpha r, per piece a degree-5 interpolant p of erfc(x); the Gaussian of the field factor is its derivative
+//    (exp(-x^2) = -(sqrt(pi) / 2) erfc'(x)), so erfc + 2 x / sqrt(pi) exp(-x^2) = p - (x / H) p' costs one Horner pass for both and one fma.
+//    Three ds_read_b128 gathers and 11 (energy) / 16 (energy and field) VALU instructions replace 57 (rounds 2-3: erfcx to degree 4 times
+//    G_k exp(t), 22); relative error of erfc 3e-14 over [0, 4), of the field factor 1e-13 below x = 2 and 3e-11 at 4
+//    (tools/fit_erfc_table.py, tests/test_erfc_table.py).  The table is why a workgroup is four waves: they share it;
 //  * the four waves of a workgroup take four tile pairs (I0 .. I0+3, J) behind ONE j-tile image in LDS, stored as three double2
 //    arrays (x,y | z,q | sigma/2, 2 sqrt(eps)) and read with three ds_read_b128 per step (twice over, so that l + s never wraps);
 //  * per dimension with a tile-pair-wide periodic image (CLS_UNIFORM_*, k_classify) the displacement is  (x_i - x_j) - B img : two
@@ -31,7 +33,6 @@ namespace mpmc {
 constexpr int kSweepWaves = 4;
 constexpr int kSpecialAtom = AF_FROZEN | AF_NULL_RD | AF_HAS_DISP | AF_NEG_SIGMA | AF_ZERO_SIGMA | AF_ZERO_Q; // (what pair_flags / lj_mix look at)
 constexpr int kUnmaskable = kAtomFlagsMixing; // (pair_math.h) these change the MIXING (lj_mix), not just the masks: the generic kernel keeps them
-constexpr double kTwoOverSqrtPi = 2.0 * kOneOverSqrtPi;
 
 __device__ __forceinline__ int sweep_tp_index(int I, int J, int nt) { return I * nt - (I * (I - 1)) / 2 + (J - I); }
 
@@ -116,18 +117,21 @@ __device__ __forceinline__ void sweep_finish(const double2 *__restrict__ s_se, c
 			const double xs = x * MPMC_ERFTAB_INV_H;
 			const int it = (int)xs;
 			const double dd = __builtin_amdgcn_fract(xs) - 0.5;
-			const double2 c01 = s_tab[it], c23 = s_tab[MPMC_ERFTAB_PIECES + it], c4g = s_tab[2 * MPMC_ERFTAB_PIECES + it];
-			const double w = fma(fma(fma(fma(c4g.x, dd, c23.y), dd, c23.x), dd, c01.y), dd, c01.x); // erfcx(x)
-			const double d = dd * (1.0 / MPMC_ERFTAB_INV_H);
-			const double t = -(d * fma(2.0, x, -d)); // x_k^2 - x^2
-			constexpr double e[MPMC_ERFTAB_EXP_DEG + 1] = {MPMC_ERFTAB_EXP_COEFFS};
-			double p = e[MPMC_ERFTAB_EXP_DEG];
-#pragma unroll
-			for (int k = MPMC_ERFTAB_EXP_DEG - 1; k >= 0; --k) p = hstep(p, t, e[k]);
-			const double G = c4g.y * p; // exp(-x^2)
-			if (es_on) A.e_re = fma((I.q * zq.y) * (G * w), ir, A.e_re); // q_i q_j erfc(alpha r) / r
+			const double2 c01 = s_tab[it], c23 = s_tab[MPMC_ERFTAB_PIECES + it], c45 = s_tab[2 * MPMC_ERFTAB_PIECES + it];
+			// p(dd) = erfc(x); with the field also p'(dd) = -(2 / sqrt(pi)) exp(-x^2) / 128 from the same coefficients (Horner's pass for a
+			// polynomial and its derivative)
+			double b = fma(c45.y, dd, c45.x), d1 = 0.0;
+			if (FIELD) d1 = fma(c45.y, dd, b);
+			b = fma(b, dd, c23.y);
+			if (FIELD) d1 = fma(d1, dd, b);
+			b = fma(b, dd, c23.x);
+			if (FIELD) d1 = fma(d1, dd, b);
+			b = fma(b, dd, c01.y);
+			if (FIELD) d1 = fma(d1, dd, b);
+			const double erfc_x = fma(b, dd, c01.x);
+			if (es_on) A.e_re = fma((I.q * zq.y) * erfc_x, ir, A.e_re); // q_i q_j erfc(alpha r) / r
 			if (fld_on) { // real_term :2919-2934: (2 alpha r / sqrt(pi) exp(-alpha^2 r^2) + erfc) / r^3, erf form (= that - 1) for es_excluded pairs
-				double B = G * fma(kTwoOverSqrtPi, x, w);
+				double B = fma(-xs, d1, erfc_x); // erfc(x) + 2 x / sqrt(pi) exp(-x^2) = p - (x / H) p'
 				if (MODE >= 1) B -= excl_es ? 1.0 : 0.0;
 				const double fac = B * ((ir * ir) * ir);
 				const double fj = fac * zq.y, fi = fac * I.q;

@@ -150,6 +150,8 @@ def lib():
     L.mpmc_debug_last_pair_kernel.argtypes = [vp]
     L.mpmc_debug_last_trial_was_full.argtypes = [vp]
     L.mpmc_debug_erfc_table.argtypes = [C.c_double, dp, dp]
+    if hasattr(L, "mpmc_debug_erfc_table_field") or not os.environ.get("MPMC_ENERGY_LIB"):
+        L.mpmc_debug_erfc_table_field.argtypes = [C.c_double, dp]
     L.mpmc_debug_pair_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.mpmc_debug_time_panel.argtypes = [vp, C.c_int, dp]
     L.mpmc_debug_time_pair.argtypes = [vp, C.c_int, dp]
