@@ -31,7 +31,7 @@ extern "C" int mpmc_debug_erfc_table(double x, double *erfc_out, double *gauss_o
 	if (!(x >= 0.0) || !(x < MPMC_ERFTAB_XMAX)) return 1;
 	const double xs = x * MPMC_ERFTAB_INV_H;
 	const int it = (int)xs;
-	const double dd = (xs - (double)it) - 0.5;
+	const double dd = xs - (double)it;
 	const double *c = kRows[it];
 	double b = c[5], d1 = c[5];
 	for (int k = 4; k >= 1; --k) {
@@ -49,7 +49,7 @@ extern "C" int mpmc_debug_erfc_table_field(double x, double *factor_out) {
 	if (!(x >= 0.0) || !(x < MPMC_ERFTAB_XMAX) || !factor_out) return 1;
 	const double xs = x * MPMC_ERFTAB_INV_H;
 	const int it = (int)xs;
-	const double dd = (xs - (double)it) - 0.5;
+	const double dd = xs - (double)it;
 	const double *c = kRows[it];
 	double b = c[5], d1 = c[5];
 	for (int k = 4; k >= 1; --k) {

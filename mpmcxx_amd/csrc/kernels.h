@@ -145,7 +145,7 @@ void launch_pair_fused(hipStream_t st, const AtomsDev &at, const Box &bx, const 
 // ---- the fast pair sweep (kernels_pair.hip): any cell, Ewald electrostatics with alpha r_c inside the erfc table; every tile pair
 // except those with an atom that changes lj_mix (kAtomFlagsMixing: sigma < 0, dispersion coefficients) ----
 struct PairSweepParams {
-	double ewald_alpha, polar_damp, thole_far_x;
+	double alpha_scaled, polar_damp, thole_far_x; // alpha_scaled: Ewald alpha over the erfc table's piece width
 	int store;      // write the Thole tensor store
 	int nt;         // tiles
 	int have_shift; // tp_shift / CLS_UNIFORM_* are valid

@@ -105,18 +105,17 @@ __device__ __forceinline__ void sweep_finish(const double2 *__restrict__ s_se, c
 	if (in_lj) {
 		const double2 se = s_se[jl];
 		if (lj_on) {
-			const double sig = I.hs + se.x, e4 = I.e2 * se.y; // Lorentz-Berthelot: (s_i + s_j)/2, 4 sqrt(e_i e_j)
+			const double sig = I.hs + se.x; // Lorentz-Berthelot: (s_i + s_j)/2; of 4 sqrt(e_i e_j) the j-atom's factor here, the lane's own at the end of the walk
 			const double sr = sig * ir;
 			const double s3 = (sr * sr) * sr;
 			const double s6 = s3 * s3;
-			A.e_lj = fma(e4, fma(s6, s6, -s6), A.e_lj); // 4 eps (s^12 - s^6)  (:965-993)
+			A.e_lj = fma(se.y, fma(s6, s6, -s6), A.e_lj); // 4 eps (s^12 - s^6)  (:965-993)
 		}
 		const bool fld_on = FIELD && in_es && !(MODE == 2 && no_field);
 		if (es_on || fld_on) {
-			const double x = r * pp.ewald_alpha;
-			const double xs = x * MPMC_ERFTAB_INV_H;
+			const double xs = r * pp.alpha_scaled; // alpha r / H: the integer part is the piece, the fraction the argument of its polynomial
 			const int it = (int)xs;
-			const double dd = __builtin_amdgcn_fract(xs) - 0.5;
+			const double dd = __builtin_amdgcn_fract(xs);
 			const double2 c01 = s_tab[it], c23 = s_tab[MPMC_ERFTAB_PIECES + it], c45 = s_tab[2 * MPMC_ERFTAB_PIECES + it];
 			// p(dd) = erfc(x); with the field also p'(dd) = -(2 / sqrt(pi)) exp(-x^2) / 128 from the same coefficients (Horner's pass for a
 			// polynomial and its derivative)
@@ -129,7 +128,7 @@ __device__ __forceinline__ void sweep_finish(const double2 *__restrict__ s_se, c
 			b = fma(b, dd, c01.y);
 			if (FIELD) d1 = fma(d1, dd, b);
 			const double erfc_x = fma(b, dd, c01.x);
-			if (es_on) A.e_re = fma((I.q * zq.y) * erfc_x, ir, A.e_re); // q_i q_j erfc(alpha r) / r
+			if (es_on) A.e_re = fma(zq.y * erfc_x, ir, A.e_re); // q_i q_j erfc(alpha r) / r, the lane's own q_i at the end of the walk
 			if (fld_on) { // real_term :2919-2934: (2 alpha r / sqrt(pi) exp(-alpha^2 r^2) + erfc) / r^3, erf form (= that - 1) for es_excluded pairs
 				double B = fma(-xs, d1, erfc_x); // erfc(x) + 2 x / sqrt(pi) exp(-x^2) = p - (x / H) p'
 				if (MODE >= 1) B -= excl_es ? 1.0 : 0.0;
@@ -376,6 +375,8 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 		}
 #undef MPMC_SWEEP_UM
 #undef MPMC_SWEEP_ARGS
+		A.e_lj *= Ai.e2; // (the i-atom's factors of 4 sqrt(e_i e_j) and q_i q_j, once per wave instead of once per pair)
+		A.e_re *= Ai.q;
 	}
 	// the j-atom whose accumulator this lane ended up holding: after step s (no rotation behind the last one) lane l pairs with (l + s) & 63
 	const int jown = (lane + s_end - 1) & 63;
@@ -463,7 +464,7 @@ void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const 
                        bool split, bool fast_geometry) {
 	PairSweepParams pp;
 	pp.split = split ? 1 : 0;
-	pp.ewald_alpha = fp.ewald_alpha;
+	pp.alpha_scaled = fp.ewald_alpha * MPMC_ERFTAB_INV_H; // (a power of two: (alpha r) / H and (alpha / H) r are the same double)
 	pp.polar_damp = fp.polar_damp;
 	pp.thole_far_x = fp.thole_far_x;
 	pp.store = (fp.do_thole && ab) ? 1 : 0;
