@@ -36,6 +36,7 @@ namespace mpmc {
 int panel_segment_entries(int J) { return J / 2 + 3; }
 constexpr int kPanFar = 8, kPanDiag = 16;
 constexpr int kPanelWaves = 4; // waves per workgroup: they split the steps of ONE entry's walk
+constexpr double kFarSumScale = 0.125; // the far-field walk works with 2 / r (pan_step): its sums carry 8 / r^3
 
 __device__ __forceinline__ int tp_index(int I, int J, int nt) { return I * nt - (I * (I - 1)) / 2 + (J - I); }
 
@@ -153,11 +154,14 @@ __device__ __forceinline__ void pan_step(const Box &bx, const double2 *__restric
 		double ta, tb;
 		if (FAR) { // bare dipole tensor T = a (w d (x) d - 1), a = 1/r^3, w = 3/r^2: beyond lambda r = kTholeFarX the Thole damping is dropped (kernels.h)
 			const double r2 = fma(oz, oz, fma(oy, oy, ox * ox));
-			const double ir = fast_rsqrt_1(r2);
-			const double ir2 = ir * ir;
-			ta = ir2 * ir;
+			// 2 / r: hardware seed and one Newton step in its product form y (3 - x y^2) -- the halving that 1 / r would need is a power of two and is
+			// applied once per wave to the sums instead (kFarSumScale: a = 8 / r^3 here); ~2e-14 relative like fast_rsqrt_1, one instruction less per pair
+			const double y0 = __builtin_amdgcn_rsq(r2);
+			const double y2 = y0 * fma(-(r2 * y0), y0, 3.0);
+			const double i4 = y2 * y2; // 4 / r^2
+			ta = i4 * y2;              // 8 / r^3
 			if (PAD) ta *= vj; // padded slots of the last tile
-			tb = 3.0 * ir2; // (w, not b = a w: the factor a is applied once per component below, which saves the product a w)
+			tb = 0.75 * i4; // 3 / r^2  (w, not b = a w: the factor a is applied once per component below, which saves the product a w)
 			const double sj = tb * fma(oz, mjz, fma(oy, mjy, ox * mjx));
 			const double si = tb * fma(oz, m[k][2], fma(oy, m[k][1], ox * m[k][0]));
 			A.f[k][0] = fma(ta, fma(sj, ox, -mjx), A.f[k][0]);
@@ -350,6 +354,14 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	}
 #undef MPMC_PWALK
 #undef MPMC_PWALK_TRI
+	if (far) { // the far-field walk accumulates with a = 8 / r^3 (pan_step)
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+#pragma unroll
+			for (int k = 0; k < NI; ++k) A.f[k][d] *= kFarSumScale;
+			A.g[d] *= kFarSumScale;
+		}
+	}
 	// the waves' partial sums meet in LDS: F of lane l's own atoms, G parked at the atom it belongs to -- after n_steps - 1 rotations
 	// lane l holds the accumulator of j = (l + s_first + n_steps - 1) & 63
 	{
