@@ -247,6 +247,75 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env, cwd=os.getcwd())
 
 
+def join_cabi_communicator(dist, torch, world, rank, dev, ready_here, make_unique_id, make_comm, timeout_s, comm_error):
+    """The RCCL communicator of the C ABI for a job of `world` ranks, or None on EVERY rank.  Returns (comm, a_thread_is_stuck, why_not).
+
+    Rank 0 makes the RCCL unique id, the launcher's channel (torch.distributed) carries its 128 bytes, every rank joins.  Three votes keep
+    the ranks together: (1) everything a rank does on its own first (device index valid, RCCL symbols resolved) -- a rank that failed there
+    alone would leave the others inside the collective initialisation; (2) ncclCommInitRank and a probe all-gather BLOCK until every rank
+    is in them, and on a node where that never happens the job would hang: they run on a helper thread, and a rank that is not through after
+    `timeout_s` votes no; (3) the outcome is a MIN over ranks, so all ranks use the communicator or none does (the combine then goes
+    through torch.distributed).  `make_unique_id()`, `make_comm(uid)` and `comm_error` are parameters so that the votes can be exercised
+    without RCCL (tests/test_bench_launch.py: two gloo ranks, one of which hangs)."""
+    import threading
+
+    import numpy as np
+
+    def vote(value, op):
+        t = torch.tensor([int(value)], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=op)
+        return int(t.item())
+
+    uid = [None]
+    if vote(1 if ready_here else 0, dist.ReduceOp.MIN) == 1:
+        if rank == 0:
+            try:
+                uid = [make_unique_id()]
+            except comm_error:
+                uid = [None]
+        dist.broadcast_object_list(uid, src=0)
+    comm, stuck, ok, why = None, False, 1, ""
+    if uid[0] is None:
+        ok, why = 0, "RCCL could not be opened below Python on every rank"
+    else:
+        box = {}
+
+        def join_ranks():
+            try:
+                c = make_comm(uid[0])
+                probe = c.allgather(np.array([float(rank)]))
+                box["probe_ok"] = bool(np.array_equal(np.asarray(probe).reshape(-1), np.arange(world, dtype=np.float64)))
+                box["comm"] = c
+            except comm_error as e:
+                box["err"] = str(e)
+
+        th = threading.Thread(target=join_ranks, daemon=True)
+        th.start()
+        th.join(timeout_s)
+        if th.is_alive():
+            stuck, ok = True, 0
+            print(f"[rank {rank}] the C-ABI communicator did not come up within {timeout_s:.0f} s; voting for torch.distributed", file=sys.stderr)
+        elif "err" in box:
+            ok = 0
+            print(f"[rank {rank}] mpmc_comm_init_rank failed ({box['err']}); falling back to torch.distributed", file=sys.stderr)
+        else:
+            comm = box["comm"]
+            if not box["probe_ok"]:
+                ok = 0
+                print(f"[rank {rank}] the probe all-gather over the C-ABI communicator returned the wrong ranks; falling back to torch.distributed", file=sys.stderr)
+    all_ok = vote(ok, dist.ReduceOp.MIN) == 1
+    any_stuck = vote(1 if stuck else 0, dist.ReduceOp.MAX) == 1
+    if not all_ok:
+        if comm is not None and not any_stuck:
+            comm.close()  # (with a rank still inside the collective initialisation the communicator is left alone: destroying it can block too)
+        comm = None
+        if any_stuck:
+            why = f"the C-ABI communicator timed out after {timeout_s:.0f} s on some rank"
+        elif not why:
+            why = "mpmc_comm_init_rank or its probe all-gather failed on some rank"
+    return comm, any_stuck, why
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--launch", choices=["ranks", "inprocess"], default="ranks",
@@ -266,6 +335,9 @@ def main():
     ap.add_argument("--combine-impl", choices=["cabi", "torch"], default="cabi",
                     help="cabi: ncclAllGather inside libmpmc_energy.so (mpmc_pi_gather_beads; falls back to torch if RCCL cannot be initialised "
                          "below Python, recorded in config.combine_impl); torch: torch.distributed")
+    ap.add_argument("--comm-init-timeout", type=float, default=120.0,
+                    help="seconds a rank waits for the C-ABI communicator (ncclCommInitRank + one probe all-gather, both blocking collectives) before "
+                         "the job falls back to torch.distributed for the combine instead of hanging")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="diagnostic (rounds 1-3 behaviour): per-launch HIP events on one bead's stream INSIDE the timed region; by default the timed "
                          "region carries no instrumentation and the in-flight kernel durations come from a separate short pass behind it")
@@ -334,38 +406,16 @@ def main():
         rccl_ver = energy.rccl_version()
     except energy.MpmcError:
         pass
+    state_comm_stuck = False
     if world > 1 and args.combine_impl == "cabi" and args.dist_backend == "nccl" and args.combine == "gather":
-        # rank 0 makes the RCCL unique id, the launcher's channel (torch.distributed) carries its 128 bytes, every rank joins.
-        # ncclCommInitRank blocks until ALL ranks have called it, so first make sure every rank can open RCCL below Python at all.
-        ok = 1
-        # ... and that everything a rank does on its own before the blocking ncclCommInitRank can succeed there (device index valid, RCCL
-        # symbols resolved): a rank that failed one of these alone would leave the others waiting inside the collective initialisation
-        ready_here = 1 if (rccl_ver and 0 <= local_rank < energy.device_count()) else 0
-        ready = torch.tensor([ready_here], dtype=torch.int32, device=dev)
-        dist.all_reduce(ready, op=dist.ReduceOp.MIN)
-        uid = [None]
-        if int(ready.item()) == 1:
-            try:
-                uid = [energy.Comm.unique_id() if rank == 0 else None]
-            except energy.MpmcError:
-                uid = [None]
-            dist.broadcast_object_list(uid, src=0)
-        if uid[0] is None:
-            ok = 0
-        else:
-            try:
-                comm = energy.Comm(world, rank, uid[0], local_rank)
-            except energy.MpmcError as e:
-                print(f"[rank {rank}] mpmc_comm_init_rank failed ({e}); falling back to torch.distributed", file=sys.stderr)
-                ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:  # all ranks or none
-            if comm is not None:
-                comm.close()
-            comm = None
-        else:
+        ready_here = bool(rccl_ver) and 0 <= local_rank < energy.device_count()
+        comm, state_comm_stuck, why = join_cabi_communicator(dist, torch, world, rank, dev, ready_here, energy.Comm.unique_id,
+                                                             lambda uid: energy.Comm(world, rank, uid, local_rank), args.comm_init_timeout,
+                                                             energy.MpmcError)
+        if comm is not None:
             combine_impl = "libmpmc_energy.so: mpmc_pi_gather_beads (ncclAllGather, communicator from mpmc_comm_init_rank)"
+        elif why:
+            combine_impl = f"torch.distributed ({why})"
 
     P = args.beads
     n_gpus = world * n_dev
@@ -714,6 +764,10 @@ def main():
         comm.close()
     if world > 1:
         dist.destroy_process_group()
+    if state_comm_stuck:  # a helper thread is still inside a blocking RCCL call: leave without running its destructors
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

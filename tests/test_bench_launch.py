@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 import util
 
 
@@ -29,3 +31,77 @@ def test_the_parent_of_a_bare_multi_gpu_run_never_imports_torch():
     assert "import torch" not in launcher and "os.exec" not in launcher and "execv" not in src
     main = src[src.index("def main"):]
     assert main.index("sys.exit(self_launch(args))") < main.index("import torch")
+
+
+# ---- the votes around the C-ABI communicator (bench.join_cabi_communicator), two gloo ranks, RCCL replaced by stand-ins ----------------
+class _CommError(Exception):
+    pass
+
+
+class _StandInComm:
+    def __init__(self, world):
+        self.world, self.closed = world, False
+
+    def allgather(self, local):
+        import numpy as np
+
+        return np.arange(self.world, dtype=np.float64).reshape(self.world, 1)
+
+    def close(self):
+        self.closed = True
+
+
+def _vote_worker(rank, world, port, case, out):
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, util.ROOT)
+    import bench
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        made = {}
+
+        def make_comm(uid):
+            assert uid == b"id-of-rank-0"
+            if case == "rank1_hangs" and rank == 1:
+                time.sleep(120)  # (a daemon thread: the worker leaves through os._exit below, as bench.py does)
+            if case == "rank1_fails" and rank == 1:
+                raise _CommError("no transport")
+            made["comm"] = _StandInComm(world)
+            return made["comm"]
+
+        ready = not (case == "rank0_not_ready" and rank == 0)
+        t0 = time.time()
+        comm, stuck, why = bench.join_cabi_communicator(dist, torch, world, rank, "cpu", ready, lambda: b"id-of-rank-0", make_comm, 3.0, _CommError)
+        out[rank] = (comm is not None, stuck, why, made.get("comm").closed if made.get("comm") else None, time.time() - t0)
+    finally:
+        dist.destroy_process_group()
+    if case == "rank1_hangs":
+        os._exit(0)
+
+
+@pytest.mark.parametrize("case", ["all_join", "rank1_hangs", "rank1_fails", "rank0_not_ready"])
+def test_every_rank_takes_the_same_route_around_the_cabi_communicator(case):
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29100 + (os.getpid() % 400) + ["all_join", "rank1_hangs", "rank1_fails", "rank0_not_ready"].index(case)
+    mp.spawn(_vote_worker, args=(2, port, case, out), nprocs=2, join=True)
+    assert set(out.keys()) == {0, 1}
+    have = [out[r][0] for r in (0, 1)]
+    assert have[0] == have[1]  # all ranks or none
+    if case == "all_join":
+        assert have == [True, True] and not out[0][1] and out[0][2] == ""
+    else:
+        assert have == [False, False]
+        assert out[0][1] == out[1][1] == (case == "rank1_hangs")
+        assert out[0][2] and out[1][2]
+        if case == "rank1_hangs":
+            assert "timed out" in out[0][2] and out[0][4] < 30 and out[0][3] is False  # rank 0's communicator is left alone, nobody waits for the hung rank
+        if case == "rank1_fails":
+            assert out[0][3] is True  # rank 0 had joined: its communicator is closed again
