@@ -55,15 +55,24 @@ FP64_FMA_SUSTAINED_TFLOPS = 59.0  # what tools/microbench_f64.hip measures for b
 # a uniform dimension costs nothing in the Jacobi kernels (the i-atom is shifted once) and 1 subtraction in the pair sweep.
 #   Jacobi contraction, (a, b) read from the store:  d 3,  mu_j.d and mu_i.d 2 x (mul + 2 fma) 10,  b x dot 2,
 #       F_i += -a mu_j + (b mu_j.d) d and the same for F_j: 12 fma 24                                                   = 39 + 3 nu
-#   ... recomputed (far field): + r^2 (mul + 2 fma) 5, 1/r = rsq 1 + one Newton step (2 mul + 2 fma) 6, 1/r^3 and 3/r^5 4   = 55 + 3 nu
-#   pair sweep (k_pair_sweep), every walked pair: d 3, image nu x 3 + (3 - nu) x 1, r^2 (3 mul + 2 add) 5, 1/r 7, r 1  = 19 + 2 nu
-#       inside the cutoff: LJ (add, 6 mul, 2 fma) 11 - 1 = 10;  erfc and Gaussian from the LDS table: x, x / h, centring 3, degree-4
-#       interpolant 8, t = x_k^2 - x^2 4, exp(t) degree 6 12, G_k exp(t) 1, q_i q_j erfc / r (3 mul + fma) 5 = 33;  field factor
-#       (fma, 5 mul) 7 + 6 fma 12 + 1 = 20                                                                           = 63
+#   ... recomputed (far field): + r^2 (mul + 2 fma) 5, 2 / r = rsq 1 + one Newton step in product form (mul, fma, mul) 4, 4 / r^2, 8 / r^3,
+#       3 / r^2 3 (the power of two goes onto the sums once per wave)                                                    = 52 + 3 nu
+#       (rounds 1-3 and most of round 4: 55 -- Newton step as a correction, 2 mul + 2 fma, and one product more)
+#   pair sweep (k_pair_sweep), every walked pair: per dimension 1 (subtraction from the pre-shifted i-atom) or, without a common image,
+#       sub + mul + (rint) + fma 4; r^2 (mul + 2 fma) 5, 1/r = rsq + Newton (2 mul + 2 fma) 7, r 1                          = 16 + 3 nu
+#       (round 3, unfused geometry: 19 + 2 nu)
+#       inside the cutoff: LJ (add, 4 mul, 2 fma) 9;  erfc from the LDS table: alpha r / H 1, degree-5 interpolant 5 fma 10, q_j erfc / r
+#       (mul + fma) 3 = 14;  with the field its derivative 4 fma 8, the field factor p - (x / H) p' (fma) 2, / r^3 3, q_j, q_i 2,
+#       6 fma 12 = 27                                                                                                    = 23 / 50
+#       (rounds 3-4 with the erfcx x G_k exp(t) table: 43 / 63)
 #       Thole damping and (a, b) for the pairs of the stored tile pairs: 1/r^3, 1/r^5 4, lambda r 1, exp 28, polynomials 11, a, b 3   = 47
 #   reciprocal space: K N (6 + ~40) for the structure factors, the same again for the field
-FLOP_JAC_STORED, FLOP_JAC_FAR, FLOP_JAC_PER_NU = 39.0, 55.0, 3.0
-FLOP_SWEEP_BASE, FLOP_SWEEP_PER_NU, FLOP_SWEEP_CUTOFF, FLOP_SWEEP_STORE = 19.0, 2.0, 63.0, 47.0
+# The counts follow the ARITHMETIC THE KERNELS DO (checked against the PMC's FMA / MUL / ADD counts, profiles/*_pmc_stalls.txt): a kernel
+# that reaches the same result with fewer operations gets FASTER and its `frac` goes DOWN.  The line therefore carries both: `frac` (this
+# build's arithmetic) and `frac_with_round3_flop_count` (the yardstick the round-3 review quoted its targets in).
+FLOP_JAC_STORED, FLOP_JAC_FAR, FLOP_JAC_PER_NU = 39.0, 52.0, 3.0
+FLOP_SWEEP_BASE, FLOP_SWEEP_PER_NU, FLOP_SWEEP_CUTOFF, FLOP_SWEEP_CUTOFF_NO_FIELD, FLOP_SWEEP_STORE = 16.0, 3.0, 50.0, 23.0, 47.0
+FLOP_R3 = {"jac_far": 55.0, "sweep_base": 19.0, "sweep_per_nu": 2.0, "sweep_cutoff": 63.0, "sweep_cutoff_no_field": 43.0}
 FLOP_RECIP_PER_K_ATOM = 2 * 46.0
 
 
@@ -193,8 +202,10 @@ def other_configs(headline_beads, headline_value, local_rank: int, workdir: str)
                 cut = float(r["n_es_in_cutoff"])
                 polar = name == "ion10k_polar"
                 fl = (FLOP_SWEEP_BASE * ps["pairs_swept"] + FLOP_SWEEP_PER_NU * ps["nonuniform_dims_x_pairs_swept"]
-                      + (FLOP_SWEEP_CUTOFF if polar else FLOP_SWEEP_CUTOFF - 20.0) * cut + (FLOP_SWEEP_STORE * ps["pairs_stored"] if polar else 0.0))
-                roof = {"kernel": "k_pair_sweep" if S.last_pair_kernel() == "sweep" else "k_pair_fused", "algorithmic_flops": fl, "avg_launch_ms": ms,
+                      + (FLOP_SWEEP_CUTOFF if polar else FLOP_SWEEP_CUTOFF_NO_FIELD) * cut + (FLOP_SWEEP_STORE * ps["pairs_stored"] if polar else 0.0))
+                fl_r3 = (FLOP_R3["sweep_base"] * ps["pairs_swept"] + FLOP_R3["sweep_per_nu"] * ps["nonuniform_dims_x_pairs_swept"]
+                         + (FLOP_R3["sweep_cutoff"] if polar else FLOP_R3["sweep_cutoff_no_field"]) * cut + (FLOP_SWEEP_STORE * ps["pairs_stored"] if polar else 0.0))
+                roof = {"kernel": "k_pair_sweep" if S.last_pair_kernel() == "sweep" else "k_pair_fused", "algorithmic_flops": fl, "flops_by_round3_count": fl_r3, "avg_launch_ms": ms,
                         "clock": "30 launches back to back between ONE pair of HIP events on the kernel's stream (kernel alone on the GPU)",
                         "pairs": ps["pairs"], "pairs_in_cutoff": int(cut)}
             except energy.MpmcError:
@@ -202,6 +213,8 @@ def other_configs(headline_beads, headline_value, local_rank: int, workdir: str)
         if roof:
             ach = roof["algorithmic_flops"] / (roof["avg_launch_ms"] * 1e-3) / 1e12
             roof.update({"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS})
+            if roof.get("flops_by_round3_count"):
+                roof["frac_with_round3_flop_count"] = roof["flops_by_round3_count"] / (roof["avg_launch_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
         entry["roofline"] = roof
         S.close()
         if name == "ion10k_polar" and headline_beads >= 32 and headline_value:
@@ -599,6 +612,9 @@ def main():
     flops_pair = (FLOP_SWEEP_BASE * pairs.get("pairs_swept", 0) + FLOP_SWEEP_PER_NU * pairs.get("nonuniform_dims_x_pairs_swept", 0)
                   + FLOP_SWEEP_CUTOFF * cut_frac * pairs.get("pairs", 0) + FLOP_SWEEP_STORE * pairs.get("pairs_stored", 0))
     flops_eval = flops_pair + iters * flops_jacobi + (FLOP_RECIP_PER_K_ATOM * K * n if K else 0.0)
+    flops_r3 = {"dipole_iter": flops_jacobi + (FLOP_R3["jac_far"] - FLOP_JAC_FAR) * pairs.get("pairs_far", 0),
+                "pair": ((FLOP_R3["sweep_base"] * pairs.get("pairs_swept", 0) + FLOP_R3["sweep_per_nu"] * pairs.get("nonuniform_dims_x_pairs_swept", 0)
+                          + FLOP_R3["sweep_cutoff"] * cut_frac * pairs.get("pairs", 0) + FLOP_SWEEP_STORE * pairs.get("pairs_stored", 0)))}
     bytes_jacobi = 16.0 * 4096 * pairs.get("tile_pairs_stored", 0) + n * 80.0
 
     if rank == 0:
@@ -623,6 +639,8 @@ def main():
                            "per launch (kernel alone on the GPU)" if back_to_back.get(cls_key) else "HIP events around every launch on the kernel's stream")}
             if back_to_back.get(cls_key):
                 e["avg_launch_ms_batches"] = back_to_back_runs.get(cls_key)
+            if flops_r3.get(cls_key):  # the same duration priced with the operation counts of the round-3 kernels (what the review's targets were quoted in)
+                e["frac_with_round3_flop_count"] = flops_r3[cls_key] / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
             # context, not the judged fraction: against the FMA rate the chip sustains (clock under fp64 load), and the ceiling of THIS instruction
             # stream at that rate -- algorithmic flops per issued VALU instruction (PMC) x the sustained issue rate
             e["frac_of_sustained_fma_rate"] = ach / FP64_FMA_SUSTAINED_TFLOPS
@@ -683,6 +701,7 @@ def main():
         roof["pairs"] = dict(pairs, in_cutoff_fraction=cut_frac)
         roof["flop_model"] = {"jacobi_stored": FLOP_JAC_STORED, "jacobi_far": FLOP_JAC_FAR, "jacobi_per_nonuniform_dim": FLOP_JAC_PER_NU,
                               "sweep_base": FLOP_SWEEP_BASE, "sweep_per_nonuniform_dim": FLOP_SWEEP_PER_NU, "sweep_in_cutoff": FLOP_SWEEP_CUTOFF,
+                              "sweep_in_cutoff_no_field": FLOP_SWEEP_CUTOFF_NO_FIELD, "round3_counts": FLOP_R3,
                               "sweep_stored": FLOP_SWEEP_STORE, "what": "fp64 flops per unordered atom pair, FMA = 2 (top of bench.py, DESIGN.md section 3); "
                                                                         "pair counts are exact atom pairs per tile-pair class (mpmc_debug_pair_stats)"}
         roof["share_of_device_time_alone"] = share[dom] / max(sum((src.get(k) or 0.0) * (iters if k in ("dipole_iter", "reduce") else 1) for k in src), 1e-30)
