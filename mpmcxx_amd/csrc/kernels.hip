@@ -479,7 +479,8 @@ __global__ __launch_bounds__(64) void k_field_recip_tab(AtomsDev at, Box bx, Rec
 	const int per = (rc.K + (int)gridDim.y - 1) / (int)gridDim.y; // gridDim.y = recip_ksplit(n_pad) slices
 	const int k0 = blockIdx.y * per, k1 = min(rc.K, k0 + per);
 	double ex = 0, ey = 0, ez = 0;
-	for (int k = k0; k < k1; ++k) {
+#pragma unroll 8
+	for (int k = k0; k < k1; ++k) { // (unrolled: the wave-uniform loads of eight k-vectors are requested together instead of one latency per k-vector)
 		const int4 l = rc.lvec[k];
 		const double4 sf = rc.sf[k];
 		const double4 kw = rc.kw[k];
