@@ -460,24 +460,31 @@ __global__ __launch_bounds__(512) void k_field_finalize(AtomsDev at, Box bx, int
 	}
 }
 
-// the field sum with the factorised phases: thread = atom, its table column [dir][m][lane] in LDS (every lane reads the same m: no
-// conflicts), k-vectors walked by all lanes together (l from uniform loads)
-__global__ __launch_bounds__(64) void k_field_recip_tab(AtomsDev at, Box bx, RecipDev rc, int kmax, double *__restrict__ e_part) {
+// the field sum with the factorised phases: lane = atom, its table column [dir][m][lane] in LDS (every lane reads the same m: no
+// conflicts), k-vectors walked by all lanes together (l from uniform loads).  A workgroup is FOUR waves behind one table (round 4: one
+// wave per (tile, slice) walked its 89 k-vectors behind three sincos and 21 dependent complex products of its own -- a 30 us latency
+// chain at one wave per SIMD): waves 0..2 build one direction each, then every wave takes a quarter of the slice's k-vectors and the
+// quarters are added in wave order.
+constexpr int kFieldRecipWaves = 4;
+__global__ __launch_bounds__(64 * kFieldRecipWaves) void k_field_recip_tab(AtomsDev at, Box bx, RecipDev rc, int kmax, double *__restrict__ e_part) {
 	extern __shared__ double2 tab[];
+	__shared__ double s_e[kFieldRecipWaves][3][kTile];
 	const int KM1 = kmax + 1;
-	const int lane = threadIdx.x, i = blockIdx.x * kTile + lane;
-	const double4 p = at.xyzq[i];
-	for (int q = 0; q < 3; ++q) {
-		const double2 base = phase_base(bx, p, q);
+	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = blockIdx.x * kTile + lane;
+	if (w < 3) {
+		const double2 base = phase_base(bx, at.xyzq[i], w);
 		double2 v = make_double2(1.0, 0.0);
-		tab[(size_t)(q * KM1) * kTile + lane] = v;
+		tab[(size_t)(w * KM1) * kTile + lane] = v;
 		for (int m = 1; m <= kmax; ++m) {
 			v = cmul(v, base);
-			tab[(size_t)(q * KM1 + m) * kTile + lane] = v;
+			tab[(size_t)(w * KM1 + m) * kTile + lane] = v;
 		}
 	}
+	__syncthreads();
 	const int per = (rc.K + (int)gridDim.y - 1) / (int)gridDim.y; // gridDim.y = recip_ksplit(n_pad) slices
-	const int k0 = blockIdx.y * per, k1 = min(rc.K, k0 + per);
+	const int s0 = blockIdx.y * per, s1 = min(rc.K, s0 + per);
+	const int quarter = (s1 - s0 + kFieldRecipWaves - 1) / kFieldRecipWaves;
+	const int k0 = min(s1, s0 + w * quarter), k1 = min(s1, k0 + quarter);
 	double ex = 0, ey = 0, ez = 0;
 #pragma unroll 8
 	for (int k = k0; k < k1; ++k) { // (unrolled: the wave-uniform loads of eight k-vectors are requested together instead of one latency per k-vector)
@@ -495,10 +502,15 @@ __global__ __launch_bounds__(64) void k_field_recip_tab(AtomsDev at, Box bx, Rec
 		ey += kw.y * g;
 		ez += kw.z * g;
 	}
-	double *o = e_part + ((size_t)blockIdx.y * at.n_pad + i) * 3;
-	o[0] = ex;
-	o[1] = ey;
-	o[2] = ez;
+	s_e[w][0][lane] = ex;
+	s_e[w][1][lane] = ey;
+	s_e[w][2][lane] = ez;
+	__syncthreads();
+	if (w == 0) {
+		double *o = e_part + ((size_t)blockIdx.y * at.n_pad + i) * 3;
+#pragma unroll
+		for (int d = 0; d < 3; ++d) o[d] = ((s_e[0][d][lane] + s_e[1][d][lane]) + s_e[2][d][lane]) + s_e[3][d][lane];
+	}
 }
 
 __global__ __launch_bounds__(64) void k_post_results(double *__restrict__ scal, double *__restrict__ out_host, double seq) {
@@ -519,7 +531,7 @@ void launch_post_results(hipStream_t st, double *scal, double *out_host, double 
 void launch_field_recip(hipStream_t st, const AtomsDev &at, const Box &bx, const RecipDev &rc, int kmax, double *e_recip_part) {
 	if (rc.lvec && kmax <= kRecipTabMaxK) {
 		const size_t lds = (size_t)3 * kTile * (kmax + 1) * sizeof(double2);
-		hipLaunchKernelGGL(k_field_recip_tab, dim3(at.n_pad / kTile, recip_ksplit(at.n_pad)), dim3(kTile), lds, st, at, bx, rc, kmax, e_recip_part);
+		hipLaunchKernelGGL(k_field_recip_tab, dim3(at.n_pad / kTile, recip_ksplit(at.n_pad)), dim3(kTile * kFieldRecipWaves), lds, st, at, bx, rc, kmax, e_recip_part);
 		return;
 	}
 	hipLaunchKernelGGL(k_field_recip, dim3(at.n_pad / kTile, recip_ksplit(at.n_pad)), dim3(kTile), 0, st, at, rc, e_recip_part);
