@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MPMC_ABI_VERSION 5
+#define MPMC_ABI_VERSION 6
 
 /* ---- status codes -------------------------------------------------------------------------------------- */
 #define MPMC_OK 0
@@ -152,6 +152,10 @@ typedef struct mpmc_timings {
 /* ---- library ---------------------------------------------------------------------------------------- */
 int mpmc_abi_version(void);
 int mpmc_device_count(int *count);
+/* (ABI 6) for host programs that carry no HIP binding of their own (bench.py's ranks import neither torch nor hip-python): a fence over
+ * everything this process has enqueued on `device`, and "<marketing name> (<gcnArchName>, <n> CUs)" for the job's log. */
+int mpmc_device_synchronize(int device);
+int mpmc_device_name(int device, char *name, int capacity);
 const char *mpmc_last_error(const mpmc_ctx *ctx); /* ctx may be NULL: last create-time error of this thread */
 
 /* ---- PeriodicBoundary::update (src/PeriodicBoundary.cpp:31-101): volume = det(basis), reciprocal = inverse,
@@ -252,14 +256,18 @@ double mpmc_pi_finish(const double sums4_global[4], int P, double obs4[4]);
 /* ---- the cross-GPU exchange of PI_calculate_potential on RCCL over xGMI ------------------------------------------
  * Reference: MPI_Allgather x 4 of one double per rank, then the ordered sum s = 0..P-1 (PathIntegral.cpp:763-766, :786-801).
  * Here: ONE ncclAllGather of `stride` fp64 per bead, then the same ordered sum on the host (bit-identical on every rank).
- * Bead s lives on rank s % n_ranks, local slot s / n_ranks.  RCCL is opened with dlopen at first use (librccl.so.1, or
- * $MPMC_RCCL_LIB); without it these calls fail with MPMC_ERR_COMM and nothing else in the library is affected.
+ * Bead s lives on rank s % n_ranks, local slot s / n_ranks.  RCCL is opened with dlopen at first use (mpmc_rccl_library_path);
+ * without it these calls fail with MPMC_ERR_COMM and nothing else in the library is affected.
  *   one process per GPU : rank 0 calls mpmc_comm_unique_id, the host program carries the 128 bytes to the other ranks
  *                         (MPI_Bcast, a file, the torch.distributed store), every rank calls mpmc_comm_init_rank;
  *   one process, G GPUs : mpmc_comm_init_all / mpmc_pi_allreduce. */
 typedef struct mpmc_comm mpmc_comm;
 #define MPMC_COMM_ID_BYTES 128
 int mpmc_rccl_version(int *version); /* ncclGetVersion: e.g. 22707 */
+/* (ABI 6) the file the RCCL entry points were resolved from and why that copy, e.g. "/opt/rocm/lib/librccl.so.1 (next to the bound
+ * libamdhip64)"; "" when RCCL could not be opened.  Order: $MPMC_RCCL_LIB, a librccl.so.1 the host program already mapped (shared, not
+ * duplicated), the copy next to the HIP runtime this library is bound to, the loader's search path; always RTLD_LOCAL. */
+const char *mpmc_rccl_library_path(void);
 int mpmc_comm_unique_id(char id[MPMC_COMM_ID_BYTES]);
 int mpmc_comm_init_rank(mpmc_comm **out, int n_ranks, int rank, const char id[MPMC_COMM_ID_BYTES], int device);
 int mpmc_comm_init_all(mpmc_comm **out, int n_devices, const int *devices /* NULL: 0..n_devices-1 */);

@@ -8,8 +8,8 @@
 //                            torch.distributed store ...) -> mpmc_comm_init_rank everywhere;
 //   * one process, G GPUs  : mpmc_comm_init_all (ncclCommInitAll), bead b on device b mod G; mpmc_pi_allreduce drives
 //                            evaluation and combine with one host thread per device.
-// RCCL is opened with dlopen at first use: the energy path itself has no link-time dependency on it, and a host program that already
-// carries an RCCL (PyTorch does) shares that copy.  Messages are 32 B .. a few KiB: latency-bound, link bandwidth is irrelevant.
+// RCCL is opened with dlopen at first use (see rccl() for which copy): the energy path itself has no link-time dependency on it, and a
+// host program that already carries an RCCL (PyTorch does) shares that copy.  Messages are 32 B .. a few KiB: latency-bound, link bandwidth is irrelevant.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -28,7 +28,7 @@ namespace {
 
 struct RcclApi {
 	void *handle = nullptr;
-	std::string error, path;
+	std::string error, path, how, described;
 	decltype(&ncclGetVersion) GetVersion = nullptr;
 	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
 	decltype(&ncclCommInitRank) CommInitRank = nullptr;
@@ -43,20 +43,49 @@ struct RcclApi {
 RcclApi g_rccl;
 std::string rccl_error_text() { return g_rccl.error.empty() ? std::string("librccl.so not found") : g_rccl.error; }
 
+// directory of the HIP runtime this library is bound to (the copy the dynamic linker resolved libamdhip64.so.7 to in THIS process)
+static std::string dir_of_bound_hip_runtime() {
+	Dl_info info;
+	if (!dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) || !info.dli_fname) return "";
+	std::string f = info.dli_fname;
+	size_t cut = f.rfind('/');
+	return cut == std::string::npos ? std::string() : f.substr(0, cut);
+}
+
+// Which RCCL (one per process, and the one that belongs to the HIP runtime in use):
+//   1. $MPMC_RCCL_LIB, if set: the host program's explicit choice;
+//   2. a librccl.so.1 that is ALREADY mapped (RTLD_NOLOAD): a host that carries an RCCL -- PyTorch does -- shares its copy, so the
+//      process keeps one RCCL and one librocm_smi64 underneath it;
+//   3. the librccl next to the libamdhip64 this library is bound to: same ROCm release as the runtime whose streams and buffers it gets;
+//   4. the loader's search path.
+// Always RTLD_LOCAL.  Round 4 opened /opt/rocm's copy RTLD_GLOBAL: its librocm_smi64.so.1 then sat in the global scope, the
+// librocm_smi64.so.7 of a PyTorch imported LATER bound its exported statics (amd::smi::Device::devInfoTypesStrings) to the first copy, and
+// both ran the destructor at exit -- "double free or corruption" (tests/test_rccl_loading.py replays that order in a child process).
 RcclApi *rccl() {
 	RcclApi &api = g_rccl;
 	static std::once_flag once;
 	std::call_once(once, [&api] {
-		std::vector<std::string> cand;
-		if (const char *e = std::getenv("MPMC_RCCL_LIB")) cand.push_back(e);
-		cand.insert(cand.end(), {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"});
-		for (const std::string &p : cand) {
-			api.handle = dlopen(p.c_str(), RTLD_NOW | RTLD_GLOBAL);
+		struct Cand {
+			std::string path;
+			int flags;
+			const char *how;
+		};
+		std::vector<Cand> cand;
+		if (const char *e = std::getenv("MPMC_RCCL_LIB"))
+			if (*e) cand.push_back({e, RTLD_NOW | RTLD_LOCAL, "MPMC_RCCL_LIB"});
+		for (const char *nm : {"librccl.so.1", "librccl.so"}) cand.push_back({nm, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD, "already mapped by the host program"});
+		const std::string hipdir = dir_of_bound_hip_runtime();
+		if (!hipdir.empty())
+			for (const char *nm : {"/librccl.so.1", "/librccl.so"}) cand.push_back({hipdir + nm, RTLD_NOW | RTLD_LOCAL, "next to the bound libamdhip64"});
+		for (const char *nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) cand.push_back({nm, RTLD_NOW | RTLD_LOCAL, "loader search path"});
+		for (const Cand &c : cand) {
+			api.handle = dlopen(c.path.c_str(), c.flags);
 			if (api.handle) {
-				api.path = p;
+				api.path = c.path;
+				api.how = c.how;
 				break;
 			}
-			api.error = dlerror();
+			if (!(c.flags & RTLD_NOLOAD)) api.error = dlerror();
 		}
 		if (!api.handle) return;
 #define MPMC_SYM(name)                                                             \
@@ -76,6 +105,9 @@ RcclApi *rccl() {
 		MPMC_SYM(GroupEnd)
 		MPMC_SYM(GetErrorString)
 #undef MPMC_SYM
+		Dl_info info; // the file the symbols really come from (a bare soname says nothing)
+		if (dladdr(reinterpret_cast<void *>(api.GetVersion), &info) && info.dli_fname) api.path = info.dli_fname;
+		api.described = api.path + " (" + api.how + ")";
 	});
 	return api.handle ? &api : nullptr;
 }
@@ -148,6 +180,11 @@ extern "C" int mpmc_rccl_version(int *version) {
 	RcclApi *api = rccl();
 	if (!api) return comm_fail(MPMC_ERR_COMM, "RCCL could not be loaded: " + rccl_error_text());
 	return api->GetVersion(version) == ncclSuccess ? MPMC_OK : comm_fail(MPMC_ERR_COMM, "ncclGetVersion failed");
+}
+
+extern "C" const char *mpmc_rccl_library_path(void) {
+	RcclApi *api = rccl();
+	return api ? api->described.c_str() : "";
 }
 
 extern "C" int mpmc_comm_unique_id(char id[MPMC_COMM_ID_BYTES]) {

@@ -20,6 +20,21 @@ extern "C" int mpmc_device_count(int *count) {
 	return (e == hipSuccess) ? MPMC_OK : MPMC_ERR_NO_DEVICE;
 }
 
+// (ABI 6) what a host program without its own HIP binding needs around the path: a fence over everything this process enqueued on a
+// device (the timing bracket of a benchmark, the reference's MPI_Barrier companion) and the device's marketing name for its log
+extern "C" int mpmc_device_synchronize(int device) {
+	if (hipSetDevice(device) != hipSuccess) return MPMC_ERR_NO_DEVICE;
+	return hipDeviceSynchronize() == hipSuccess ? MPMC_OK : MPMC_ERR_HIP;
+}
+extern "C" int mpmc_device_name(int device, char *name, int capacity) {
+	if (!name || capacity < 1) return MPMC_ERR_ARG;
+	name[0] = 0;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MPMC_ERR_NO_DEVICE;
+	std::snprintf(name, (size_t)capacity, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+	return MPMC_OK;
+}
+
 extern "C" const char *mpmc_last_error(const mpmc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 // PeriodicBoundary::update, reference src/PeriodicBoundary.cpp:31-101 (same association order)
@@ -934,6 +949,10 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 	else if (k == "polar_delta") t.no_polar_delta = !on;
 	else if (k == "inline_move") t.no_inline_move = !on;
 	else if (k == "trace_panel") t.trace_panel = on;
+	else if (k == "fail_next_wait") {
+		if (!c) return MPMC_ERR_ARG;
+		t.fail_next_wait = on ? 1 : 0;
+	}
 	else if (k == "panel_replicas") {
 		if (!c || v < 1 || v > 64) return MPMC_ERR_ARG;
 		c->debug_panel_replicas = v;

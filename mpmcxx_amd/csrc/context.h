@@ -56,6 +56,7 @@ struct mpmc_tuning {
 	bool no_order_carry = false; // "order_carry" = 0: every upload of the atom list sorts
 	bool no_polar_delta = false; // "polar_delta" = 0: trial moves of polarizable boxes run a full evaluation
 	bool no_inline_move = false; // "inline_move" = 0: trial moves always travel through the staging block
+	int fail_next_wait = 0;      // "fail_next_wait" = 1: the next wait of this context fails as if the runtime had refused it (test of the recovery path)
 	bool trace_panel = false;    // "trace_panel" = 1: per-workgroup time stamps of the panel kernel (tools/panel_trace.py)
 	long long tensor_budget_mb = 4096; // "tensor_budget_mb": AUTO solver: largest tensor store it will allocate
 };

@@ -686,7 +686,20 @@ extern "C" int mpmc_debug_time_pair(mpmc_ctx *c, int reps, double *ms_per_launch
 
 int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 	if (!c->pending) return fail(c, MPMC_ERR_ARG, "mpmc_energy_wait: nothing enqueued");
-	HIP_TRY(c, hipSetDevice(c->device));
+	// a wait that fails must not leave the context refusing every later enqueue ("still in flight"): whatever happens below, the
+	// evaluation is over for the host -- best-effort drain, state back to idle, scalar block marked dirty so that the next one clears it
+	auto abandon = [c](hipError_t e, const char *what) {
+		(void)hipStreamSynchronize(c->stream);
+		if (c->two_streams && c->stream2) (void)hipStreamSynchronize(c->stream2);
+		c->sync_stream = nullptr;
+		c->pending = false;
+		c->scal_clean = false;
+		c->static_ride_gen = 0;
+		return fail(c, MPMC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+	};
+	hipError_t werr = c->tune.fail_next_wait ? hipErrorUnknown : hipSetDevice(c->device);
+	c->tune.fail_next_wait = 0;
+	if (werr != hipSuccess) return abandon(werr, "mpmc_energy_wait: hipSetDevice");
 	bool seen = false;
 	if (c->last_was_single || c->spin_on_post) {
 		// the kernel posts its launch number behind the results (system-scope release): a short spin on the pinned slot returns a few
@@ -697,7 +710,8 @@ int mpmc::wait_and_fill(mpmc_ctx *c, mpmc_result *out) {
 	}
 	if (!seen) {
 		c->n_stream_syncs++;
-		HIP_TRY(c, hipStreamSynchronize(c->sync_stream ? c->sync_stream : c->stream));
+		werr = hipStreamSynchronize(c->sync_stream ? c->sync_stream : c->stream);
+		if (werr != hipSuccess) return abandon(werr, "mpmc_energy_wait: hipStreamSynchronize");
 	} else if (c->tune.poll_retire && c->n_tile_pairs > kOneStreamMaxPairs) {
 		// the results are in, but the runtime has not been told: a stream that is never synchronised keeps its finished commands, and
 		// the next asynchronous copy on it pays for the backlog (measured with positions handed over in host memory: 900 against 966

@@ -90,6 +90,9 @@ def lib():
     vp = C.c_void_p
     L.mpmc_abi_version.restype = C.c_int
     L.mpmc_device_count.argtypes = [C.POINTER(C.c_int)]
+    if hasattr(L, "mpmc_device_synchronize") or not os.environ.get("MPMC_ENERGY_LIB"):  # (ABI 6)
+        L.mpmc_device_synchronize.argtypes = [C.c_int]
+        L.mpmc_device_name.argtypes = [C.c_int, C.c_char_p, C.c_int]
     L.mpmc_last_error.argtypes = [vp]
     L.mpmc_last_error.restype = C.c_char_p
     L.mpmc_pbc_compute.argtypes = [dp, dp, dp, dp]
@@ -132,6 +135,9 @@ def lib():
     L.mpmc_gibbs_energy.argtypes = [vp, vp, C.POINTER(Result), C.POINTER(Result)]
     L.mpmc_gibbs_boltzmann_factor.argtypes = [C.POINTER(GibbsMove), dp, dp]
     L.mpmc_rccl_version.argtypes = [C.POINTER(C.c_int)]
+    if hasattr(L, "mpmc_rccl_library_path") or not os.environ.get("MPMC_ENERGY_LIB"):  # (ABI 6)
+        L.mpmc_rccl_library_path.argtypes = []
+        L.mpmc_rccl_library_path.restype = C.c_char_p
     L.mpmc_comm_unique_id.argtypes = [C.c_char_p]
     L.mpmc_comm_init_rank.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_int]
     L.mpmc_comm_init_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
@@ -178,6 +184,21 @@ def device_count() -> int:
     n = C.c_int(0)
     lib().mpmc_device_count(C.byref(n))
     return n.value
+
+
+def device_synchronize(device: int = 0):
+    """everything this process enqueued on `device` has finished (mpmc_device_synchronize)."""
+    rc = lib().mpmc_device_synchronize(int(device))
+    if rc != MPMC_OK:
+        raise MpmcError(rc, f"mpmc_device_synchronize({device})")
+
+
+def device_name(device: int = 0) -> str:
+    buf = C.create_string_buffer(256)
+    rc = lib().mpmc_device_name(int(device), buf, 256)
+    if rc != MPMC_OK:
+        raise MpmcError(rc, f"mpmc_device_name({device})")
+    return buf.value.decode()
 
 
 def pbc_compute(basis: np.ndarray):
@@ -556,6 +577,29 @@ def rccl_version() -> int:
     if rc != MPMC_OK:
         raise MpmcError(rc, (lib().mpmc_comm_last_error(None) or b"").decode())
     return v.value
+
+
+def rccl_library_path() -> str:
+    """the file RCCL's entry points were resolved from and why that copy (mpmc_rccl_library_path); "" if RCCL could not be opened."""
+    return (lib().mpmc_rccl_library_path() or b"").decode()
+
+
+def loaded_rocm_libs() -> Dict[str, list]:
+    """the ROCm runtime libraries mapped into THIS process (/proc/self/maps): {"libamdhip64": [paths], "librccl": [...], ...}.
+    One path per name = one ROCm in the process (what a rank of the multi-GPU job must show)."""
+    names = ("libamdhip64", "librccl", "libhsa-runtime64", "librocm_smi64", "libmpmc_energy", "libtorch_hip")
+    found: Dict[str, list] = {k: [] for k in names}
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                path = ln.split(None, 5)[-1].strip() if ln.count("/") else ""
+                base = os.path.basename(path)
+                for k in names:
+                    if base.startswith(k + ".so") and path not in found[k]:
+                        found[k].append(path)
+    except OSError:
+        pass
+    return {k: v for k, v in found.items() if v}
 
 
 class Comm:

@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(syms) >= 30
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, missing
-    assert L.mpmc_abi_version() == 5
+    assert L.mpmc_abi_version() == 6
 
 
 def test_code_object_is_gfx950():

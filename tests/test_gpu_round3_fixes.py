@@ -97,3 +97,20 @@ def test_every_switch_leaves_the_reference_numbers(key, value):
     util.assert_energies(S.observables, g, False, label=f"{key}={value}")
     assert util.max_rel(S.dipoles()[0].reshape(-1), g["mu"]) < util.REL_TOL
     S.close()
+
+
+def test_a_failed_wait_does_not_lock_the_context():
+    """round-4 advisor: an error inside mpmc_energy_wait left `pending` set and every later enqueue was refused ("still in flight")."""
+    atoms, basis, opts = util.load_fixture("ion216_polar")
+    S = energy.System(atoms, basis, opts)
+    e0 = S.energy()
+    S.configure("fail_next_wait", 1)  # the next wait fails as if the runtime had refused it
+    with pytest.raises(energy.MpmcError):
+        S.energy()
+    assert S.energy() == e0  # the context evaluates again, same bits
+    S.energy_async()
+    S.configure("fail_next_wait", 1)
+    with pytest.raises(energy.MpmcError):
+        S.energy_wait()
+    assert S.energy() == e0
+    S.close()
