@@ -210,7 +210,7 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	for (auto &e : c->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	void *ptrs[] = {c->d_atoms_blob, c->d_atom_part, c->d_tile_pairs, c->d_block_part, c->d_block_cnt, c->d_scal,
 	                c->d_flag, c->d_counter, c->d_kvec, c->d_kw, c->d_sf, c->d_w_en, c->d_e_recip_part, c->d_part, c->d_e_static, c->d_mu[0], c->d_mu[1],
-	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_tile_bounds, c->d_panels, c->d_seg, c->d_gpart, c->d_trace, c->d_mv_blob, c->d_moved_idx,
+	                c->d_e_induced, c->d_rrms, c->d_arows, c->d_adense, c->d_ab, c->d_cls, c->d_tp_shift, c->d_lvec, c->d_sf_part, c->d_tile_bounds, c->d_panels, c->d_seg, c->d_arrive, c->d_gpart, c->d_trace, c->d_mv_blob, c->d_moved_idx,
 	                c->d_sf_trial, c->d_delta_out, c->d_e_real, c->d_e_real_trial, c->d_dk_part, c->d_gs_ul, c->d_gs_blocks, c->d_erf_tab, c->d_sweep_blocks, c->d_generic_list};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -938,6 +938,11 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 		if (v < -1 || v > 1) return MPMC_ERR_ARG;
 		t.pair_split = v;
 	} else if (k == "panels") t.use_panels = on;
+	else if (k == "fused_update") {
+		if (v < 0 || v > 2) return MPMC_ERR_ARG;
+		t.fused_update = v;
+	}
+	else if (k == "panel_reverse") t.panel_reverse = on;
 	else if (k == "uniform_images") t.no_uniform = !on;
 	else if (k == "tile_classes") t.no_classes = !on;
 	else if (k == "single_launch") t.single_launch = on;

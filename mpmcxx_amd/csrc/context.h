@@ -47,6 +47,8 @@ struct mpmc_tuning {
 	bool dense_symmetric = true; // "dense_symmetric": the dense solver reads the upper block triangle of A only (0: rounds 1-3, the whole matrix)
 	bool fast_geometry = true; // "fast_geometry": fused minimum image in the pair sweep, the reference's form only inside a 1e-9 band around the cutoff (0: everywhere)
 	int pair_split = -1;    // "pair_split": two waves per tile pair in the fast sweep (half-length workgroups): -1 by default rule, 0 | 1
+	int fused_update = 0; // "fused_update" = 1 (2: measurement only, arrivals without the update -- results invalid): the dipole update rides the panel launch (last-arriving workgroup per tile); 0 (default): its own launch per iteration -- measured in round 5, profiles/r05_fused_update.txt
+	bool panel_reverse = true; // "panel_reverse": panel entries launched in descending j-tile order; 0: table order (rounds 2-4)
 	bool use_panels = true; // "panels": panel form of the Jacobi contraction (orthorhombic cells, stored tensors); 0: one tile pair per workgroup
 	bool no_uniform = false;   // "uniform_images" = 0: no tile-pair-wide periodic images
 	bool no_classes = false;   // "tile_classes" = 0: every tile pair is "near" (nothing skipped, every tensor stored)
@@ -105,7 +107,8 @@ struct mpmc_ctx {
 	double4 *d_tp_shift = nullptr;   // [n_tile_pairs] lattice vector components of the common image index (CLS_UNIFORM_X/Y/Z)
 	int4 *d_panels = nullptr;        // work table of the panel form of the Jacobi contraction (k_build_panels), rebuilt every evaluation
 	int *d_seg = nullptr;            // [n_tiles + 1] first entry of every j-tile's segment of that table
-	double *d_gpart = nullptr;       // [entries][64][3] j-side partial sums, one slot per entry of the table
+	double *d_gpart = nullptr;       // [entries][3][64] j-side partial sums, one slot per entry of the table
+	int *d_arrive = nullptr;         // [n_tiles] arrival counters of the fused dipole update (zero between launches)
 	size_t cap_panels = 0, cap_seg = 0;
 	long long *d_trace = nullptr;    // measurement only (tune.trace_panel): [entries][4] start / end ticks, HW_ID, XCC_ID of every workgroup of the LAST panel launch
 	int n_panel_entries = 0, seg_tiles = -1; // entries of the table / the tile count its layout was made for

@@ -373,8 +373,10 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				for (int J = 0; J < c->n_tiles; J++) seg[J + 1] = seg[J] + panel_segment_entries(J);
 				if ((size_t)c->n_tiles + 1 > c->cap_seg) {
 					dev_free(c, &c->d_seg, c->cap_seg);
+					dev_free(c, &c->d_arrive, c->cap_seg);
 					c->cap_seg = 0;
 					if ((rc = dev_alloc(c, &c->d_seg, (size_t)c->n_tiles + 1)) != MPMC_OK) return rc;
+					if ((rc = dev_alloc(c, &c->d_arrive, (size_t)c->n_tiles + 1)) != MPMC_OK) return rc;
 					c->cap_seg = (size_t)c->n_tiles + 1;
 				}
 				HIP_TRY(c, hipMemcpyAsync(c->d_seg, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice, st));
@@ -400,7 +402,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			panel_side = c->two_streams;
 			if (!panel_side) {
 				ProfScope pc(c, MPMC_K_CLASSES, st);
-				launch_build_panels(st, c->d_cls, c->n_tiles, c->d_seg, c->d_panels);
+				launch_build_panels(st, c->d_cls, c->n_tiles, c->d_seg, c->d_panels, c->d_arrive);
 			}
 			c->panels_built = true;
 		}
@@ -433,7 +435,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		}
 		if (panel_side) {
 			ProfScope pc(c, MPMC_K_CLASSES, s_side);
-			launch_build_panels(s_side, c->d_cls, c->n_tiles, c->d_seg, c->d_panels);
+			launch_build_panels(s_side, c->d_cls, c->n_tiles, c->d_seg, c->d_panels, c->d_arrive);
 		}
 	}
 	if ((side_work && side_fork) || panel_side) join_side(c);
@@ -495,6 +497,8 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 			ProfScope p(c, MPMC_K_TENSOR);
 			launch_gs_blocks(st, at, c->box, o.polar_damp, c->d_gs_blocks);
 		}
+		// compact solver on the panel path: the update of the dipoles is the tail of the contraction's own launch (kernels_panel.hip)
+		const bool fused_update = compact && c->panels_built && !dense && !o.polar_gs && c->tune.fused_update;
 		int it = 0;
 		bool keep = true;
 		while (keep) {
@@ -532,10 +536,14 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				else launch_dense_matvec(st, c->d_adense, c->n_pad, c->d_mu[c->mu_cur], kDenseChunks, c->d_part);
 			} else if (compact) {
 				ProfScope p(c, MPMC_K_DIPOLE_ITER);
-				if (c->panels_built) // every tile pair through the panel table: two per wave where classes allow
+				if (c->panels_built) { // every tile pair through the panel table: two per wave where classes allow; the update rides along
+					PanelFuse fu{};
+					fu.arrive = fused_update ? c->d_arrive : nullptr, fu.reverse = c->tune.panel_reverse ? 1 : 0;
+					fu.e_static = c->d_e_static, fu.seg = c->d_seg, fu.mu_new = c->d_mu[1 - c->mu_cur], fu.e_induced = c->d_e_induced, fu.rrms_atom = c->d_rrms;
+					fu.allowed_sqerr = allowed, fu.ctl = ctl, fu.host_flag = host_flag, fu.it = it, fu.want_rrms = want_rrms, fu.probe = c->tune.fused_update == 2;
 					launch_dipole_iter_panel(st, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels,
-					                         c->n_panel_entries, c->d_ab, c->d_part, c->d_gpart, converged, c->d_trace);
-				else
+					                         c->n_panel_entries, c->d_ab, c->d_part, c->d_gpart, converged, c->d_trace, 1, &fu);
+				} else
 					launch_dipole_iter_hybrid(st, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_cls,
 					                          (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, c->d_ab, c->d_part, o.polar_damp,
 					                          converged);
@@ -545,7 +553,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				                          (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->n_tile_pairs, nullptr, c->d_part, o.polar_damp,
 				                          converged);
 			}
-			{
+			if (!fused_update) {
 				ProfScope p(c, MPMC_K_REDUCE);
 				if (compact && c->panels_built && !dense)
 					launch_dipole_update_panel(st, at, c->d_e_static, c->d_part, c->d_gpart, c->d_seg, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur],
@@ -624,14 +632,19 @@ extern "C" int mpmc_debug_time_panel(mpmc_ctx *c, int reps, double *ms_per_launc
 	hipEvent_t e0, e1;
 	HIP_TRY(c, hipEventCreate(&e0));
 	HIP_TRY(c, hipEventCreate(&e1));
+	// the launch as the solve makes it: with the fused update (default) the new dipoles go to the buffer that is dead after the solve and the
+	// induced field is not stored, so the evaluation's results stay as they are
+	PanelFuse fu{};
+	fu.arrive = c->tune.fused_update ? c->d_arrive : nullptr, fu.reverse = c->tune.panel_reverse ? 1 : 0;
+	fu.e_static = c->d_e_static, fu.seg = c->d_seg, fu.mu_new = c->d_mu[1 - c->mu_cur], fu.e_induced = nullptr, fu.rrms_atom = c->d_rrms, fu.probe = c->tune.fused_update == 2;
 	for (int r = 0; r < 3; r++) // (warm)
 		launch_dipole_iter_panel(c->stream, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels, c->n_panel_entries,
-		                         c->d_ab, c->d_part, c->d_gpart, nullptr, nullptr);
+		                         c->d_ab, c->d_part, c->d_gpart, nullptr, nullptr, 1, &fu);
 	HIP_TRY(c, hipEventRecord(e0, c->stream));
-	const int replicas = c->debug_panel_replicas; // (> 1: every launch carries the grid that many times: what a batched launch would cost per system)
+	const int replicas = c->debug_panel_replicas; // (> 1: every launch carries the grid that many times, without the update: what a batched launch would cost per system)
 	for (int r = 0; r < reps; r++)
 		launch_dipole_iter_panel(c->stream, at, c->box, c->d_mu[c->mu_cur], c->d_tile_pairs, c->d_tp_shift, c->d_panels, c->n_panel_entries,
-		                         c->d_ab, c->d_part, c->d_gpart, nullptr, nullptr, replicas);
+		                         c->d_ab, c->d_part, c->d_gpart, nullptr, nullptr, replicas, &fu);
 	HIP_TRY(c, hipEventRecord(e1, c->stream));
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipEventSynchronize(e1));

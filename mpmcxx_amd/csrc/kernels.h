@@ -202,12 +202,26 @@ void launch_dipole_iter_hybrid(hipStream_t st, const AtomsDev &at, const Box &bx
 // ---- panel form of the contraction (kernels_panel.hip; any cell): two tile pairs that share their j-tile per workgroup ----
 int panel_segment_entries(int J); // entries the work table reserves for j-tile J; seg[J] = their running sum
 // the work table of the panel kernel: per j-tile its diagonal tile pair, panels of two tile pairs of equal class, odd singles
-void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg /*[n_tiles + 1]*/, int4 *panels);
-// i-side partial sums -> part[J][I atoms] (the usual slots, upper triangle + diagonal only); j-side -> gpart[entry][64][3]
+void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg /*[n_tiles + 1]*/, int4 *panels,
+                         int *arrive /*[n_tiles] arrival counters of the fused update, zeroed here; may be null*/);
+// the dipole update riding the contraction's launch: the workgroup that delivers the last contribution to a tile updates that tile
+struct PanelFuse {
+	int *arrive; // [n_tiles] arrival counters, zero between launches; null: no fused update (launch_dipole_update_panel follows)
+	int reverse; // entries in descending j-tile order (default); 0: table order (measurement)
+	const double *e_static;
+	const int *seg;
+	double *mu_new, *e_induced /*may be null*/, *rrms_atom;
+	double allowed_sqerr;
+	int *ctl, *host_flag;
+	int it, want_rrms;
+	int probe; // measurement only (fused_update = 2): arrive but skip the update
+};
+// i-side partial sums -> part[J][I atoms] (the usual slots, upper triangle + diagonal only; [3][64] inside a slot); j-side -> gpart[entry][3][64]
 void launch_dipole_iter_panel(hipStream_t st, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                               const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart,
                               const int *converged = nullptr, long long *trace = nullptr /*measurement only (trace_panel)*/,
-                              int replicas = 1 /*measurement only: the grid repeated in y (mpmc_debug_time_panel)*/);
+                              int replicas = 1 /*measurement only: the grid repeated in y (mpmc_debug_time_panel)*/,
+                              const PanelFuse *fuse = nullptr);
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,
                                 const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr,
                                 int *ctl, int *host_flag, int it);

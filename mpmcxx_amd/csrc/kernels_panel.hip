@@ -22,8 +22,19 @@
 // through the same walk with one member, in the same launch.  Skewed cells: "dimension" = lattice direction; the i-atom is pre-shifted by the
 // lattice vectors of the directions with a common index (a whole vector: B^T img mixes the Cartesian components), the others cost the row of R,
 // rint and the lattice vector per pair (TRI, instantiated per mask for the far-field walk).
-// Every partial slot part[source tile][atom] is still written exactly once per iteration: F_k -> part[J][I_k atoms], the combined
-// G -> part[I_0][J atoms], zeros -> part[I_k][J atoms], k > 0.
+// Partial sums: F_k -> part[J][I_k atoms] (i-side), the entry's combined G -> gpart[entry] (j-side), each written exactly once per
+// iteration.  Inside this path a slot holds its 64 x 3 doubles COMPONENT-major ([3][64]): every store instruction of the closing wave
+// writes four whole 128-byte lines (what a write-through store wants) and every load of the update is unit-stride.
+//
+// The update of the dipoles rides the same launch (round 5): the workgroup that delivers the LAST contribution to tile X -- the nt - X
+// i-side slots part[S][X], S >= X, and the slots of the entries of X's segment -- runs new_mu = alpha (E0 + F) for X's 64 atoms, sums
+// taken from the slots in the fixed (group, slot) order of k_dipole_update_panel, so the result does not depend on who arrives last.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): the closing wave stores its slots write-through (sc1), waits for its own
+// stores (s_waitcnt vmcnt(0)), then adds to the tiles' arrival counters (agent-scope atomics; the add whose return value completes the
+// count is the last one); the arriving workgroup takes ONE agent-scope acquire, waits for it, and passes a workgroup barrier before any
+// of its waves loads a slot (sc1 loads on top: L1 is not trusted).  The entries are launched in DESCENDING j-tile order: tile X is
+// complete when segment X is (its i-side pairs (X, S) live in the segments S > X), so the updates spread over the whole launch and the
+// longest segments start first; iteration k + 1 still starts at the kernel boundary.
 #include "kernels.h"
 #include "device_math.h"
 
@@ -45,10 +56,12 @@ __device__ __forceinline__ int tp_index(int I, int J, int nt) { return I * nt - 
 // is carried to the next chunk of 64 as that class's pending member.  At the end the pending members of equal kind (stored / far)
 // pair up across classes -- the panel then keeps only the dimensions uniform for BOTH -- and what is still single becomes a
 // one-member entry.  Every step is wave-uniform or a fixed function of the lane: the table is the same whatever the timing.
-__global__ __launch_bounds__(64) void k_build_panels(const int *__restrict__ cls, int nt, const int *__restrict__ seg, int4 *__restrict__ panels) {
+__global__ __launch_bounds__(64) void k_build_panels(const int *__restrict__ cls, int nt, const int *__restrict__ seg, int4 *__restrict__ panels,
+                                                     int *__restrict__ arrive /*[nt] arrival counters of the fused update: left at zero*/) {
 	__shared__ int s_odd[16][33]; // the odd-rank member of every pair of one chunk, by class and pair index
 	const int J = blockIdx.x, lane = threadIdx.x;
 	if (J >= nt) return;
+	if (arrive && lane == 0) arrive[J] = 0; // (an evaluation that failed half way may have left a count behind)
 	int4 *out = panels + seg[J];
 	const int cap = seg[J + 1] - seg[J];
 	int n = 0; // entries written so far (wave-uniform)
@@ -110,6 +123,18 @@ __global__ __launch_bounds__(64) void k_build_panels(const int *__restrict__ cls
 		}
 		for (; n < cap; ++n) out[n] = make_int4(-1, -1, 0, J);
 	}
+}
+
+// write-through store / L1-bypassing load (global_store / global_load ... sc1): the hand-off of the partial slots between workgroups
+template <bool SC1>
+__device__ __forceinline__ void st_slot(double *p, double v) {
+	if (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	else *p = v;
+}
+template <bool SC1>
+__device__ __forceinline__ double ld_slot(const double *p) {
+	if (SC1) return __hip_atomic_load(const_cast<double *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return *p;
 }
 
 template <int NI>
@@ -250,7 +275,7 @@ __device__ __forceinline__ void pan_walk(const Box &bx, const double2 *__restric
 	}
 }
 
-template <int PIPE, int NI, bool ORTHO>
+template <int PIPE, int NI, bool ORTHO, bool FUSED>
 __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, const double *__restrict__ mu, const int2 *__restrict__ tile_pairs,
                                             const double4 *__restrict__ tp_shift, const double2 *__restrict__ ab, double *__restrict__ part,
                                             double *__restrict__ gslot, const int tpA, const int tpB, const int flags, const int J,
@@ -401,105 +426,91 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 				g[d] = 0.0;
 			}
 		}
-		double *oi = part + (size_t)J * nt_pad3 + 3 * (size_t)(Is[k] * kTile + lane);
-		oi[p0] = f[0];
-		oi[p1] = f[1];
-		oi[p2] = f[2];
+		double *oi = part + (size_t)J * nt_pad3 + 3 * (size_t)(Is[k] * kTile) + lane; // slot [J][I_k atoms], component-major
+		st_slot<FUSED>(oi + p0 * kTile, f[0]);
+		st_slot<FUSED>(oi + p1 * kTile, f[1]);
+		st_slot<FUSED>(oi + p2 * kTile, f[2]);
 	}
-	gslot[3 * lane + p0] = g[0];
-	gslot[3 * lane + p1] = g[1];
-	gslot[3 * lane + p2] = g[2];
+	st_slot<FUSED>(gslot + p0 * kTile + lane, g[0]);
+	st_slot<FUSED>(gslot + p1 * kTile + lane, g[1]);
+	st_slot<FUSED>(gslot + p2 * kTile + lane, g[2]);
 }
 
-// (two instantiations: the orthorhombic one reads three diagonal elements of the cell and its inverse, which keeps most of the Box out of
-// its scalar registers; the other holds the walks of skewed cells)
-template <int PIPE, bool ORTHO>
-__global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev at, Box bx, const double *__restrict__ mu,
-                                                                        const int2 *__restrict__ tile_pairs, const double4 *__restrict__ tp_shift,
-                                                                        const int4 *__restrict__ panels, const double2 *__restrict__ ab,
-                                                                        double *__restrict__ part, double *__restrict__ gpart /*[entries][64][3]*/,
-                                                                        const int *__restrict__ converged /*null, or &ctl[1] of the precision-terminated solve*/,
-                                                                        long long *__restrict__ trace /*null; measurement only: [entries][4] = start, end (100 MHz ticks), HW_ID, XCC_ID*/) {
-	long long t_start = 0;
-	if (trace) t_start = wall_clock64();
-	__shared__ double2 s_xy[2 * kTile], s_zm[2 * kTile], s_mm[2 * kTile];
-	if (converged && *converged != 0) return; // an iteration enqueued ahead of the verdict: nothing to do
-	__shared__ double s_valid[2 * kTile];
-	__shared__ double s_F[kPanelWaves][2][3][kTile];
-	__shared__ double s_G[kPanelWaves][3][kTile];
-	const int4 e = panels[blockIdx.x];
-	// everything that describes the entry is wave-uniform: keep it in scalar registers
-	const int tpA = __builtin_amdgcn_readfirstlane(e.x), tpB = __builtin_amdgcn_readfirstlane(e.y);
-	const int flags = __builtin_amdgcn_readfirstlane(e.z), J = __builtin_amdgcn_readfirstlane(e.w);
-	double *gslot = gpart + (size_t)blockIdx.x * kTile * 3;
-	if (tpA < 0) { // unused entry of this j-tile's segment: its slot is read by the update kernel all the same
-		if (threadIdx.x < kTile) gslot[3 * threadIdx.x] = gslot[3 * threadIdx.x + 1] = gslot[3 * threadIdx.x + 2] = 0.0;
-		if (trace && threadIdx.x == 0) trace[4 * (size_t)blockIdx.x + 1] = 0; // no work: the reader drops entries whose end stamp is 0
-		return;
-	}
-	if (tpB >= 0) panel_block<PIPE, 2, ORTHO>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
-	else panel_block<PIPE, 1, ORTHO>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
-	if (trace && threadIdx.x == 0) { // (wave 0 is the last one to leave a workgroup: it folds the partial sums)
-		long long *o = trace + 4 * (size_t)blockIdx.x;
-		o[0] = t_start;
-		o[1] = wall_clock64();
-		o[2] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
-		o[3] = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (3 << 11));
-	}
-}
-
-// new_mu = alpha (E0 + F), F = sum of the panel kernel's slots of this tile X: part[S][X atoms] for S = X .. nt-1 (i-side, the diagonal
-// included) and gpart[e][.] for the entries of X's segment of the work table (j-side).  Same tail as k_dipole_update (contract_dipoles :3586-3593,
-// calc_dipole_rrms :3147-3177, are_we_done_yet :3227-3236).
+// ---- new_mu = alpha (E0 + F) for the 64 atoms of tile X ------------------------------------------------------------------------------
+// F = sum of the panel kernel's slots of this tile: part[S][X atoms] for S = X .. nt-1 (i-side, the diagonal included) and gpart[e] for
+// the entries of X's segment of the work table (j-side).  Tail as k_dipole_update (contract_dipoles :3586-3593, calc_dipole_rrms
+// :3147-3177, are_we_done_yet :3227-3236).  The sums are taken in kUpdGroups strided groups -- group g: slots g, g + 16, ... of the i-side,
+// then of the j-side -- and the groups added in order: fixed by (g, t) alone, whoever runs it and with however many waves (NW waves take
+// kUpdGroups / NW groups each, with independent accumulators: the loads of a wave are in flight together).
 constexpr int kUpdGroups = 16;
-__global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDev at, const double *__restrict__ e_static, const double *__restrict__ part,
-                                                                         const double *__restrict__ gpart, const int *__restrict__ seg, int nt,
-                                                                         const double *__restrict__ mu_old, double *__restrict__ mu_new,
-                                                                         double *__restrict__ e_induced, int want_rrms, double *__restrict__ rrms_atom,
-                                                                         double allowed_sqerr, int *__restrict__ ctl, int *__restrict__ host_flag, int it) {
-	__shared__ double sh[kUpdGroups][kTile][3];
-	if (ctl && ctl[1] != 0) return; // converged in an earlier iteration (block-uniform)
-	// (the group index as a SCALAR: the slot addresses below are then a wave-uniform base in scalar registers plus the lane's 32-bit offset,
-	// i.e. no vector arithmetic per slot -- with a per-lane 64-bit pointer the kernel spent 2/3 of its 272 instructions per wave on addresses,
-	// 1.8 % of all the instructions of an evaluation)
-	const int a = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int X = blockIdx.x, i = X * kTile + a;
-	const int nF = nt - X, wg0 = seg[X], nG = seg[X + 1] - wg0;
+struct PanelUpdate {
+	const double *e_static;
+	const int *seg;
+	double *mu_new, *e_induced /*may be null: not wanted (timing launches)*/, *rrms_atom;
+	double allowed_sqerr;
+	int *ctl, *host_flag;
+	int *arrive; // [nt] arrival counters; null: the update is a launch of its own (k_dipole_update_panel)
+	int nt, it, want_rrms, reverse;
+	int probe; // measurement only: arrive, but skip the update (the producer side of the hand-off alone; results are NOT valid)
+};
+
+template <int NW, bool SC1>
+__device__ __forceinline__ void panel_update_tile(const AtomsDev &at, const PanelUpdate &u, const double *__restrict__ part, const double *__restrict__ gpart,
+                                                  const double *__restrict__ mu_old, const int X, double (*__restrict__ sh)[kTile][3]) {
+	constexpr int GW = kUpdGroups / NW; // groups per wave
+	const int a = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int i = X * kTile + a;
+	const int nF = u.nt - X, wg0 = u.seg[X], nG = u.seg[X + 1] - wg0;
 	// what the closing wave needs behind the barrier is requested now (it would be a second latency chain there)
 	double al = 0.0, es[3] = {0, 0, 0}, mo[3] = {0, 0, 0};
-	if (g == 0) {
+	if (w == 0) {
 		al = at.alpha[i];
 		for (int p = 0; p < 3; ++p) {
-			es[p] = e_static[3 * (size_t)i + p];
+			es[p] = u.e_static[3 * (size_t)i + p];
 			mo[p] = mu_old[3 * (size_t)i + p];
 		}
 	}
-	// two plain strided walks (i-side slots, then j-side slots) so that the loads of an unrolled group are independent and in flight
-	// together: the kernel is a latency chain otherwise (fewer workgroups than CUs).  The order of the sums is fixed by (g, t) alone.
-	// (Round 4 tried batches of eight predicated loads per group: more loads in flight, but the padding loads cost more than the latency
-	// they hide -- 8.5 against 7.4 us in rocprofv3's trace -- and was taken back.)
-	double f[3] = {0, 0, 0};
-	const unsigned lane3 = 3u * (unsigned)a;
+	// One list of T = nF + nG slots (i-side first); group g takes t = g, g + 16, ...  Every load is issued unconditionally (a slot index
+	// past the end is clamped and its value replaced by zero: no branch between the loads), two rounds of the wave's groups per trip: 24
+	// independent loads in flight per lane -- the update is a latency chain (few workgroups, data fresh from other CUs), not a bandwidth one.
+	double f[GW][3] = {};
 	const size_t n_pad = (size_t)at.n_pad;
-#pragma unroll 4
-	for (int t = g; t < nF; t += kUpdGroups) {
-		const double *__restrict__ q = part + ((size_t)(X + t) * n_pad + (size_t)X * kTile) * 3; // slot X + t, this tile's atoms: wave-uniform
-		f[0] += q[lane3];
-		f[1] += q[lane3 + 1];
-		f[2] += q[lane3 + 2];
+	const int T = nF + nG;
+	const double *__restrict__ pX = part + ((size_t)X * n_pad + (size_t)X * kTile) * 3 + a; // slot X, this tile's block; slot X + t is t * n_pad * 3 further
+	const double *__restrict__ gX = gpart + (size_t)wg0 * (kTile * 3) + a;
+	constexpr int ROUNDS = 2;
+	for (int t0 = 0; t0 < T; t0 += ROUNDS * kUpdGroups) {
+		double v[ROUNDS][GW][3];
+#pragma unroll
+		for (int r = 0; r < ROUNDS; ++r) {
+#pragma unroll
+			for (int c = 0; c < GW; ++c) {
+				const int t = t0 + r * kUpdGroups + w * GW + c;
+				const int tc = t < T ? t : T - 1;
+				const double *__restrict__ q = tc < nF ? pX + (size_t)tc * n_pad * 3 : gX + (size_t)(tc - nF) * (kTile * 3);
+				v[r][c][0] = ld_slot<SC1>(q);
+				v[r][c][1] = ld_slot<SC1>(q + kTile);
+				v[r][c][2] = ld_slot<SC1>(q + 2 * kTile);
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < ROUNDS; ++r) {
+#pragma unroll
+			for (int c = 0; c < GW; ++c) {
+				const bool ok = t0 + r * kUpdGroups + w * GW + c < T;
+#pragma unroll
+				for (int p = 0; p < 3; ++p) f[c][p] += ok ? v[r][c][p] : 0.0;
+			}
+		}
 	}
-#pragma unroll 4
-	for (int t = g; t < nG; t += kUpdGroups) {
-		const double *__restrict__ q = gpart + (size_t)(wg0 + t) * (kTile * 3);
-		f[0] += q[lane3];
-		f[1] += q[lane3 + 1];
-		f[2] += q[lane3 + 2];
+#pragma unroll
+	for (int c = 0; c < GW; ++c) {
+		sh[w * GW + c][a][0] = f[c][0];
+		sh[w * GW + c][a][1] = f[c][1];
+		sh[w * GW + c][a][2] = f[c][2];
 	}
-	sh[g][a][0] = f[0];
-	sh[g][a][1] = f[1];
-	sh[g][a][2] = f[2];
 	__syncthreads();
-	if (g != 0) return;
+	if (w != 0) return;
 	double fsum[3];
 	for (int p = 0; p < 3; ++p) {
 		double v = sh[0][a][p];
@@ -520,52 +531,160 @@ __global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDe
 		const double d = nm[p] - mo[p];
 		acc += d * d;
 		nn += nm[p] * nm[p];
-		if (d * d > allowed_sqerr) broke = true;
-		mu_new[3 * (size_t)i + p] = nm[p];
-		e_induced[3 * (size_t)i + p] = fo[p];
+		if (d * d > u.allowed_sqerr) broke = true;
+		u.mu_new[3 * (size_t)i + p] = nm[p];
+		if (u.e_induced) u.e_induced[3 * (size_t)i + p] = fo[p];
 	}
-	if (want_rrms) {
+	if (u.want_rrms) {
 		double r = sqrt(acc / nn);
 		if (!isfinite(r)) r = 0.0;
-		rrms_atom[i] = (i < at.n) ? r : 0.0;
+		u.rrms_atom[i] = (i < at.n) ? r : 0.0;
 	}
-	if (ctl) { // are_we_done_yet on the device (iteration_verdict in kernels.hip; repeated here: separate translation unit)
-		const bool wave_broke = __any(allowed_sqerr > 0.0 && broke && i < at.n);
+	if (u.ctl) { // are_we_done_yet on the device (iteration_verdict in kernels.hip; repeated here: separate translation unit)
+		int *ctl = u.ctl;
+		const bool wave_broke = __any(u.allowed_sqerr > 0.0 && broke && i < at.n);
 		if (a != 0) return;
 		if (wave_broke) atomicOr(&ctl[0], 1);
 		__threadfence();
 		const int ticket = atomicAdd(&ctl[2], 1);
-		if (ticket != (int)gridDim.x - 1) return;
+		if (ticket != u.nt - 1) return;
 		__threadfence();
 		const int any_broke = atomicOr(&ctl[0], 0);
-		if (!any_broke) ctl[1] = it;
+		if (!any_broke) ctl[1] = u.it;
 		ctl[0] = 0;
 		ctl[2] = 0;
-		if (host_flag) { // pinned { last closed iteration, converged-at }: the host spins on it instead of synchronising the stream
-			__hip_atomic_store(host_flag + 1, any_broke ? 0 : it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			__hip_atomic_store(host_flag, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		if (u.host_flag) { // pinned { last closed iteration, converged-at }: the host spins on it instead of synchronising the stream
+			__hip_atomic_store(u.host_flag + 1, any_broke ? 0 : u.it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(u.host_flag, u.it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 	}
 }
 
-void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg, int4 *panels) {
-	hipLaunchKernelGGL(k_build_panels, dim3(n_tiles), dim3(64), 0, st, cls, n_tiles, seg, panels);
+// (per FUSED two instantiations: the orthorhombic one reads three diagonal elements of the cell and its inverse, which keeps most of the
+// Box out of its scalar registers; the other holds the walks of skewed cells)
+constexpr int kPanelLdsDouble2 = 6 * kTile + kTile + (kPanelWaves * 2 * 3 * kTile + kPanelWaves * 3 * kTile) / 2; // j-tile image (every value twice), valid flags, s_F, s_G
+static_assert(kPanelLdsDouble2 * 2 >= kUpdGroups * kTile * 3, "the update's group sums reuse the walk's LDS");
+template <int PIPE, bool ORTHO, bool FUSED>
+__global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev at, Box bx, const double *__restrict__ mu,
+                                                                        const int2 *__restrict__ tile_pairs, const double4 *__restrict__ tp_shift,
+                                                                        const int4 *__restrict__ panels, const double2 *__restrict__ ab,
+                                                                        double *__restrict__ part, double *__restrict__ gpart /*[entries][3][64]*/,
+                                                                        const int *__restrict__ converged /*null, or &ctl[1] of the precision-terminated solve*/,
+                                                                        long long *__restrict__ trace /*null; measurement only: [entries][4] = start, end (100 MHz ticks), HW_ID, XCC_ID*/,
+                                                                        const PanelUpdate u) {
+	long long t_start = 0;
+	if (trace) t_start = wall_clock64();
+	__shared__ double2 s_all[kPanelLdsDouble2];
+	__shared__ int s_todo[4];
+	if (converged && *converged != 0) return; // an iteration enqueued ahead of the verdict: nothing to do
+	double2 *s_xy = s_all, *s_zm = s_all + 2 * kTile, *s_mm = s_all + 4 * kTile;
+	double *s_valid = reinterpret_cast<double *>(s_all + 6 * kTile);
+	double(*s_F)[2][3][kTile] = reinterpret_cast<double(*)[2][3][kTile]>(s_all + 7 * kTile);
+	double(*s_G)[3][kTile] = reinterpret_cast<double(*)[3][kTile]>(s_all + 7 * kTile + kPanelWaves * 2 * 3 * kTile / 2);
+	// entries in descending j-tile order (the table is ascending): the longest segments first, tile X complete when segment X is
+	const int ent = u.reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+	const int4 e = panels[ent];
+	// everything that describes the entry is wave-uniform: keep it in scalar registers
+	const int tpA = __builtin_amdgcn_readfirstlane(e.x), tpB = __builtin_amdgcn_readfirstlane(e.y);
+	const int flags = __builtin_amdgcn_readfirstlane(e.z), J = __builtin_amdgcn_readfirstlane(e.w);
+	double *gslot = gpart + (size_t)ent * kTile * 3;
+	if (tpA < 0) { // unused entry of this j-tile's segment: its slot is read by the update all the same
+		if (threadIdx.x < kTile) {
+			st_slot<FUSED>(gslot + threadIdx.x, 0.0);
+			st_slot<FUSED>(gslot + kTile + threadIdx.x, 0.0);
+			st_slot<FUSED>(gslot + 2 * kTile + threadIdx.x, 0.0);
+		}
+		if (trace && threadIdx.x == 0) trace[4 * (size_t)ent + 1] = 0; // no work: the reader drops entries whose end stamp is 0
+		if (!FUSED) return;
+	} else if (tpB >= 0) panel_block<PIPE, 2, ORTHO, FUSED>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
+	else panel_block<PIPE, 1, ORTHO, FUSED>(at, bx, mu, tile_pairs, tp_shift, ab, part, gslot, tpA, tpB, flags, J, s_xy, s_zm, s_mm, s_valid, s_F, s_G);
+	if (FUSED) {
+		// arrival: wave 0 stored every slot of this entry; its lanes 0..2 add to the counters of the tiles those slots belong to
+		//   diagonal or unused entry: { J };  off-diagonal: { I_A, I_B (panels of two), J }
+		const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+		if (w == 0) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores have been acknowledged
+			int target = -1;
+			const bool offdiag = tpA >= 0 && !(flags & kPanDiag);
+			if (lane == 0) target = J;
+			else if (lane == 1 && offdiag) target = tile_pairs[tpA].x;
+			else if (lane == 2 && offdiag && tpB >= 0) target = tile_pairs[tpB].x;
+			bool last = false;
+			if (target >= 0) {
+				const int expected = (u.nt - target) + (u.seg[target + 1] - u.seg[target] - 1);
+				last = __hip_atomic_fetch_add(&u.arrive[target], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1;
+			}
+			if (lane < 3) s_todo[lane] = last ? target : -1;
+			if (__any(last)) { // ONE agent-scope acquire per arriving workgroup, complete before the barrier lets anybody load
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			}
+		}
+		__syncthreads();
+		double(*sh)[kTile][3] = reinterpret_cast<double(*)[kTile][3]>(s_all);
+#pragma unroll 1
+		for (int k = 0; k < 3; ++k) {
+			const int X = __builtin_amdgcn_readfirstlane(s_todo[k]);
+			if (X < 0) continue; // (block-uniform)
+			if (!u.probe) panel_update_tile<kPanelWaves, true>(at, u, part, gpart, mu, X, sh);
+			if (threadIdx.x == 0) u.arrive[X] = 0; // (nobody else touches it any more in this launch; the next one starts from zero)
+			__syncthreads();
+		}
+	}
+	if (trace && threadIdx.x == 0 && tpA >= 0) { // (wave 0 is the last one to leave a workgroup: it folds the partial sums)
+		long long *o = trace + 4 * (size_t)ent;
+		o[0] = t_start;
+		o[1] = wall_clock64();
+		o[2] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+		o[3] = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (3 << 11));
+	}
+}
+
+// the update as a launch of its own (measurement switch fused_update = 0, and the timing launches of mpmc_debug_time_panel's replicas):
+// one workgroup of sixteen waves per tile, the same function, the same sums
+__global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDev at, const double *__restrict__ part, const double *__restrict__ gpart,
+                                                                         const double *__restrict__ mu_old, const PanelUpdate u) {
+	__shared__ double sh[kUpdGroups][kTile][3];
+	if (u.ctl && u.ctl[1] != 0) return; // converged in an earlier iteration (block-uniform)
+	panel_update_tile<kUpdGroups, false>(at, u, part, gpart, mu_old, blockIdx.x, sh);
+}
+
+void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg, int4 *panels, int *arrive) {
+	hipLaunchKernelGGL(k_build_panels, dim3(n_tiles), dim3(64), 0, st, cls, n_tiles, seg, panels, arrive);
 }
 
 void launch_dipole_iter_panel(hipStream_t st, const AtomsDev &at, const Box &bx, const double *mu, const int2 *tile_pairs,
                               const double4 *tp_shift, const int4 *panels, int n_entries, const double2 *ab, double *part, double *gpart,
-                              const int *converged, long long *trace, int replicas) {
+                              const int *converged, long long *trace, int replicas, const PanelFuse *fuse) {
 	if (n_entries <= 0) return;
 	dim3 grid(n_entries, replicas > 1 ? replicas : 1), block(kTile * kPanelWaves); // (replicas: measurement only -- the same work blockIdx.y times)
-	if (bx.ortho) hipLaunchKernelGGL((k_dipole_iter_panel<4, true>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace);
-	else hipLaunchKernelGGL((k_dipole_iter_panel<4, false>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace);
+	PanelUpdate u{};
+	u.reverse = 1;
+	const bool fused = fuse && fuse->arrive && replicas <= 1;
+	if (fuse) u.reverse = fuse->reverse;
+	if (fused) {
+		u.e_static = fuse->e_static, u.seg = fuse->seg, u.mu_new = fuse->mu_new, u.e_induced = fuse->e_induced, u.rrms_atom = fuse->rrms_atom;
+		u.allowed_sqerr = fuse->allowed_sqerr, u.ctl = fuse->ctl, u.host_flag = fuse->host_flag, u.arrive = fuse->arrive;
+		u.nt = at.n_pad / kTile, u.it = fuse->it, u.want_rrms = fuse->want_rrms, u.probe = fuse->probe;
+	}
+#define MPMC_PANEL(O, F) hipLaunchKernelGGL((k_dipole_iter_panel<4, O, F>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace, u)
+	if (bx.ortho) {
+		if (fused) MPMC_PANEL(true, true);
+		else MPMC_PANEL(true, false);
+	} else {
+		if (fused) MPMC_PANEL(false, true);
+		else MPMC_PANEL(false, false);
+	}
+#undef MPMC_PANEL
 }
 
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,
                                 const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr,
                                 int *ctl, int *host_flag, int it) {
-	hipLaunchKernelGGL(k_dipole_update_panel, dim3(at.n_pad / kTile), dim3(kTile * kUpdGroups), 0, st, at, e_static, part, gpart, seg, at.n_pad / kTile,
-	                   mu_old, mu_new, e_induced, want_rrms, rrms_atom, allowed_sqerr, ctl, host_flag, it);
+	PanelUpdate u{};
+	u.e_static = e_static, u.seg = seg, u.mu_new = mu_new, u.e_induced = e_induced, u.rrms_atom = rrms_atom, u.allowed_sqerr = allowed_sqerr;
+	u.ctl = ctl, u.host_flag = host_flag, u.arrive = nullptr, u.nt = at.n_pad / kTile, u.it = it, u.want_rrms = want_rrms;
+	hipLaunchKernelGGL(k_dipole_update_panel, dim3(at.n_pad / kTile), dim3(kTile * kUpdGroups), 0, st, at, part, gpart, mu_old, u);
 }
 
 } // namespace mpmc

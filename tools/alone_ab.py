@@ -18,10 +18,17 @@ for name, reps in (("ion10k_es", 300), ("ion10k_polar", 60)):
     systems = {}
     for spec in specs:
         label, _, envs = spec.partition(":")
+        kvs = [kv.partition("=") for kv in filter(None, envs.split(","))]
+        at_create = {}  # switches that are read when the context (its side stream) is made: process-wide default around the constructor
+        for k, _, v in kvs:
+            if k in at_create:
+                energy.configure(k, float(v))
         S = energy.System(atoms, basis, opts)
-        for kv in filter(None, envs.split(",")):
-            k, _, v = kv.partition("=")
-            S.configure(k, float(v))
+        for k, dflt in at_create.items():
+            energy.configure(k, dflt)
+        for k, _, v in kvs:
+            if k not in at_create:
+                S.configure(k, float(v))
         S.energy()
         S.energy()
         systems[label] = S
