@@ -409,6 +409,11 @@ def main():
         a = dict(atoms)
         a["pos"] = bead_positions(atoms["pos"], b)
         beads.append(energy.System(a, basis, opts, device=devices[k % n_dev]))
+    if inprocess and args.force_device is not None:
+        # rehearsal on one GPU: bead k counts as living on "device" k mod N (the library's test hook "virtual_device"), so that the step below
+        # runs the real thread-per-device path -- worker threads, hand-off, ordered combine -- with a host copy in RCCL's place
+        for k, s in enumerate(beads):
+            s.configure("virtual_device", k % n_dev)
     host_pos = [np.ascontiguousarray(bead_positions(atoms["pos"], b)) for b in mine]
     state = {"host_positions": bool(args.host_positions), "per": None}
 

@@ -135,6 +135,7 @@ struct mpmc_comm {
 	int rank0 = 0;    // communicator rank of members[0]; members[g] is rank0 + g
 	std::vector<CommMember> members;
 	std::string err;
+	bool host_only = false; // members are "virtual devices" of one GPU (test hook, see group_beads): the gather is a host copy, no RCCL underneath
 };
 
 #define RCCL_TRY(cm, api, call)                                                                      \
@@ -159,15 +160,15 @@ static int member_reserve(mpmc_comm *cm, CommMember &m, size_t per_rank) {
 	HIPC_TRY(cm, hipSetDevice(m.device));
 	if (m.d_send) (void)hipFree(m.d_send);
 	if (m.d_recv) (void)hipFree(m.d_recv);
-	if (m.h_send) (void)hipHostFree(m.h_send);
-	if (m.h_recv) (void)hipHostFree(m.h_recv);
+	if (m.h_send) (void)pinned_free(m.h_send);
+	if (m.h_recv) (void)pinned_free(m.h_recv);
 	m.d_send = m.d_recv = m.h_send = m.h_recv = nullptr;
 	m.cap = 0;
 	const size_t cap = std::max<size_t>(per_rank, 64);
 	HIPC_TRY(cm, hipMalloc((void **)&m.d_send, cap * sizeof(double)));
 	HIPC_TRY(cm, hipMalloc((void **)&m.d_recv, cap * (size_t)cm->n_ranks * sizeof(double)));
-	HIPC_TRY(cm, hipHostMalloc((void **)&m.h_send, cap * sizeof(double)));
-	HIPC_TRY(cm, hipHostMalloc((void **)&m.h_recv, cap * (size_t)cm->n_ranks * sizeof(double)));
+	HIPC_TRY(cm, pinned_alloc(&m.h_send, cap * sizeof(double)));
+	HIPC_TRY(cm, pinned_alloc(&m.h_recv, cap * (size_t)cm->n_ranks * sizeof(double)));
 	m.cap = cap;
 	return MPMC_OK;
 }
@@ -283,8 +284,8 @@ extern "C" int mpmc_comm_destroy(mpmc_comm *cm) {
 		if (m.comm && api) (void)api->CommDestroy(m.comm);
 		if (m.d_send) (void)hipFree(m.d_send);
 		if (m.d_recv) (void)hipFree(m.d_recv);
-		if (m.h_send) (void)hipHostFree(m.h_send);
-		if (m.h_recv) (void)hipHostFree(m.h_recv);
+		if (m.h_send) (void)pinned_free(m.h_send);
+		if (m.h_recv) (void)pinned_free(m.h_recv);
 		if (m.stream) (void)hipStreamDestroy(m.stream);
 	}
 	delete cm;
@@ -302,9 +303,15 @@ extern "C" int mpmc_comm_info(const mpmc_comm *cm, int *n_ranks, int *rank, int 
 // every member contributes `count` doubles (local[g] for member g); all[g] receives n_ranks x count doubles in rank order.
 // One ncclAllGather per member inside a group (RCCL's rule for several devices in one thread).
 static int allgather_members(mpmc_comm *cm, const std::vector<const double *> &local, size_t count, const std::vector<double *> &all) {
+	const int G = (int)cm->members.size();
+	if (cm->host_only) { // every member's block to every member that asked, in member order (what ncclAllGather delivers)
+		for (int g = 0; g < G; g++)
+			if (all[g])
+				for (int h = 0; h < G; h++) std::memcpy(all[g] + (size_t)h * count, local[h], count * sizeof(double));
+		return MPMC_OK;
+	}
 	RcclApi *api = rccl();
 	if (!api) return comm_fail(MPMC_ERR_COMM, "RCCL could not be loaded");
-	const int G = (int)cm->members.size();
 	for (int g = 0; g < G; g++) {
 		CommMember &m = cm->members[g];
 		int rc = member_reserve(cm, m, count);
@@ -415,7 +422,11 @@ static void destroy_auto_comms() {
 	g_auto_groups.clear();
 }
 
-// devices of the beads in order of first appearance (rank g of the communicator = g-th device) and every bead's place
+// devices of the beads in order of first appearance (rank g of the communicator = g-th device) and every bead's place.
+// Test hook: a context configured with "virtual_device" = v >= 0 counts as living on device -(1 + v): a one-GPU box then drives the
+// thread-per-device path for real (worker hand-off, per-thread evaluation, ordered combine) -- tools/host_tsan.sh, tests/test_gpu_comm.py --
+// with a host copy in RCCL's place (RCCL admits one rank per physical device).
+static int device_key(const mpmc_ctx *c) { return c->tune.virtual_device >= 0 ? -(1 + c->tune.virtual_device) : c->device; }
 static void group_beads(mpmc_ctx **beads, int n_beads, std::vector<int> &devs, std::vector<int> &dev_of, std::vector<int> &slot_of,
                         std::vector<std::vector<int>> &members) {
 	dev_of.assign(n_beads, 0);
@@ -423,9 +434,9 @@ static void group_beads(mpmc_ctx **beads, int n_beads, std::vector<int> &devs, s
 	for (int b = 0; b < n_beads; b++) {
 		int g = 0;
 		for (; g < (int)devs.size(); g++)
-			if (devs[g] == beads[b]->device) break;
+			if (devs[g] == device_key(beads[b])) break;
 		if (g == (int)devs.size()) {
-			devs.push_back(beads[b]->device);
+			devs.push_back(device_key(beads[b]));
 			members.emplace_back();
 		}
 		dev_of[b] = g;
@@ -465,8 +476,17 @@ extern "C" int mpmc_pi_allreduce(mpmc_ctx **beads, int n_beads, double sums4[4],
 		auto it = g_auto_groups.find(devs);
 		if (it == g_auto_groups.end()) {
 			mpmc_comm *cm = nullptr;
-			int rc = mpmc_comm_init_all(&cm, G, devs.data());
-			if (rc != MPMC_OK) return fail(beads[0], rc, "mpmc_pi_allreduce: " + g_comm_error);
+			bool any_virtual = false;
+			for (int d : devs) any_virtual |= d < 0;
+			if (any_virtual) { // (test hook: virtual devices of one GPU, no RCCL)
+				cm = new mpmc_comm();
+				cm->n_ranks = G, cm->rank0 = 0, cm->host_only = true;
+				cm->members.resize(G);
+				for (int g = 0; g < G; g++) cm->members[g].device = beads[members[g][0]]->device;
+			} else {
+				int rc = mpmc_comm_init_all(&cm, G, devs.data());
+				if (rc != MPMC_OK) return fail(beads[0], rc, "mpmc_pi_allreduce: " + g_comm_error);
+			}
 			if (g_auto_groups.empty()) std::atexit(destroy_auto_comms);
 			std::unique_ptr<AutoGroup> ng(new AutoGroup);
 			ng->cm = cm;

@@ -182,12 +182,12 @@ extern "C" int mpmc_ctx_create(int device, int max_atoms, mpmc_ctx **out) {
 			rc = MPMC_ERR_HIP;
 	}
 	static_assert(sizeof(long long) == sizeof(double), "scalars and counts share one buffer");
-	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_scal, (S_COUNT + C_COUNT + 1) * sizeof(double)) != hipSuccess) rc = MPMC_ERR_HIP;
+	if (rc == MPMC_OK && pinned_alloc(&c->h_scal, (S_COUNT + C_COUNT + 1) * sizeof(double)) != hipSuccess) rc = MPMC_ERR_HIP;
 	if (rc == MPMC_OK) {
 		c->h_cnt = reinterpret_cast<long long *>(c->h_scal + S_COUNT);
 		std::memset(c->h_scal, 0, (S_COUNT + C_COUNT + 1) * sizeof(double)); // (the launch-number slot the waits poll starts at 0: a recycled pinned block may hold an old context's 1.0)
 	}
-	if (rc == MPMC_OK && hipHostMalloc((void **)&c->h_flag, 4 * sizeof(int)) != hipSuccess) rc = MPMC_ERR_HIP;
+	if (rc == MPMC_OK && pinned_alloc(&c->h_flag, 4 * sizeof(int)) != hipSuccess) rc = MPMC_ERR_HIP;
 	if (rc == MPMC_OK) rc = rot_selftest(c);
 	if (rc != MPMC_OK) {
 		g_create_error = "mpmc_ctx_create: device allocation failed: " + c->err;
@@ -214,17 +214,17 @@ extern "C" int mpmc_ctx_destroy(mpmc_ctx *c) {
 	                c->d_sf_trial, c->d_delta_out, c->d_e_real, c->d_e_real_trial, c->d_dk_part, c->d_gs_ul, c->d_gs_blocks, c->d_erf_tab, c->d_sweep_blocks, c->d_generic_list};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
-	if (c->h_stage) (void)hipHostFree(c->h_stage);
-	if (c->h_xyzq) (void)hipHostFree(c->h_xyzq);
+	if (c->h_stage) (void)pinned_free(c->h_stage);
+	if (c->h_xyzq) (void)pinned_free(c->h_xyzq);
 	if (c->ev_xyzq) (void)hipEventDestroy(c->ev_xyzq);
-	if (c->h_kstage) (void)hipHostFree(c->h_kstage);
+	if (c->h_kstage) (void)pinned_free(c->h_kstage);
 	if (c->ev_kstage) (void)hipEventDestroy(c->ev_kstage);
-	if (c->static_cnt) (void)hipHostFree(c->static_cnt);
+	if (c->static_cnt) (void)pinned_free(c->static_cnt);
 	if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
-	if (c->h_scal) (void)hipHostFree(c->h_scal);
-	if (c->h_flag) (void)hipHostFree(c->h_flag);
-	if (c->h_delta_out) (void)hipHostFree(c->h_delta_out);
-	if (c->h_mv_blob) (void)hipHostFree(c->h_mv_blob);
+	if (c->h_scal) (void)pinned_free(c->h_scal);
+	if (c->h_flag) (void)pinned_free(c->h_flag);
+	if (c->h_delta_out) (void)pinned_free(c->h_delta_out);
+	if (c->h_mv_blob) (void)pinned_free(c->h_mv_blob);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return MPMC_OK;
@@ -458,11 +458,11 @@ int mpmc::upload_atoms(mpmc_ctx *c) {
 	// (uVT, Gibbs) pays for a sort and eight enqueues here, nothing else.
 	const size_t P = (size_t)c->max_pad;
 	if (!c->h_stage) {
-		HIP_TRY(c, hipHostMalloc((void **)&c->h_stage, P * kAtomRecordBytes));
-		HIP_TRY(c, hipHostMalloc((void **)&c->h_xyzq, P * sizeof(double4)));
+		HIP_TRY(c, pinned_alloc(&c->h_stage, P * kAtomRecordBytes));
+		HIP_TRY(c, pinned_alloc(&c->h_xyzq, P * sizeof(double4)));
 		HIP_TRY(c, hipEventCreateWithFlags(&c->ev_xyzq, hipEventDisableTiming));
 		HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
-		HIP_TRY(c, hipHostMalloc((void **)&c->static_cnt, 4 * sizeof(long long)));
+		HIP_TRY(c, pinned_alloc(&c->static_cnt, 4 * sizeof(long long)));
 		for (int k = 0; k < 4; k++) c->static_cnt[k] = 0;
 	}
 	if (c->stage_in_flight) { // (an upload per evaluation at most, and evaluations are waited for: normally long done)
@@ -943,6 +943,10 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 		t.fused_update = v;
 	}
 	else if (k == "panel_reverse") t.panel_reverse = on;
+	else if (k == "sweep_lds_pad") {
+		if (v < 0 || v > 65536) return MPMC_ERR_ARG;
+		t.sweep_lds_pad = v;
+	}
 	else if (k == "uniform_images") t.no_uniform = !on;
 	else if (k == "tile_classes") t.no_classes = !on;
 	else if (k == "single_launch") t.single_launch = on;
@@ -954,7 +958,10 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 	else if (k == "polar_delta") t.no_polar_delta = !on;
 	else if (k == "inline_move") t.no_inline_move = !on;
 	else if (k == "trace_panel") t.trace_panel = on;
-	else if (k == "fail_next_wait") {
+	else if (k == "virtual_device") {
+		if (!c || v < -1 || v > 63) return MPMC_ERR_ARG;
+		t.virtual_device = v;
+	} else if (k == "fail_next_wait") {
 		if (!c) return MPMC_ERR_ARG;
 		t.fail_next_wait = on ? 1 : 0;
 	}

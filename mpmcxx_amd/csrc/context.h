@@ -32,6 +32,29 @@ struct EvPair {
 
 // Measurement / A-B switches (mpmc_debug_configure; the library reads no environment variable for any of them).  The defaults are the
 // production path; none of them changes a result beyond the last bits (tests/test_gpu_round3_fixes.py holds every one to the reference).
+// Pinned host memory comes from the HIP runtime's own pool: an address freed by one context is handed to the next.  The runtime is not
+// instrumented, so the sanitizer build (tools/host_tsan.sh) is told here what the pool's lock orders: every release happens before every
+// later allocation -- otherwise the old owner's writes and the new owner's count as a race between two threads that never shared anything.
+#if defined(__SANITIZE_THREAD__)
+extern "C" void AnnotateHappensBefore(const char *file, int line, const volatile void *tag);
+extern "C" void AnnotateHappensAfter(const char *file, int line, const volatile void *tag);
+inline char g_pinned_pool_tag;
+#endif
+template <class T>
+inline hipError_t pinned_alloc(T **p, size_t bytes) {
+	hipError_t e = hipHostMalloc((void **)p, bytes);
+#if defined(__SANITIZE_THREAD__)
+	AnnotateHappensAfter(__FILE__, __LINE__, &g_pinned_pool_tag);
+#endif
+	return e;
+}
+inline hipError_t pinned_free(void *p) {
+#if defined(__SANITIZE_THREAD__)
+	AnnotateHappensBefore(__FILE__, __LINE__, &g_pinned_pool_tag);
+#endif
+	return hipHostFree(p);
+}
+
 struct mpmc_tuning {
 	int stream_mode = -1;   // "side_stream": -1 by table size (kOneStreamMaxPairs), 0 never fork the side stream, 1 always
 	int pair_kernel = 0;    // "pair_kernel": 0 the fast sweep (kernels_pair.hip) where it applies and the table is large, 1 never, 2 wherever it applies
@@ -47,6 +70,9 @@ struct mpmc_tuning {
 	bool dense_symmetric = true; // "dense_symmetric": the dense solver reads the upper block triangle of A only (0: rounds 1-3, the whole matrix)
 	bool fast_geometry = true; // "fast_geometry": fused minimum image in the pair sweep, the reference's form only inside a 1e-9 band around the cutoff (0: everywhere)
 	int pair_split = -1;    // "pair_split": two waves per tile pair in the fast sweep (half-length workgroups): -1 by default rule, 0 | 1
+	int sweep_lds_pad = 2048; // "sweep_lds_pad": bytes of unused dynamic LDS on the pair sweep's launch when the side stream runs beside it: four
+	                          // workgroups per CU instead of five (no loss: 133 -> 131 us) leave 30 KB of LDS for the reciprocal-space kernels, which otherwise
+	                          // wait for sweep workgroups to retire (k_recip_sf_tab 68 -> 53 us beside the sweep; profiles/r05_one_evaluation_timeline.txt)
 	int fused_update = 0; // "fused_update" = 1 (2: measurement only, arrivals without the update -- results invalid): the dipole update rides the panel launch (last-arriving workgroup per tile); 0 (default): its own launch per iteration -- measured in round 5, profiles/r05_fused_update.txt
 	bool panel_reverse = true; // "panel_reverse": panel entries launched in descending j-tile order; 0: table order (rounds 2-4)
 	bool use_panels = true; // "panels": panel form of the Jacobi contraction (orthorhombic cells, stored tensors); 0: one tile pair per workgroup
@@ -58,6 +84,7 @@ struct mpmc_tuning {
 	bool no_order_carry = false; // "order_carry" = 0: every upload of the atom list sorts
 	bool no_polar_delta = false; // "polar_delta" = 0: trial moves of polarizable boxes run a full evaluation
 	bool no_inline_move = false; // "inline_move" = 0: trial moves always travel through the staging block
+	int virtual_device = -1;     // "virtual_device" = v >= 0 (test hook): mpmc_pi_allreduce treats this context as living on a device of its own (csrc/comm.cpp group_beads)
 	int fail_next_wait = 0;      // "fail_next_wait" = 1: the next wait of this context fails as if the runtime had refused it (test of the recovery path)
 	bool trace_panel = false;    // "trace_panel" = 1: per-workgroup time stamps of the panel kernel (tools/panel_trace.py)
 	long long tensor_budget_mb = 4096; // "tensor_budget_mb": AUTO solver: largest tensor store it will allocate

@@ -45,10 +45,10 @@ static int build_k_tables(mpmc_ctx *c) {
 			c->kstage_in_flight = false;
 		}
 		if ((size_t)K > c->cap_kstage) {
-			if (c->h_kstage) HIP_TRY(c, hipHostFree(c->h_kstage));
+			if (c->h_kstage) HIP_TRY(c, pinned_free(c->h_kstage));
 			c->h_kstage = nullptr;
 			c->cap_kstage = 0;
-			HIP_TRY(c, hipHostMalloc((void **)&c->h_kstage, (size_t)K * (2 * sizeof(double4) + sizeof(double) + sizeof(int4))));
+			HIP_TRY(c, pinned_alloc(&c->h_kstage, (size_t)K * (2 * sizeof(double4) + sizeof(double) + sizeof(int4))));
 			c->cap_kstage = (size_t)K;
 			if (!c->ev_kstage) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_kstage, hipEventDisableTiming));
 		}
@@ -422,7 +422,8 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		if (sweep) {
 			launch_pair_sweep(st, at, c->box, fp, c->n_molecules != c->n, c->d_sweep_blocks, c->n_sweep_blocks, c->d_cls,
 			                  (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->d_erf_tab, c->d_block_part, c->d_block_cnt, c->d_part,
-			                  compact ? c->d_ab : nullptr, sweep_split(c), c->tune.fast_geometry);
+			                  compact ? c->d_ab : nullptr, sweep_split(c), c->tune.fast_geometry,
+			                  (side_deferred || panel_side) ? c->tune.sweep_lds_pad : 0);
 			if (c->n_generic > 0)
 				launch_pair_fused(st, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_generic, c->d_block_part, c->d_block_cnt, c->d_part,
 				                  compact ? c->d_ab : nullptr, c->d_generic_list);
@@ -671,7 +672,8 @@ extern "C" int mpmc_debug_time_pair(mpmc_ctx *c, int reps, double *ms_per_launch
 		if (c->last_pair_was_sweep) {
 			launch_pair_sweep(c->stream, at, c->box, fp, c->n_molecules != c->n, c->d_sweep_blocks, c->n_sweep_blocks, c->d_cls,
 			                  (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->d_erf_tab, c->d_block_part, c->d_block_cnt, c->d_part,
-			                  compact ? c->d_ab : nullptr, sweep_split(c), c->tune.fast_geometry);
+			                  compact ? c->d_ab : nullptr, sweep_split(c), c->tune.fast_geometry,
+			                  c->two_streams ? c->tune.sweep_lds_pad : 0);
 			if (c->n_generic > 0)
 				launch_pair_fused(c->stream, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_generic, c->d_block_part, c->d_block_cnt, c->d_part,
 				                  compact ? c->d_ab : nullptr, c->d_generic_list);

@@ -145,7 +145,7 @@ void launch_pair_fused(hipStream_t st, const AtomsDev &at, const Box &bx, const 
 // ---- the fast pair sweep (kernels_pair.hip): any cell, Ewald electrostatics with alpha r_c inside the erfc table; every tile pair
 // except those with an atom that changes lj_mix (kAtomFlagsMixing: sigma < 0, dispersion coefficients) ----
 struct PairSweepParams {
-	double alpha_scaled, polar_damp, thole_far_x; // alpha_scaled: Ewald alpha over the erfc table's piece width
+	double alpha_scaled_half, polar_damp_half, thole_far_x; // half of: the Ewald alpha over the erfc table's piece width, the Thole damping parameter (the sweep works with 2 r)
 	int store;      // write the Thole tensor store
 	int nt;         // tiles
 	int have_shift; // tp_shift / CLS_UNIFORM_* are valid
@@ -171,7 +171,7 @@ bool pair_sweep_covers(const Box &bx, const FusedParams &fp, double ewald_alpha)
 void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, bool intra /*some molecule has more than one atom*/,
                        const int2 *blocks, int n_blocks, const int *cls, const double4 *tp_shift /*null: no uniform images*/,
                        const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab, bool split = false,
-                       bool fast_geometry = false);
+                       bool fast_geometry = false, int lds_pad_bytes = 0 /*unused dynamic LDS per workgroup: fewer workgroups per CU*/);
 void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt);
 // polarizable evaluations: launch_polar_energy and launch_reduce_pairs as the two blocks of one launch (the tail of the evaluation)
 void launch_polar_energy_and_pairs(hipStream_t st, const AtomsDev &at, const double *mu, const double *e_static, const double *rrms_atom,

@@ -36,8 +36,12 @@ constexpr int kUnmaskable = kAtomFlagsMixing; // (pair_math.h) these change the 
 
 __device__ __forceinline__ int sweep_tp_index(int I, int J, int nt) { return I * nt - (I * (I - 1)) / 2 + (J - I); }
 
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr double kSweepEsScale = 0.5, kSweepFieldScale = 0.125; // the walk works with Y = 2 / r: its Coulomb sum carries 2 / r, its field sums 8 / r^3
+
 struct SweepI { // the i-atom a lane owns
-	double x, y, z, q, hs, e2; // position, charge, sigma / 2, 2 sqrt(epsilon)
+	double x, y, z, q, hs, e2; // position, charge, sigma / 4 (half of the mixing rule's term: the walk multiplies by 2 / r), 2 sqrt(epsilon)
 	double xs, ys, zs;         // position minus the tile pair's common image translation (used per uniform dimension)
 	int mol, fl;
 };
@@ -52,10 +56,16 @@ template <bool FIELD, int MODE, bool PAD>
 __device__ __forceinline__ void sweep_finish(const double2 *__restrict__ s_se, const double2 *__restrict__ s_tab, const int jl, const int lane,
                                              const SweepI &I, const double2 zq, const int2 mfj, const bool ok, const double ox, const double oy,
                                              const double oz, const double ri2, const unsigned long long m_cut_lj, const unsigned long long m_cut_es, const Box &bx,
-                                             const PairSweepParams &pp, const bool half, const bool store, double2 *__restrict__ ab_row, SweepAcc &A,
-                                             int &n_lj, int &n_es) {
-	const double ir = fast_rsqrt_1(ri2);
-	const double r = ri2 * ir;
+                                             const PairSweepParams &pp, const bool half, const bool store, const rsrc_t ab_rsrc, const int ab_soffset,
+                                             SweepAcc &A, int &n_lj, int &n_es) {
+	// Y = 2 / r: hardware seed and one Newton step in its product form y (3 - x y^2) -- one instruction less than the step towards 1 / r,
+	// and every use below absorbs the power of two exactly: the atoms' sigma / 2 arrive as sigma / 4, alpha / H and lambda as halves, the
+	// Coulomb and field sums are scaled once per wave behind the walk (kSweepEsScale, kSweepFieldScale), the Thole factors carry 1 / 8 and
+	// 3 / 32 in their constants.  ~2e-14 relative like fast_rsqrt_1.
+	const double y0 = __builtin_amdgcn_rsq(ri2);
+	const double Y = y0 * fma(-(ri2 * y0), y0, 3.0);
+	const double R2 = ri2 * Y; // 2 r
+	const double Y2 = Y * Y;   // 4 / r^2
 	// pair_exclusions (src/System.cpp:1035-1197) for what this grade of tile pair can hold:
 	//   frozen pair (both frozen): no LJ, no Coulomb, no field -- only the Thole tensor;   excl_rd / excl_es: same molecule, or an atom without
 	//   sigma / epsilon (rd) resp. without charge (es);   no_field: both charges zero (real_term :2916).  MODE 0 / 1 know none / only "same molecule".
@@ -70,16 +80,15 @@ __device__ __forceinline__ void sweep_finish(const double2 *__restrict__ s_se, c
 	}
 
 	if (store) { // thole_amatrix couples every pair: no cutoff, no exclusions, frozen included (:2694-2767)
-		const double ir2 = ir * ir;
-		const double ir3 = ir2 * ir, ir5 = (ir2 * ir2) * ir;
-		const double lr = pp.polar_damp * r;
-		double damp1 = 1.0, damp2 = 1.0;
+		const double Y3 = Y2 * Y, Y5 = (Y2 * Y2) * Y; // 8 / r^3, 32 / r^5
+		const double lr = pp.polar_damp_half * R2;
+		double damp1s = 0.125, damp2s = 0.09375; // damp1 / 8 and 3 damp2 / 32 (the powers of two of Y^3 and Y^5 taken out)
 		if (__any(lr < pp.thole_far_x)) { // wave-uniform: beyond lambda r = kTholeFarX the damping is dropped (as in CLS_THOLE_FAR)
 			const double explr = exp_fast(-lr);
-			damp1 = fma(-explr, fma(lr, fma(0.5, lr, 1.0), 1.0), 1.0); // 1 - e^{-lr} (lr^2/2 + lr + 1)
-			damp2 = fma(-explr, (lr * lr) * (lr * (1.0 / 6.0)), damp1); // damp1 - e^{-lr} lr^3/6
+			damp1s = fma(-explr, fma(lr, fma(0.0625, lr, 0.125), 0.125), 0.125); // (1 - e^{-lr} (lr^2/2 + lr + 1)) / 8
+			damp2s = fma(-explr, (lr * lr) * (lr * 0.015625), 0.75 * damp1s);     // 3 (damp1 - e^{-lr} lr^3/6) / 32
 		}
-		double ta = damp1 * ir3, tb = (3.0 * damp2) * ir5;
+		double ta = damp1s * Y3, tb = damp2s * Y5;
 		if (PAD || half || MODE == 2) {
 			// (coincident sites -- a dummy site on top of an atom -- exist among special atoms: the reference's MAXVALUE guard (:2704-2705) times
 			// its vanishing damping factors is 0)
@@ -87,7 +96,9 @@ __device__ __forceinline__ void sweep_finish(const double2 *__restrict__ s_se, c
 			ta = live ? ta : 0.0;
 			tb = live ? tb : 0.0;
 		}
-		ab_row[lane] = make_double2(ta, tb);
+		// one 16-byte store per lane through a buffer descriptor of the tile pair's block: the row advances in a SCALAR offset (a per-lane 64-bit
+		// pointer cost a v_lshl_add_u64 in every step of every tile pair, stored or not)
+		__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, make_double2(ta, tb)), ab_rsrc, lane * 16, ab_soffset, 0);
 	}
 
 	// the inclusion predicates, and the counts of the pairs they admit: wave-level masks and popcounts (scalar unit), taken OUTSIDE the
@@ -105,15 +116,15 @@ __device__ __forceinline__ void sweep_finish(const double2 *__restrict__ s_se, c
 	if (in_lj) {
 		const double2 se = s_se[jl];
 		if (lj_on) {
-			const double sig = I.hs + se.x; // Lorentz-Berthelot: (s_i + s_j)/2; of 4 sqrt(e_i e_j) the j-atom's factor here, the lane's own at the end of the walk
-			const double sr = sig * ir;
+			const double sig = I.hs + se.x; // Lorentz-Berthelot: (s_i + s_j)/2, here as its half ((s_i + s_j)/4 times Y = 2/r); of 4 sqrt(e_i e_j) the j-atom's factor here, the lane's own at the end of the walk
+			const double sr = sig * Y;
 			const double s3 = (sr * sr) * sr;
 			const double s6 = s3 * s3;
 			A.e_lj = fma(se.y, fma(s6, s6, -s6), A.e_lj); // 4 eps (s^12 - s^6)  (:965-993)
 		}
 		const bool fld_on = FIELD && in_es && !(MODE == 2 && no_field);
 		if (es_on || fld_on) {
-			const double xs = r * pp.alpha_scaled; // alpha r / H: the integer part is the piece, the fraction the argument of its polynomial
+			const double xs = R2 * pp.alpha_scaled_half; // alpha r / H: the integer part is the piece, the fraction the argument of its polynomial
 			const int it = (int)xs;
 			const double dd = __builtin_amdgcn_fract(xs);
 			const double2 c01 = s_tab[it], c23 = s_tab[MPMC_ERFTAB_PIECES + it], c45 = s_tab[2 * MPMC_ERFTAB_PIECES + it];
@@ -128,11 +139,11 @@ __device__ __forceinline__ void sweep_finish(const double2 *__restrict__ s_se, c
 			b = fma(b, dd, c01.y);
 			if (FIELD) d1 = fma(d1, dd, b);
 			const double erfc_x = fma(b, dd, c01.x);
-			if (es_on) A.e_re = fma(zq.y * erfc_x, ir, A.e_re); // q_i q_j erfc(alpha r) / r, the lane's own q_i at the end of the walk
+			if (es_on) A.e_re = fma(zq.y * erfc_x, Y, A.e_re); // 2 q_j erfc(alpha r) / r; the lane's own q_i and the half at the end of the walk
 			if (fld_on) { // real_term :2919-2934: (2 alpha r / sqrt(pi) exp(-alpha^2 r^2) + erfc) / r^3, erf form (= that - 1) for es_excluded pairs
 				double B = fma(-xs, d1, erfc_x); // erfc(x) + 2 x / sqrt(pi) exp(-x^2) = p - (x / H) p'
 				if (MODE >= 1) B -= excl_es ? 1.0 : 0.0;
-				const double fac = B * ((ir * ir) * ir);
+				const double fac = B * (Y2 * Y); // 8 B / r^3 (kSweepFieldScale behind the walk)
 				const double fj = fac * zq.y, fi = fac * I.q;
 				A.ex = fma(fj, ox, A.ex);
 				A.ey = fma(fj, oy, A.ey);
@@ -151,8 +162,8 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
                                            const int2 *__restrict__ s_mf, const double2 *__restrict__ s_tab, const int jl, const int lane,
                                            const SweepI &I, const double shx, const double shy, const double shz, const double t_lo,
                                            const double t_hi, const Box &bx, const PairSweepParams &pp, const bool half, const bool i_real, const bool store,
-                                           double2 *__restrict__ ab_row /*this step's 64 slots of the tensor store (wave-uniform)*/, SweepAcc &A, int &n_lj,
-                                           int &n_es) {
+                                           const rsrc_t ab_rsrc, const int ab_soffset /*this step's row of the tile pair's block of the tensor store: byte offset, scalar*/,
+                                           SweepAcc &A, int &n_lj, int &n_es) {
 	const double2 xy = s_xy[jl], zq = s_zq[jl];
 	int2 mfj = make_int2(0, 0);
 	if (MODE >= 1 || PAD) mfj = s_mf[jl]; // molecule id, flags (padding slots: negative ids, AF_PAD)
@@ -218,7 +229,7 @@ __device__ __forceinline__ void sweep_step(const double2 *__restrict__ s_xy, con
 			exact_geometry();
 		}
 	}
-	sweep_finish<FIELD, MODE, PAD>(s_se, s_tab, jl, lane, I, zq, mfj, ok, ox, oy, oz, ri2, m_lj, m_es, bx, pp, half, store, ab_row, A, n_lj, n_es);
+	sweep_finish<FIELD, MODE, PAD>(s_se, s_tab, jl, lane, I, zq, mfj, ok, ox, oy, oz, ri2, m_lj, m_es, bx, pp, half, store, ab_rsrc, ab_soffset, A, n_lj, n_es);
 }
 
 template <int UM, bool FIELD, int MODE, bool PAD, bool TRI = false>
@@ -226,14 +237,14 @@ __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, con
                                         const int2 *__restrict__ s_mf, const double2 *__restrict__ s_tab, const int lane, const SweepI &I,
                                         const double shx, const double shy, const double shz, const double t_lo, const double t_hi,
                                         const Box &bx, const PairSweepParams &pp, const bool tail_half, const int s_begin, const int s_end, const bool i_real, const bool store,
-                                        double2 *__restrict__ ab_tile, SweepAcc &A, int &n_lj, int &n_es) {
+                                        const rsrc_t ab_rsrc, SweepAcc &A, int &n_lj, int &n_es) {
 	// diagonal tile pair: s = 1..32, the last one with lanes 0..31 only (each pair once); off-diagonal: s = 0..63.  A wave walks the
 	// steps [s_begin, s_end) of that sequence: all of them, or one half of them when two waves share a tile pair (pp.split);
 	// tail_half: this wave's last step is the diagonal tile pair's closing half step
 	// (the closing step is spelled out: inside the loop "half" is a compile-time false and costs nothing)
 	for (int s = s_begin; s < s_end - 1; ++s) {
 		sweep_step<UM, FIELD, MODE, PAD, TRI>(s_xy, s_zq, s_se, s_mf, s_tab, lane + s, lane, I, shx, shy, shz, t_lo, t_hi, bx, pp, false, i_real, store,
-		                                  ab_tile + s * kTile, A, n_lj, n_es);
+		                                  ab_rsrc, s * (kTile * 16), A, n_lj, n_es);
 		if (FIELD) {
 			A.gx = rot_from_next(A.gx);
 			A.gy = rot_from_next(A.gy);
@@ -242,7 +253,7 @@ __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, con
 	}
 	const int s = s_end - 1;
 	sweep_step<UM, FIELD, MODE, PAD, TRI>(s_xy, s_zq, s_se, s_mf, s_tab, lane + s, lane, I, shx, shy, shz, t_lo, t_hi, bx, pp, tail_half, i_real, store,
-	                                  ab_tile + s * kTile, A, n_lj, n_es);
+	                                  ab_rsrc, s * (kTile * 16), A, n_lj, n_es);
 }
 
 // blocks: { J, I0 } -- the workgroup's waves take the tile pairs (I0 + w, J), w = 0..3, as far as I0 + w <= J
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 		const int2 mj = at.mf[j0 + lane];
 		s_xy[lane] = s_xy[lane + kTile] = make_double2(pj.x, pj.y);
 		s_zq[lane] = s_zq[lane + kTile] = make_double2(pj.z, pj.w);
-		s_se[lane] = s_se[lane + kTile] = make_double2(0.5 * lj.x, 2.0 * lj.y);
+		s_se[lane] = s_se[lane + kTile] = make_double2(0.25 * lj.x, 2.0 * lj.y); // sigma / 4, 2 sqrt(eps)
 		s_mf[lane] = s_mf[lane + kTile] = mj; // (padding slots carry negative ids and AF_PAD)
 		const bool padj = (mj.y & AF_PAD) != 0;
 		const int any_unmask = __any(!padj && (mj.y & kUnmaskable) != 0), any_pad = __any(padj), any_spec = __any(!padj && (mj.y & kSpecialAtom) != 0);
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 	if (walk) {
 		SweepI Ai;
 		Ai.x = pi.x, Ai.y = pi.y, Ai.z = pi.z, Ai.q = pi.w;
-		Ai.hs = 0.5 * li.x, Ai.e2 = 2.0 * li.y;
+		Ai.hs = 0.25 * li.x, Ai.e2 = 2.0 * li.y;
 		Ai.mol = mi.x;
 		Ai.fl = mi.y;
 		int um = (pp.have_shift && !pad) ? ((cl / CLS_UNIFORM_X) & 7) : 0; // (the padded tile's pairs take the general image path: one variant)
@@ -349,8 +360,9 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 		}
 		const double t_lo = bx.t_es - bx.t_es * band, t_hi = bx.t_lj + bx.t_lj * band;
 		Ai.xs = Ai.x - shx, Ai.ys = Ai.y - shy, Ai.zs = Ai.z - shz;
-		double2 *ab_tile = store ? ab + (size_t)tp * (kTile * kTile) : nullptr;
-#define MPMC_SWEEP_ARGS s_xy, s_zq, s_se, s_mf, s_tab, lane, Ai, shx, shy, shz, t_lo, t_hi, bx, pp, tail_half, s_begin, s_end, i_real, store, ab_tile, A, n_lj, n_es
+		// the tile pair's 64 x 64 block of the tensor store behind a buffer descriptor (64 KiB; raw, 32-bit elements): rows are scalar offsets
+		const rsrc_t ab_rsrc = __builtin_amdgcn_make_buffer_rsrc(store ? (void *)(ab + (size_t)tp * (kTile * kTile)) : (void *)nullptr, 0, store ? kTile * kTile * 16 : 0, 0x00027000);
+#define MPMC_SWEEP_ARGS s_xy, s_zq, s_se, s_mf, s_tab, lane, Ai, shx, shy, shz, t_lo, t_hi, bx, pp, tail_half, s_begin, s_end, i_real, store, ab_rsrc, A, n_lj, n_es
 #define MPMC_SWEEP_UM(MODE)                                                        \
 	switch (um) {                                                                  \
 	case 0:                                                                        \
@@ -376,7 +388,11 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 #undef MPMC_SWEEP_UM
 #undef MPMC_SWEEP_ARGS
 		A.e_lj *= Ai.e2; // (the i-atom's factors of 4 sqrt(e_i e_j) and q_i q_j, once per wave instead of once per pair)
-		A.e_re *= Ai.q;
+		A.e_re *= kSweepEsScale * Ai.q;
+		if (FIELD) {
+			A.ex *= kSweepFieldScale, A.ey *= kSweepFieldScale, A.ez *= kSweepFieldScale;
+			A.gx *= kSweepFieldScale, A.gy *= kSweepFieldScale, A.gz *= kSweepFieldScale;
+		}
 	}
 	// the j-atom whose accumulator this lane ended up holding: after step s (no rotation behind the last one) lane l pairs with (l + s) & 63
 	const int jown = (lane + s_end - 1) & 63;
@@ -461,25 +477,26 @@ bool pair_sweep_covers(const Box &bx, const FusedParams &fp, double ewald_alpha)
 
 void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, bool intra, const int2 *blocks, int n_blocks,
                        const int *cls, const double4 *tp_shift, const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab,
-                       bool split, bool fast_geometry) {
+                       bool split, bool fast_geometry, int lds_pad_bytes) {
 	PairSweepParams pp;
 	pp.split = split ? 1 : 0;
-	pp.alpha_scaled = fp.ewald_alpha * MPMC_ERFTAB_INV_H; // (a power of two: (alpha r) / H and (alpha / H) r are the same double)
-	pp.polar_damp = fp.polar_damp;
+	pp.alpha_scaled_half = 0.5 * (fp.ewald_alpha * MPMC_ERFTAB_INV_H); // (powers of two: (alpha r) / H and (alpha / 2H) (2r) are the same double)
+	pp.polar_damp_half = 0.5 * fp.polar_damp;
 	pp.thole_far_x = fp.thole_far_x;
 	pp.store = (fp.do_thole && ab) ? 1 : 0;
 	pp.nt = at.n_pad / kTile;
 	pp.have_shift = tp_shift ? 1 : 0;
 	pp.fast = fast_geometry ? 1 : 0; // (the per-tile-pair band comes from k_classify: tp_shift.w)
 	dim3 grid(split ? 2 * n_blocks : n_blocks), block(64 * kSweepWaves);
+	const unsigned lds = lds_pad_bytes > 0 ? (unsigned)lds_pad_bytes : 0u; // unused dynamic LDS: caps the workgroups per CU (see evaluate.cpp)
 #define MPMC_PS(F, N)                                                                                                                                 \
 	do {                                                                                                                                          \
 		if (bx.ortho) {                                                                                                                           \
-			if (split) hipLaunchKernelGGL((k_pair_sweep<F, N, true, true>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab); \
-			else hipLaunchKernelGGL((k_pair_sweep<F, N, true, false>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab);    \
+			if (split) hipLaunchKernelGGL((k_pair_sweep<F, N, true, true>), grid, block, lds, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab); \
+			else hipLaunchKernelGGL((k_pair_sweep<F, N, true, false>), grid, block, lds, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab);    \
 		} else {                                                                                                                                  \
-			if (split) hipLaunchKernelGGL((k_pair_sweep<F, N, false, true>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab); \
-			else hipLaunchKernelGGL((k_pair_sweep<F, N, false, false>), grid, block, 0, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab);   \
+			if (split) hipLaunchKernelGGL((k_pair_sweep<F, N, false, true>), grid, block, lds, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab); \
+			else hipLaunchKernelGGL((k_pair_sweep<F, N, false, false>), grid, block, lds, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab);   \
 		}                                                                                                                                         \
 	} while (0)
 	if (fp.do_field == 1) {

@@ -471,14 +471,14 @@ __device__ __forceinline__ void panel_update_tile(const AtomsDev &at, const Pane
 		}
 	}
 	// One list of T = nF + nG slots (i-side first); group g takes t = g, g + 16, ...  Every load is issued unconditionally (a slot index
-	// past the end is clamped and its value replaced by zero: no branch between the loads), two rounds of the wave's groups per trip: 24
+	// past the end is clamped and its value replaced by zero: no branch between the loads), 8 / GW rounds of the wave's groups per trip: 24
 	// independent loads in flight per lane -- the update is a latency chain (few workgroups, data fresh from other CUs), not a bandwidth one.
 	double f[GW][3] = {};
 	const size_t n_pad = (size_t)at.n_pad;
 	const int T = nF + nG;
 	const double *__restrict__ pX = part + ((size_t)X * n_pad + (size_t)X * kTile) * 3 + a; // slot X, this tile's block; slot X + t is t * n_pad * 3 further
 	const double *__restrict__ gX = gpart + (size_t)wg0 * (kTile * 3) + a;
-	constexpr int ROUNDS = 2;
+	constexpr int ROUNDS = 8 / GW;
 	for (int t0 = 0; t0 < T; t0 += ROUNDS * kUpdGroups) {
 		double v[ROUNDS][GW][3];
 #pragma unroll

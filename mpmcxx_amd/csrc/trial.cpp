@@ -21,10 +21,10 @@ static int ensure_trial_buffers(mpmc_ctx *c) {
 		if ((rc = dev_alloc(c, &c->d_delta_out, (size_t)8)) != MPMC_OK) return rc; // 5 doubles + 2 int64 counts
 		c->d_delta_cnt = reinterpret_cast<long long *>(c->d_delta_out + 5);
 		HIP_TRY(c, hipMemsetAsync(c->d_moved_idx, 0xff, (size_t)c->max_pad * sizeof(int), c->stream)); // all -1; on our stream (ordered before the first delta kernel)
-		HIP_TRY(c, hipHostMalloc((void **)&c->h_delta_out, 9 * sizeof(double)));
+		HIP_TRY(c, pinned_alloc(&c->h_delta_out, 9 * sizeof(double)));
 		c->h_delta_out[8] = 0.0;
 		c->h_delta_cnt = reinterpret_cast<long long *>(c->h_delta_out + 5);
-		HIP_TRY(c, hipHostMalloc((void **)&c->h_mv_blob, kMvBlobBytes));
+		HIP_TRY(c, pinned_alloc(&c->h_mv_blob, kMvBlobBytes));
 	}
 	if (c->K > c->cap_sf_trial) {
 		dev_free(c, &c->d_sf_trial, (size_t)c->cap_sf_trial);

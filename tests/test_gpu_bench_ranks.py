@@ -102,7 +102,8 @@ def test_two_ranks_on_two_devices_over_rccl(single):
 
 def test_inprocess_launch_drives_the_devices_through_mpmc_pi_allreduce():
     """--launch inprocess: ONE process, bead b on device b mod N, mpmc_pi_allreduce (host thread per device, ncclCommInitAll).  On a one-GPU
-    box both "devices" are device 0 (--force-device), so the communicator has one rank; the step and its ordered sum are the real ones."""
+    box both "devices" are virtual devices of device 0 (--force-device: the library's test hook): two host threads, the real hand-off and
+    ordered sum, a host copy where RCCL (one rank per physical device) would be."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, cwd=util.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -112,7 +113,7 @@ def test_inprocess_launch_drives_the_devices_through_mpmc_pi_allreduce():
     a, b = last_json(one.stdout), last_json(inp.stdout)
     assert b["n_gpus"] == 2 and b["config"]["world_size"] == 1 and b["config"]["launch"].startswith("inprocess")
     assert "mpmc_pi_allreduce" in b["config"]["combine_impl"]
-    assert len(b["config"]["ranks"]) == 2 and all(r["comm_n_ranks"] == 1 and r["distinct_devices"] == 1 for r in b["config"]["ranks"])
+    assert len(b["config"]["ranks"]) == 2 and all(r["comm_n_ranks"] == 2 and r["distinct_devices"] == 2 for r in b["config"]["ranks"])
     assert a["V_mean_K"] == b["V_mean_K"] and a["obs_rd_es_pol_vdw"] == b["obs_rd_es_pol_vdw"]
 
 

@@ -63,6 +63,25 @@ def test_single_rank_communicator_round_trip():
     cm.close()
 
 
+def test_thread_per_device_path_on_virtual_devices_of_one_gpu():
+    """mpmc_pi_allreduce with G > 1: one host thread per device evaluates that device's beads, the per-bead values are gathered and summed
+    in bead order.  RCCL admits one rank per physical device, so on a one-GPU box the beads are given VIRTUAL devices (test hook
+    "virtual_device": same worker threads, same hand-off, same ordered combine; the gather is a host copy) -- repeated, with 3 "devices"
+    and 7 beads (uneven shares), against the one-thread local loop."""
+    beads = make_beads(7, name="ion216_polar")
+    s_local, per_local, f_local = energy.pi_potential_local(beads)
+    for k, b in enumerate(beads):
+        b.configure("virtual_device", k % 3)
+    assert energy.pi_allreduce_info(beads)[0] == 3
+    for _ in range(5):
+        s_thr, per_thr, f_thr = energy.pi_allreduce(beads)
+        assert np.array_equal(s_local, s_thr) and f_local == f_thr
+        assert [p["energy"] for p in per_local] == [p["energy"] for p in per_thr]
+    assert energy.pi_allreduce_info(beads) == (3, 3)
+    for b in beads:
+        b.close()
+
+
 def test_two_devices_one_process_bead_b_on_device_b_mod_g():
     if energy.device_count() < 2:
         pytest.skip("needs two GPUs (one process driving several devices: ncclCommInitAll)")

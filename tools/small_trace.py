@@ -47,6 +47,11 @@ if name in util.LARGE:  # (the 10 000-atom boxes are regenerated, not committed)
 else:
     atoms, basis, opts = util.load_fixture(name)
 S = energy.System(atoms, basis, opts)
+for arg in sys.argv[3:]:  # "cfg:key=v,key=v": measurement switches of this context
+    if arg.startswith("cfg:"):
+        for kv in filter(None, arg[4:].split(",")):
+            k, _, v = kv.partition("=")
+            S.configure(k, float(v))
 if len(sys.argv) > 3 and sys.argv[3] == "volume":  # us per volume move (NPT / Gibbs): set_box with scaled positions + full evaluation
     import numpy as np
 
