@@ -943,7 +943,10 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 		t.fused_update = v;
 	}
 	else if (k == "panel_reverse") t.panel_reverse = on;
-	else if (k == "sweep_lds_pad") {
+	else if (k == "update_waves") {
+		if (v != 0 && v != 1 && v != 2 && v != 4 && v != 16) return MPMC_ERR_ARG;
+		t.update_waves = v;
+	} else if (k == "sweep_lds_pad") {
 		if (v < 0 || v > 65536) return MPMC_ERR_ARG;
 		t.sweep_lds_pad = v;
 	}

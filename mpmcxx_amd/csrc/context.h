@@ -70,6 +70,9 @@ struct mpmc_tuning {
 	bool dense_symmetric = true; // "dense_symmetric": the dense solver reads the upper block triangle of A only (0: rounds 1-3, the whole matrix)
 	bool fast_geometry = true; // "fast_geometry": fused minimum image in the pair sweep, the reference's form only inside a 1e-9 band around the cutoff (0: everywhere)
 	int pair_split = -1;    // "pair_split": two waves per tile pair in the fast sweep (half-length workgroups): -1 by default rule, 0 | 1
+	int update_waves = 0; // "update_waves": waves per workgroup of the dipole update launch: 0 = 4 (round 5) | 1 | 2 | 4 | 16 (rounds 2-4).  A 16-wave workgroup needs
+	                      // sixteen free wave slots on ONE CU at once: with 32 beads in flight the launch waited ~170 us for them (0.02 ms with four waves, +2.3 %
+	                      // evaluations/s); alone four waves are faster too (1008 against 1019 us per evaluation): profiles/r05_update_waves.txt
 	int sweep_lds_pad = 2048; // "sweep_lds_pad": bytes of unused dynamic LDS on the pair sweep's launch when the side stream runs beside it: four
 	                          // workgroups per CU instead of five (no loss: 133 -> 131 us) leave 30 KB of LDS for the reciprocal-space kernels, which otherwise
 	                          // wait for sweep workgroups to retire (k_recip_sf_tab 68 -> 53 us beside the sweep; profiles/r05_one_evaluation_timeline.txt)

@@ -558,7 +558,8 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 				ProfScope p(c, MPMC_K_REDUCE);
 				if (compact && c->panels_built && !dense)
 					launch_dipole_update_panel(st, at, c->d_e_static, c->d_part, c->d_gpart, c->d_seg, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur],
-					                           c->d_e_induced, want_rrms, c->d_rrms, allowed, ctl, host_flag, it);
+					                           c->d_e_induced, want_rrms, c->d_rrms, allowed, ctl, host_flag, it,
+					                           c->tune.update_waves ? c->tune.update_waves : 4);
 				else
 					launch_dipole_update(st, at, c->d_e_static, c->d_part, iter_slots, c->d_mu[c->mu_cur], c->d_mu[1 - c->mu_cur], c->d_e_induced,
 					                     want_rrms, c->d_rrms, allowed, ctl, host_flag, it);
@@ -668,12 +669,13 @@ extern "C" int mpmc_debug_time_pair(mpmc_ctx *c, int reps, double *ms_per_launch
 	const AtomsDev at = atoms_view(c);
 	const FusedParams &fp = c->last_fp;
 	const bool compact = c->solver_used == MPMC_SOLVER_COMPACT && fp.do_thole;
+	bool timed = false; // (the warm-up launches run the plain grid; the timed ones carry the replicas of "panel_replicas", if any)
 	auto launch = [&] {
 		if (c->last_pair_was_sweep) {
 			launch_pair_sweep(c->stream, at, c->box, fp, c->n_molecules != c->n, c->d_sweep_blocks, c->n_sweep_blocks, c->d_cls,
 			                  (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->d_erf_tab, c->d_block_part, c->d_block_cnt, c->d_part,
 			                  compact ? c->d_ab : nullptr, sweep_split(c), c->tune.fast_geometry,
-			                  c->two_streams ? c->tune.sweep_lds_pad : 0);
+			                  c->two_streams ? c->tune.sweep_lds_pad : 0, timed ? c->debug_panel_replicas : 1);
 			if (c->n_generic > 0)
 				launch_pair_fused(c->stream, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_generic, c->d_block_part, c->d_block_cnt, c->d_part,
 				                  compact ? c->d_ab : nullptr, c->d_generic_list);
@@ -686,6 +688,7 @@ extern "C" int mpmc_debug_time_pair(mpmc_ctx *c, int reps, double *ms_per_launch
 	HIP_TRY(c, hipEventCreate(&e0));
 	HIP_TRY(c, hipEventCreate(&e1));
 	for (int r = 0; r < 2; r++) launch();
+	timed = true;
 	HIP_TRY(c, hipEventRecord(e0, c->stream));
 	for (int r = 0; r < reps; r++) launch();
 	HIP_TRY(c, hipEventRecord(e1, c->stream));

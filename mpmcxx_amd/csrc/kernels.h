@@ -171,7 +171,8 @@ bool pair_sweep_covers(const Box &bx, const FusedParams &fp, double ewald_alpha)
 void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, bool intra /*some molecule has more than one atom*/,
                        const int2 *blocks, int n_blocks, const int *cls, const double4 *tp_shift /*null: no uniform images*/,
                        const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab, bool split = false,
-                       bool fast_geometry = false, int lds_pad_bytes = 0 /*unused dynamic LDS per workgroup: fewer workgroups per CU*/);
+                       bool fast_geometry = false, int lds_pad_bytes = 0 /*unused dynamic LDS per workgroup: fewer workgroups per CU*/,
+                       int replicas = 1 /*measurement only: the grid repeated in y (mpmc_debug_time_pair with panel_replicas)*/);
 void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt);
 // polarizable evaluations: launch_polar_energy and launch_reduce_pairs as the two blocks of one launch (the tail of the evaluation)
 void launch_polar_energy_and_pairs(hipStream_t st, const AtomsDev &at, const double *mu, const double *e_static, const double *rrms_atom,
@@ -224,7 +225,7 @@ void launch_dipole_iter_panel(hipStream_t st, const AtomsDev &at, const Box &bx,
                               const PanelFuse *fuse = nullptr);
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,
                                 const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr,
-                                int *ctl, int *host_flag, int it);
+                                int *ctl, int *host_flag, int it, int waves = 16 /*waves per workgroup: 16 | 4*/);
 // lane-rotation primitive self-test: out[l] = lane whose value lane l received (must be (l+1)&63)
 void launch_rot_selftest(hipStream_t st, int *out);
 

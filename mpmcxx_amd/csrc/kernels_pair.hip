@@ -477,7 +477,7 @@ bool pair_sweep_covers(const Box &bx, const FusedParams &fp, double ewald_alpha)
 
 void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, bool intra, const int2 *blocks, int n_blocks,
                        const int *cls, const double4 *tp_shift, const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab,
-                       bool split, bool fast_geometry, int lds_pad_bytes) {
+                       bool split, bool fast_geometry, int lds_pad_bytes, int replicas) {
 	PairSweepParams pp;
 	pp.split = split ? 1 : 0;
 	pp.alpha_scaled_half = 0.5 * (fp.ewald_alpha * MPMC_ERFTAB_INV_H); // (powers of two: (alpha r) / H and (alpha / 2H) (2r) are the same double)
@@ -487,7 +487,7 @@ void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const 
 	pp.nt = at.n_pad / kTile;
 	pp.have_shift = tp_shift ? 1 : 0;
 	pp.fast = fast_geometry ? 1 : 0; // (the per-tile-pair band comes from k_classify: tp_shift.w)
-	dim3 grid(split ? 2 * n_blocks : n_blocks), block(64 * kSweepWaves);
+	dim3 grid(split ? 2 * n_blocks : n_blocks, replicas > 1 ? replicas : 1), block(64 * kSweepWaves); // (replicas: measurement only -- the same work blockIdx.y times)
 	const unsigned lds = lds_pad_bytes > 0 ? (unsigned)lds_pad_bytes : 0u; // unused dynamic LDS: caps the workgroups per CU (see evaluate.cpp)
 #define MPMC_PS(F, N)                                                                                                                                 \
 	do {                                                                                                                                          \

@@ -478,7 +478,7 @@ __device__ __forceinline__ void panel_update_tile(const AtomsDev &at, const Pane
 	const int T = nF + nG;
 	const double *__restrict__ pX = part + ((size_t)X * n_pad + (size_t)X * kTile) * 3 + a; // slot X, this tile's block; slot X + t is t * n_pad * 3 further
 	const double *__restrict__ gX = gpart + (size_t)wg0 * (kTile * 3) + a;
-	constexpr int ROUNDS = 8 / GW;
+	constexpr int ROUNDS = (8 / GW) > 0 ? 8 / GW : 1;
 	for (int t0 = 0; t0 < T; t0 += ROUNDS * kUpdGroups) {
 		double v[ROUNDS][GW][3];
 #pragma unroll
@@ -640,13 +640,15 @@ __global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev
 	}
 }
 
-// the update as a launch of its own (measurement switch fused_update = 0, and the timing launches of mpmc_debug_time_panel's replicas):
-// one workgroup of sixteen waves per tile, the same function, the same sums
-__global__ __launch_bounds__(64 * kUpdGroups) void k_dipole_update_panel(AtomsDev at, const double *__restrict__ part, const double *__restrict__ gpart,
-                                                                         const double *__restrict__ mu_old, const PanelUpdate u) {
+// the update as a launch of its own (the default; fused_update = 1 rides the contraction instead): one workgroup per tile, the same function,
+// the same sums whatever NW.  Four waves by default (update_waves): a sixteen-wave workgroup must find sixteen free wave slots on one CU,
+// which an ensemble's other kernels rarely leave (the launch then waits ~170 us for them), and is no faster alone.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_dipole_update_panel(AtomsDev at, const double *__restrict__ part, const double *__restrict__ gpart,
+                                                                 const double *__restrict__ mu_old, const PanelUpdate u) {
 	__shared__ double sh[kUpdGroups][kTile][3];
 	if (u.ctl && u.ctl[1] != 0) return; // converged in an earlier iteration (block-uniform)
-	panel_update_tile<kUpdGroups, false>(at, u, part, gpart, mu_old, blockIdx.x, sh);
+	panel_update_tile<NW, false>(at, u, part, gpart, mu_old, blockIdx.x, sh);
 }
 
 void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg, int4 *panels, int *arrive) {
@@ -680,11 +682,14 @@ void launch_dipole_iter_panel(hipStream_t st, const AtomsDev &at, const Box &bx,
 
 void launch_dipole_update_panel(hipStream_t st, const AtomsDev &at, const double *e_static, const double *part, const double *gpart, const int *seg,
                                 const double *mu_old, double *mu_new, double *e_induced, int want_rrms, double *rrms_atom, double allowed_sqerr,
-                                int *ctl, int *host_flag, int it) {
+                                int *ctl, int *host_flag, int it, int waves) {
 	PanelUpdate u{};
 	u.e_static = e_static, u.seg = seg, u.mu_new = mu_new, u.e_induced = e_induced, u.rrms_atom = rrms_atom, u.allowed_sqerr = allowed_sqerr;
 	u.ctl = ctl, u.host_flag = host_flag, u.arrive = nullptr, u.nt = at.n_pad / kTile, u.it = it, u.want_rrms = want_rrms;
-	hipLaunchKernelGGL(k_dipole_update_panel, dim3(at.n_pad / kTile), dim3(kTile * kUpdGroups), 0, st, at, part, gpart, mu_old, u);
+	if (waves == 4) hipLaunchKernelGGL(k_dipole_update_panel<4>, dim3(at.n_pad / kTile), dim3(kTile * 4), 0, st, at, part, gpart, mu_old, u);
+	else if (waves == 2) hipLaunchKernelGGL(k_dipole_update_panel<2>, dim3(at.n_pad / kTile), dim3(kTile * 2), 0, st, at, part, gpart, mu_old, u);
+	else if (waves == 1) hipLaunchKernelGGL(k_dipole_update_panel<1>, dim3(at.n_pad / kTile), dim3(kTile), 0, st, at, part, gpart, mu_old, u);
+	else hipLaunchKernelGGL(k_dipole_update_panel<kUpdGroups>, dim3(at.n_pad / kTile), dim3(kTile * kUpdGroups), 0, st, at, part, gpart, mu_old, u);
 }
 
 } // namespace mpmc

@@ -27,6 +27,9 @@ def sources():
 def test_no_null_stream_api_in_the_library():
     bad = []
     for f, txt in sources():
+        # the one exception (ABI 6): mpmc_device_synchronize IS a device-wide fence, called by a host program around its timing bracket --
+        # hipDeviceSynchronize waits for the non-blocking streams too, and nothing of the energy path runs through it
+        txt = re.sub(r'extern "C" int mpmc_device_synchronize\(int device\) \{.*?\n\}', "", txt, flags=re.S)
         for pat in FORBIDDEN:
             for m in re.finditer(pat, txt):
                 bad.append((f, txt[max(0, m.start() - 40):m.end() + 20].replace("\n", " ")))

@@ -11,7 +11,7 @@ for spec in "$@"; do
 import json
 d=json.load(open("gpurun_out/abl_${label}_${rep}.json"))
 r=d["roofline"]
-oc={o["workload"][:10]: o for o in d.get("other_configs", [])}
+oc={o["workload"][:10]: o for o in (r.get("other_configs") or d.get("other_configs", []))}
 pair=(r.get("other_kernels") or {}).get("pair", {})
 print("rep${rep} %-10s: %.1f evals/s (pcie %.1f)  panel %.2f us (frac %.3f)  pair %.1f us (frac %.3f)  alone: cfg2 %.0f/s cfg3 %.0f/s  in flight: cfg2 %.0f/s" % (
     "${label}", d["value"], d.get("pcie_inclusive_value", 0), r["avg_launch_ms"] * 1e3, r["frac"], pair.get("avg_launch_ms", 0) * 1e3, pair.get("frac", 0),
