@@ -1,6 +1,6 @@
 #!/bin/bash
 # regenerates the judged artefacts of profiles/ in ONE gpurun call (same box for every number) -- run ONCE per round, on the final build:
-#   gpurun --timeout 1200 -- 'bash tools/final_profiles.sh'   then   bash tools/final_profiles.sh --collect r04   (here, after the merge)
+#   gpurun --timeout 1200 -- 'bash tools/final_profiles.sh'   then   bash tools/final_profiles.sh --collect r05   (here, after the merge)
 # 1. the driver's command (python bench.py)                                       -> <tag>_final_bench_default.json
 # 2. rocprofv3 --kernel-trace --stats of the same command (no CPU leg)            -> <tag>_final_bench_default_kernel_stats.csv + the JSON line
 # 3. tools/rehearsal_curve.sh: 32 .. 1 beads in flight, with and without events   -> <tag>_rehearsal_beads_per_gpu.txt
@@ -13,7 +13,7 @@ set -o pipefail
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 if [ "$1" = "--collect" ]; then
-	tag=${2:-r04}
+	tag=${2:-r05}
 	id=$(cat $out/final_profiles.id)
 	cp $out/final_bench_default.json profiles/${tag}_final_bench_default.json
 	cp $out/final_bench_under_rocprof.json profiles/${tag}_final_bench_default_under_rocprof.json
@@ -26,7 +26,11 @@ if [ "$1" = "--collect" ]; then
 	cp $out/final_solver_time.txt profiles/${tag}_solver_time.txt
 	cp $out/final_trace10k.txt profiles/${tag}_one_evaluation_timeline.txt
 	cp $out/final_bench_dense.json profiles/${tag}_bench_dense_solver.json
-	cp $out/final_bench_gloo2.json profiles/${tag}_bench_two_ranks_one_gpu_gloo.json
+	cp $out/final_bench_hub2.json profiles/${tag}_bench_two_ranks_one_gpu_hub.json
+	cp $out/final_bench_cabi2.json profiles/${tag}_bench_two_ranks_one_gpu_cabi_fallback.json
+	cp $out/final_bench_torchrun2.json profiles/${tag}_bench_two_ranks_one_gpu_under_torchrun.json
+	cp $out/final_alone.txt profiles/${tag}_alone.txt
+	cp $out/final_sweep_replicas.txt profiles/${tag}_sweep_replicas.txt
 	cp $out/final_bench_inprocess2.json profiles/${tag}_bench_inprocess_two_device_slots.json
 	exit 0
 fi
@@ -45,8 +49,12 @@ echo "solver time"; timeout -k 10 300 python3 tools/solver_time.py > $out/final_
 echo "timeline"; rm -rf $out/trace10k_$id; (cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $out/trace10k_$id -- python3 $root/tools/small_trace.py ion10k_polar 30 > $out/final_trace10k.log 2>&1)
 cd $root && python3 tools/small_trace.py --report $out/trace10k_$id > $out/final_trace10k.txt 2>&1; head -3 $out/final_trace10k.txt
 echo "dense"; timeout -k 10 300 python3 bench.py --solver dense --beads 4 --steps 3 --warmup 1 --cpu-baseline none --no-other-configs > $out/final_bench_dense.json 2> $out/final_bench_dense.err || echo "dense bench failed"
-echo "two ranks on one GPU (gloo), started bare"; timeout -k 10 300 python3 bench.py --gpus 2 --dist-backend gloo --force-device 0 --steps 5 --warmup 2 --cpu-baseline none > $out/final_bench_gloo2.json 2> $out/final_bench_gloo2.err || echo "gloo2 failed"
+echo "two torch-free ranks on one GPU, started bare, combine over the socket hub"; timeout -k 10 300 python3 bench.py --gpus 2 --combine-impl hub --force-device 0 --steps 5 --warmup 2 --cpu-baseline none > $out/final_bench_hub2.json 2> $out/final_bench_hub2.err || echo "hub2 failed"
+echo "the same with the default --combine-impl cabi: RCCL refuses two ranks on one device, every rank falls back together"; timeout -k 10 300 python3 bench.py --gpus 2 --force-device 0 --comm-init-timeout 60 --steps 5 --warmup 2 --cpu-baseline none > $out/final_bench_cabi2.json 2> $out/final_bench_cabi2.err || echo "cabi2 failed"
+echo "the driver's form: two ranks under python -m torch.distributed.run"; timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --combine-impl hub --force-device 0 --steps 5 --warmup 2 --cpu-baseline none > $out/final_bench_torchrun2.json 2> $out/final_bench_torchrun2.err || echo "torchrun2 failed"
+echo "one evaluation at a time"; timeout -k 10 300 python3 tools/alone_ab.py "default:" > $out/final_alone.txt 2>&1; cat $out/final_alone.txt
+echo "sweep without fill and drain"; timeout -k 10 300 python3 tools/sweep_replicas.py > $out/final_sweep_replicas.txt 2>&1; cat $out/final_sweep_replicas.txt
 echo "in-process, two device slots"; timeout -k 10 300 python3 bench.py --gpus 2 --launch inprocess --force-device 0 --steps 5 --warmup 2 --cpu-baseline none > $out/final_bench_inprocess2.json 2> $out/final_bench_inprocess2.err || echo "inprocess2 failed"
-for f in final_bench_dense final_bench_gloo2 final_bench_inprocess2; do python3 -c "
+for f in final_bench_dense final_bench_hub2 final_bench_cabi2 final_bench_torchrun2 final_bench_inprocess2; do python3 -c "
 import json,sys
-d=json.loads(open('$out/$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['n_gpus'], d['config'].get('launch'))"; done
+d=json.loads(open('$out/$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['n_gpus'], d['config'].get('launch'), '|', d['config'].get('combine_impl'))"; done

@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import test_gpu_random as T
+if "fused" in sys.argv:  # the dipole update riding the panel launch (fused_update = 1; round 5, off by default): last-arriving workgroup per tile
+    sys.argv.remove("fused")
+    from mpmcxx_amd import energy as _E4
+    _E4.configure("fused_update", 1)
 if "split" in sys.argv:  # ... and its two-waves-per-tile-pair form (pair_split = 1; off by default since round 4)
     sys.argv.remove("split")
     from mpmcxx_amd import energy as _E2

@@ -12,6 +12,8 @@ run timeout -k 10 240 python3 tools/fuzz.py 60000 600 sweep split
 run timeout -k 10 240 python3 tools/fuzz_large.py 6000 60 sweep split
 run timeout -k 10 240 python3 tools/fuzz_large.py 7000 100 grid
 run timeout -k 10 240 python3 tools/fuzz_large.py 7500 100 sweep grid
+run timeout -k 10 240 python3 tools/fuzz_large.py 8000 100 fused
+run timeout -k 10 240 python3 tools/fuzz.py 80000 400 fused
 run timeout -k 10 200 python3 tools/fuzz_trial.py 3000 300
 run timeout -k 10 240 python3 tools/fuzz_trial.py 5000 400 polar
 run timeout -k 10 150 python3 tools/fuzz_state.py 3000 120 4

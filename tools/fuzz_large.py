@@ -11,6 +11,10 @@ if "grid" in sys.argv:  # the aligned-grid spatial order of large tables (round 
     from mpmcxx_amd import energy as _E3
     _E3.configure("sort_nx", 4)
     _E3.configure("sort_ny", 2)
+if "fused" in sys.argv:  # the dipole update riding the panel launch (fused_update = 1; round 5, off by default): last-arriving workgroup per tile
+    sys.argv.remove("fused")
+    from mpmcxx_amd import energy as _E4
+    _E4.configure("fused_update", 1)
 if "split" in sys.argv:  # ... and its two-waves-per-tile-pair form (pair_split = 1; off by default since round 4)
     sys.argv.remove("split")
     from mpmcxx_amd import energy as _E2
