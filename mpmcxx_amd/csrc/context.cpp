@@ -706,6 +706,7 @@ extern "C" int mpmc_set_atoms(mpmc_ctx *c, int n, const double *pos, const doubl
 		const int nb = pair_sweep_blocks(nt, nullptr);
 		std::vector<int2> blocks((size_t)nb);
 		pair_sweep_blocks(nt, blocks.data());
+		if (c->tune.sweep_order == 1) std::reverse(blocks.begin(), blocks.end()); // j-tiles descending (measurement)
 		if ((size_t)nb > c->cap_sweep_blocks) {
 			dev_free(c, &c->d_sweep_blocks, c->cap_sweep_blocks);
 			c->cap_sweep_blocks = 0;
@@ -943,7 +944,11 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 		t.fused_update = v;
 	}
 	else if (k == "panel_reverse") t.panel_reverse = on;
-	else if (k == "update_waves") {
+	else if (k == "sweep_order") {
+		if (v < 0 || v > 1) return MPMC_ERR_ARG;
+		t.sweep_order = v;
+		if (c) c->sweep_tiles = -1, c->atoms_dirty = true; // (the table is rebuilt with the next upload)
+	} else if (k == "update_waves") {
 		if (v != 0 && v != 1 && v != 2 && v != 4 && v != 16) return MPMC_ERR_ARG;
 		t.update_waves = v;
 	} else if (k == "sweep_lds_pad") {

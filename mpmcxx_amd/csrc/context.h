@@ -70,6 +70,8 @@ struct mpmc_tuning {
 	bool dense_symmetric = true; // "dense_symmetric": the dense solver reads the upper block triangle of A only (0: rounds 1-3, the whole matrix)
 	bool fast_geometry = true; // "fast_geometry": fused minimum image in the pair sweep, the reference's form only inside a 1e-9 band around the cutoff (0: everywhere)
 	int pair_split = -1;    // "pair_split": two waves per tile pair in the fast sweep (half-length workgroups): -1 by default rule, 0 | 1
+	int sweep_order = 1; // "sweep_order": the pair sweep's work table by descending j-tile (1, round 5: the short rows with their partial entries end the launch; -2 to -4 % per lone
+	                     // launch without field and store, level with them) | 0 ascending (rounds 3-4)
 	int update_waves = 0; // "update_waves": waves per workgroup of the dipole update launch: 0 = 4 (round 5) | 1 | 2 | 4 | 16 (rounds 2-4).  A 16-wave workgroup needs
 	                      // sixteen free wave slots on ONE CU at once: with 32 beads in flight the launch waited ~170 us for them (0.02 ms with four waves, +2.3 %
 	                      // evaluations/s); alone four waves are faster too (1008 against 1019 us per evaluation): profiles/r05_update_waves.txt
