@@ -47,6 +47,9 @@ namespace mpmc {
 int panel_segment_entries(int J) { return J / 2 + 3; }
 constexpr int kPanFar = 8, kPanDiag = 16;
 constexpr int kPanelWaves = 4; // waves per workgroup: they split the steps of ONE entry's walk
+#ifndef MPMC_PANEL_PIPE
+#define MPMC_PANEL_PIPE 4 // depth of the stored walk's prefetch ring (steps ahead): 2 / 8 measured in round 5, tools/README.md
+#endif
 constexpr double kFarSumScale = 0.125; // the far-field walk works with 2 / r (pan_step): its sums carry 8 / r^3
 
 __device__ __forceinline__ int tp_index(int I, int J, int nt) { return I * nt - (I * (I - 1)) / 2 + (J - I); }
@@ -454,7 +457,7 @@ struct PanelUpdate {
 	int probe; // measurement only: arrive, but skip the update (the producer side of the hand-off alone; results are NOT valid)
 };
 
-template <int NW, bool SC1>
+template <int NW, bool SC1, int ROUNDS = ((8 * NW) / 16 > 0 ? (8 * NW) / 16 : 1)>
 __device__ __forceinline__ void panel_update_tile(const AtomsDev &at, const PanelUpdate &u, const double *__restrict__ part, const double *__restrict__ gpart,
                                                   const double *__restrict__ mu_old, const int X, double (*__restrict__ sh)[kTile][3]) {
 	constexpr int GW = kUpdGroups / NW; // groups per wave
@@ -471,14 +474,14 @@ __device__ __forceinline__ void panel_update_tile(const AtomsDev &at, const Pane
 		}
 	}
 	// One list of T = nF + nG slots (i-side first); group g takes t = g, g + 16, ...  Every load is issued unconditionally (a slot index
-	// past the end is clamped and its value replaced by zero: no branch between the loads), 8 / GW rounds of the wave's groups per trip: 24
-	// independent loads in flight per lane -- the update is a latency chain (few workgroups, data fresh from other CUs), not a bandwidth one.
+	// past the end is clamped and its value replaced by zero: no branch between the loads), ROUNDS rounds of the wave's groups per trip: 3 GW
+	// ROUNDS independent loads in flight per lane (24; 48 measured no faster) -- the update is
+	// a latency chain (few workgroups, data fresh from other CUs), not a bandwidth one.  The order of the additions does not depend on ROUNDS.
 	double f[GW][3] = {};
 	const size_t n_pad = (size_t)at.n_pad;
 	const int T = nF + nG;
 	const double *__restrict__ pX = part + ((size_t)X * n_pad + (size_t)X * kTile) * 3 + a; // slot X, this tile's block; slot X + t is t * n_pad * 3 further
 	const double *__restrict__ gX = gpart + (size_t)wg0 * (kTile * 3) + a;
-	constexpr int ROUNDS = (8 / GW) > 0 ? 8 / GW : 1;
 	for (int t0 = 0; t0 < T; t0 += ROUNDS * kUpdGroups) {
 		double v[ROUNDS][GW][3];
 #pragma unroll
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(64 * NW) void k_dipole_update_panel(AtomsDev at, co
                                                                  const double *__restrict__ mu_old, const PanelUpdate u) {
 	__shared__ double sh[kUpdGroups][kTile][3];
 	if (u.ctl && u.ctl[1] != 0) return; // converged in an earlier iteration (block-uniform)
-	panel_update_tile<NW, false>(at, u, part, gpart, mu_old, blockIdx.x, sh);
+	panel_update_tile<NW, false>(at, u, part, gpart, mu_old, blockIdx.x, sh); // (48 loads per lane and trip instead of 24: no faster, round 5)
 }
 
 void launch_build_panels(hipStream_t st, const int *cls, int n_tiles, const int *seg, int4 *panels, int *arrive) {
@@ -669,7 +672,7 @@ void launch_dipole_iter_panel(hipStream_t st, const AtomsDev &at, const Box &bx,
 		u.allowed_sqerr = fuse->allowed_sqerr, u.ctl = fuse->ctl, u.host_flag = fuse->host_flag, u.arrive = fuse->arrive;
 		u.nt = at.n_pad / kTile, u.it = fuse->it, u.want_rrms = fuse->want_rrms, u.probe = fuse->probe;
 	}
-#define MPMC_PANEL(O, F) hipLaunchKernelGGL((k_dipole_iter_panel<4, O, F>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace, u)
+#define MPMC_PANEL(O, F) hipLaunchKernelGGL((k_dipole_iter_panel<MPMC_PANEL_PIPE, O, F>), grid, block, 0, st, at, bx, mu, tile_pairs, tp_shift, panels, ab, part, gpart, converged, trace, u)
 	if (bx.ortho) {
 		if (fused) MPMC_PANEL(true, true);
 		else MPMC_PANEL(true, false);
