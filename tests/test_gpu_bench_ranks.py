@@ -9,6 +9,7 @@ import sys
 import pytest
 
 import util
+from mpmcxx_amd import ranks
 
 pytestmark = pytest.mark.gpu
 ARGS = ["--beads", "4", "--natoms", "1000", "--steps", "2", "--warmup", "1", "--cpu-baseline", "none"]
@@ -60,7 +61,7 @@ def test_bare_multi_gpu_command_starts_its_own_torch_free_ranks(single):
 
 def test_ranks_under_an_external_launcher_stay_torch_free(single):
     """the driver's form: python -m torch.distributed.run ... bench.py --gpus 2.  The launcher is a torch program; the ranks are not."""
-    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(ranks.free_port()),
                "bench.py", "--gpus", "2", "--combine-impl", "hub", "--force-device", "0"] + ARGS, dict(clean_env(), HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert two.returncode == 0, two.stderr[-2000:]
     b = last_json(two.stdout)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import util
-from mpmcxx_amd import energy
+from mpmcxx_amd import energy, ranks
 
 # No torch import in this file (round 4 needed one, FIRST, to dodge an exit-time abort): the library now shares an RCCL the host program
 # already mapped and otherwise opens, RTLD_LOCAL, the copy next to the HIP runtime it is bound to (csrc/comm.cpp rccl();
@@ -108,7 +108,7 @@ def test_two_ranks_on_two_gpus_over_rccl():
     assert one.returncode == 0, one.stderr[-2000:]
     outs = {}
     for impl in ("cabi", "torch"):
-        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29519",
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(ranks.free_port()),
                               "bench.py", "--gpus", "2", "--combine-impl", impl] + args, cwd=util.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert two.returncode == 0, two.stderr[-2000:]
         outs[impl] = last_json(two.stdout)
