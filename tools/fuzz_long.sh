@@ -4,12 +4,13 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
 rc_all=0
 run() { echo "== $*"; "$@" | tail -n 1; local rc=${PIPESTATUS[0]}; echo "== exit code $rc"; [ $rc -ne 0 ] && rc_all=1; }
-run timeout -k 10 280 python3 tools/fuzz.py 110000 3000
-run timeout -k 10 280 python3 tools/fuzz.py 150000 2500 sweep
-run timeout -k 10 280 python3 tools/fuzz_large.py 9000 200
-run timeout -k 10 280 python3 tools/fuzz_large.py 9500 200 sweep
-run timeout -k 10 280 python3 tools/fuzz_trial.py 9000 600
-run timeout -k 10 280 python3 tools/fuzz_trial.py 9700 600 polar
-run timeout -k 10 200 python3 tools/fuzz_state.py 9000 200 4
+run timeout -k 10 280 python3 tools/fuzz.py 210000 3000
+run timeout -k 10 280 python3 tools/fuzz.py 250000 2500 sweep
+run timeout -k 10 280 python3 tools/fuzz_large.py 19000 200
+run timeout -k 10 280 python3 tools/fuzz_large.py 19500 200 sweep
+run timeout -k 10 280 python3 tools/fuzz_trial.py 19000 600
+run timeout -k 10 280 python3 tools/fuzz_trial.py 19700 600 polar
+run timeout -k 10 280 python3 tools/fuzz_large.py 29000 200 fused
+run timeout -k 10 200 python3 tools/fuzz_state.py 19000 200 4
 echo "== overall $rc_all"
 exit $rc_all
