@@ -4,8 +4,9 @@
 The reference evaluates ``systems[s]->energy()`` for the P Trotter beads (one OpenMP thread or one MPI rank per
 bead), all-gathers four doubles per bead (``MPI_Allgather`` x4, :763-766), sums them in bead order s = 0..P-1 and
 divides by P (:786-801).  Here the beads are independent device contexts sharded over ranks (bead s lives on rank
-``s % world``, local slot ``s // world``); the exchange is ONE collective of 4 fp64 per bead over
-``torch.distributed`` (backend nccl == RCCL over xGMI on the GPU node, gloo in the CPU tests).
+``s % world``, local slot ``s // world``); the exchange is ONE all-gather of 4 fp64 per bead: through ``comm`` -- an
+``energy.Comm`` (ncclAllGather inside libmpmc_energy.so over RCCL / xGMI: the production path, no torch in the rank) or a
+``ranks.Hub`` (loopback sockets: rehearsal and fall-back) -- or, opt-in, over ``torch.distributed`` (nccl / gloo; the CPU tests).
 
 The kinetic half of the estimator (``PI_calculate_kinetic``, :806-824) needs the centres of mass of ADJACENT images of
 every molecule (``PI_chain_mass_length2``, :908-965).  The reference keeps all P images on every MPI rank; here the ring
@@ -32,7 +33,7 @@ def combine(per_bead_local: np.ndarray, P: int, rank: int = 0, world: int = 1, g
     """per_bead_local: (n_local, 4) = {rd, coulombic, polarization, vdw} of this rank's beads, in local-slot order.
     Returns (V, obs4) exactly as PI_calculate_potential: obs = ordered sum / P, V = rd + coulombic + vdw + polarization.
     comm: an `energy.Comm` (RCCL communicator of the C ABI): the exchange is then ONE ncclAllGather inside libmpmc_energy.so
-    (mpmc_pi_gather_beads) and torch.distributed is not involved."""
+    (mpmc_pi_gather_beads); or a `ranks.Hub` (same `gather_beads` contract over loopback sockets).  torch.distributed is not involved."""
     per_bead_local = np.ascontiguousarray(per_bead_local, dtype=np.float64).reshape(-1, 4)
     n_local = per_bead_local.shape[0]
     if comm is not None:
