@@ -98,9 +98,14 @@ def molecule_coms(pos: np.ndarray, mass: np.ndarray, mol_id: np.ndarray, frozen:
     return c / m[:, None], m, (np.asarray(frozen)[last] == 0).astype(np.int32)
 
 
-def gather_beads(local: np.ndarray, P: int, rank: int = 0, world: int = 1, group=None, device: Optional[str] = None) -> np.ndarray:
-    """local: (n_local, ...) values of this rank's beads in local-slot order -> (P, ...) in bead order (bead = slot * world + rank)."""
+def gather_beads(local: np.ndarray, P: int, rank: int = 0, world: int = 1, group=None, device: Optional[str] = None, comm=None) -> np.ndarray:
+    """local: (n_local, ...) values of this rank's beads in local-slot order -> (P, ...) in bead order (bead = slot * world + rank).
+    comm: an `energy.Comm` or `ranks.Hub` (their `gather_beads`); else torch.distributed."""
     local = np.ascontiguousarray(local, dtype=np.float64)
+    if comm is not None:
+        if comm.n_ranks * local.shape[0] != P:
+            raise ValueError("every rank must own P / n_ranks beads")
+        return comm.gather_beads(local)
     if world == 1:
         return local
     import torch
@@ -118,12 +123,12 @@ def gather_beads(local: np.ndarray, P: int, rank: int = 0, world: int = 1, group
 
 
 def pi_calculate_kinetic(local_coms: np.ndarray, mol_mass: np.ndarray, movable: np.ndarray, P: int, temperature: float,
-                         rank: int = 0, world: int = 1, group=None, device: Optional[str] = None) -> Tuple[float, float]:
+                         rank: int = 0, world: int = 1, group=None, device: Optional[str] = None, comm=None) -> Tuple[float, float]:
     """SimulationControl::PI_calculate_kinetic (reference PathIntegral.cpp:806-824).  local_coms: (n_local, n_molecules, 3)
     from `molecule_coms` of this rank's beads.  Returns (K [Kelvin], chain_mass_len2 [kg m^2])."""
     from . import energy as _e
 
-    coms = gather_beads(local_coms, P, rank, world, group, device)
+    coms = gather_beads(local_coms, P, rank, world, group, device, comm)
     chain = _e.pi_chain_mass_length2(coms, mol_mass, movable)
     N = float(np.count_nonzero(movable))
     return _e.pi_kinetic(chain, N, P, temperature), chain

@@ -28,6 +28,10 @@ def _hub_worker(rank, world, path, case, q):
         out["gathered"] = g.tobytes().hex()
         v, obs = pi.combine(local, 2 * world, rank, world, comm=hub)
         out["v"], out["obs"] = v, obs.tolist()
+        coms = np.arange(2 * 5 * 3, dtype=np.float64).reshape(2, 5, 3) + 1000.0 * rank  # centres of mass of the kinetic estimator: (n_local, n_molecules, 3)
+        allc = pi.gather_beads(coms, 2 * world, rank, world, comm=hub)
+        out["coms_ok"] = bool(allc.shape == (2 * world, 5, 3) and all(np.array_equal(allc[s], np.arange(15, dtype=np.float64).reshape(5, 3) + 15.0 * (s // world) + 1000.0 * (s % world))
+                                                                        for s in range(2 * world)))
         hub.barrier()
         hub.close()
         q.put((rank, out))
@@ -51,7 +55,7 @@ def test_hub_all_gathers_exactly_and_in_rank_order(world):
     for r in range(world):
         assert [e["rank"] for e in res[r]["exchange"]] == list(range(world))
         assert [e["x"] for e in res[r]["exchange"]] == [0.1 * (k + 1) for k in range(world)]  # floats travel exactly
-        assert res[r]["max"] == 1.5 + world - 1 and res[r]["bcast"] == "from0"
+        assert res[r]["max"] == 1.5 + world - 1 and res[r]["bcast"] == "from0" and res[r]["coms_ok"]
         assert res[r] == res[0] or {k: v for k, v in res[r].items()} == {k: v for k, v in res[0].items()}
     # bead order: bead s = rank s % world, slot s // world; ordered sum identical on every rank and equal to the serial loop
     g = np.frombuffer(bytes.fromhex(res[0]["gathered"]), dtype=np.float64).reshape(2 * world, 4)
