@@ -182,7 +182,7 @@ def other_configs(headline_beads: int, headline_value: float, device: int, workd
         S = energy.System(atoms, basis, opts, device=device)
         e = S.energy()
         S.energy()
-        reps = 400 if name == "lj1000" else (60 if name == "ion10k_es" else 15)
+        reps = 400 if name == "lj1000" else (100 if name == "ion10k_es" else 50)  # (the same loop lengths as tools/config_rates.py, give or take: short loops read the clock ramp)
         t0 = time.perf_counter()
         for _ in range(reps):
             S.energy()

@@ -21,7 +21,7 @@ for label, name in (("configs[1]  1 000-atom LJ box (rd_only)", "lj1000"), ("con
     atoms, basis, opts = pqr.load_case(inp)
     S = energy.System(atoms, basis, opts)
     e = S.energy()
-    reps = 200 if name == "lj1000" else 50
+    reps = 400 if name == "lj1000" else (100 if name == "ion10k_es" else 50)
     t0 = time.perf_counter()
     for _ in range(reps):
         S.energy()
@@ -42,3 +42,15 @@ for label, name in (("configs[1]  1 000-atom LJ box (rd_only)", "lj1000"), ("con
         s.close()
     print(f"{label}: E = {e:.10e} K; one system at a time {one * 1e3:.3f} ms ({1 / one:.0f} evals/s); 32 systems in flight {many * 1e3:.3f} ms each "
           f"({1 / many:.0f} evals/s)", flush=True)
+# configs[3] taken literally: the dense 3N x 3N matrix on the fp64 matrix cores (--solver dense), one system
+inp, _ = gen_box.materialize("ion10k_polar", wd)
+atoms, basis, opts = pqr.load_case(inp)
+S = energy.System(atoms, basis, dict(opts, solver="dense"))
+e = S.energy()
+S.energy()
+t0 = time.perf_counter()
+for _ in range(5):
+    S.energy()
+one = (time.perf_counter() - t0) / 5
+S.close()
+print(f"configs[3] literal (dense 3N x 3N A matrix, MFMA contraction): E = {e:.10e} K; one system at a time {one * 1e3:.3f} ms ({1 / one:.0f} evals/s)", flush=True)
