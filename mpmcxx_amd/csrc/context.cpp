@@ -935,7 +935,10 @@ extern "C" int mpmc_debug_configure(mpmc_ctx *c, const char *key, double value) 
 	else if (k == "poll_retire") t.poll_retire = on;
 	else if (k == "lazy_side_stream") t.lazy_side_stream = on;
 	else if (k == "tail_fused") t.tail_fused = on;
-	else if (k == "pair_split") {
+	else if (k == "pair_split_tail") {
+		if (v < -1 || v > 1000) return MPMC_ERR_ARG;
+		t.pair_split_tail = v;
+	} else if (k == "pair_split") {
 		if (v < -1 || v > 1) return MPMC_ERR_ARG;
 		t.pair_split = v;
 	} else if (k == "panels") t.use_panels = on;

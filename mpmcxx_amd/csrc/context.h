@@ -69,7 +69,8 @@ struct mpmc_tuning {
 	bool tail_fused = true;       // "tail_fused": polarization energy and the fold of the pair partials in one launch (0: the fold forks the side stream)
 	bool dense_symmetric = true; // "dense_symmetric": the dense solver reads the upper block triangle of A only (0: rounds 1-3, the whole matrix)
 	bool fast_geometry = true; // "fast_geometry": fused minimum image in the pair sweep, the reference's form only inside a 1e-9 band around the cutoff (0: everywhere)
-	int pair_split = -1;    // "pair_split": two waves per tile pair in the fast sweep (half-length workgroups): -1 by default rule, 0 | 1
+	int pair_split = -1;    // "pair_split": two waves per tile pair in the fast sweep (half-length workgroups): -1 the last part of the table (round 5), 0 never | 1 everywhere
+	int pair_split_tail = -1; // "pair_split_tail": per mille of the sweep's work table that is halved under pair_split = -1 (default kSweepSplitTailPermille)
 	int sweep_order = 1; // "sweep_order": the pair sweep's work table by descending j-tile (1, round 5: the short rows with their partial entries end the launch; -2 to -4 % per lone
 	                     // launch without field and store, level with them) | 0 ascending (rounds 3-4)
 	int update_waves = 0; // "update_waves": waves per workgroup of the dipole update launch: 0 = 4 (round 5) | 1 | 2 | 4 | 16 (rounds 2-4).  A 16-wave workgroup needs

@@ -234,11 +234,14 @@ void mpmc::ext_params(const mpmc_ctx *c, FusedParams &fp, bool wolf_on) {
 	fp.wolf_inv_r2 = 1.0 / (c->box.cutoff * c->box.cutoff);
 }
 
-// two waves per tile pair in the fast pair sweep (half-length workgroups): the default
-// (half-length workgroups shorten the tail a LONE launch drains on: 150 -> 141 us at 10 000 atoms; with 32 evaluations in flight other
-// kernels fill that tail anyway and the doubled table staging costs ~0.4 % of the job rate.  The choice changes the order of a tile
-// pair's sums, so it is NOT made per call: an evaluation gives the same bits alone and inside an ensemble)
-static inline bool sweep_split(const mpmc_ctx *c) { return c->tune.pair_split < 0 ? kSweepSplitDefault : c->tune.pair_split != 0; }
+// two waves per tile pair in the fast pair sweep (half-length workgroups): by default for the LAST quarter of the work table only -- a lone
+// launch drains on units half as long, an ensemble (whose other kernels fill the drain anyway) pays the halved form's overhead on a quarter of
+// the work.  The rule is a function of the table alone (never of the call): an evaluation gives the same bits alone and inside an ensemble.
+static inline int sweep_split_mode(const mpmc_ctx *c) { return c->tune.pair_split < 0 ? 2 : (c->tune.pair_split != 0 ? 1 : 0); }
+static inline int sweep_split_tail(const mpmc_ctx *c) {
+	const int permille = c->tune.pair_split_tail >= 0 ? c->tune.pair_split_tail : kSweepSplitTailPermille;
+	return (int)((long long)c->n_sweep_blocks * permille / 1000);
+}
 
 // which pieces of energy() to run
 
@@ -422,7 +425,7 @@ int mpmc::enqueue(mpmc_ctx *c, unsigned mask) {
 		if (sweep) {
 			launch_pair_sweep(st, at, c->box, fp, c->n_molecules != c->n, c->d_sweep_blocks, c->n_sweep_blocks, c->d_cls,
 			                  (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->d_erf_tab, c->d_block_part, c->d_block_cnt, c->d_part,
-			                  compact ? c->d_ab : nullptr, sweep_split(c), c->tune.fast_geometry,
+			                  compact ? c->d_ab : nullptr, sweep_split_mode(c), sweep_split_tail(c), c->tune.fast_geometry,
 			                  (side_deferred || panel_side) ? c->tune.sweep_lds_pad : 0);
 			if (c->n_generic > 0)
 				launch_pair_fused(st, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_generic, c->d_block_part, c->d_block_cnt, c->d_part,
@@ -674,7 +677,7 @@ extern "C" int mpmc_debug_time_pair(mpmc_ctx *c, int reps, double *ms_per_launch
 		if (c->last_pair_was_sweep) {
 			launch_pair_sweep(c->stream, at, c->box, fp, c->n_molecules != c->n, c->d_sweep_blocks, c->n_sweep_blocks, c->d_cls,
 			                  (c->tune.no_uniform || c->tune.no_classes) ? nullptr : c->d_tp_shift, c->d_erf_tab, c->d_block_part, c->d_block_cnt, c->d_part,
-			                  compact ? c->d_ab : nullptr, sweep_split(c), c->tune.fast_geometry,
+			                  compact ? c->d_ab : nullptr, sweep_split_mode(c), sweep_split_tail(c), c->tune.fast_geometry,
 			                  c->two_streams ? c->tune.sweep_lds_pad : 0, timed ? c->debug_panel_replicas : 1);
 			if (c->n_generic > 0)
 				launch_pair_fused(c->stream, at, c->box, fp, c->d_tile_pairs, c->d_cls, c->n_generic, c->d_block_part, c->d_block_cnt, c->d_part,

@@ -149,15 +149,17 @@ struct PairSweepParams {
 	int store;      // write the Thole tensor store
 	int nt;         // tiles
 	int have_shift; // tp_shift / CLS_UNIFORM_* are valid
-	int split;      // two waves per tile pair (half the steps each), two tile pairs per workgroup
+	int split;      // 0 | 1 | 2: two waves per tile pair (half the steps each), two tile pairs per workgroup -- never / every entry / the entries behind n_main
+	int n_main;     // workgroups [0, n_main) take whole entries of the table, the ones behind them half entries
 	int fast;       // fused geometry with the tile pair's band around the cutoff thresholds (tp_shift.w); 0: the reference's form everywhere
 };
 // Tables with more tile pairs than this take the sweep by default.  Measured (profiles/r03_sweep_sizes.txt), k_pair_fused (four waves per
 // tile pair up to kPairSplitMax) against the sweep: one evaluation at a time +2 % at 3000 atoms (1128 tile pairs), -3 % at 5000 (3160),
 // -5 % at 7000, -9 % at 10 000; 32 beads in flight the sweep wins from 3000 atoms on (+4 % evaluations/s, +4.5 % at 5000, +9 % at 7000).
 constexpr int kSweepMinPairs = 2048;
-// two waves per tile pair (half the steps each; kernels_pair.hip): measured in round 4, see DESIGN section 3
-constexpr bool kSweepSplitDefault = false;
+// two waves per tile pair (half the steps each; kernels_pair.hip): for the last kSweepSplitTailPermille / 1000 of the work table (round 5; round 4
+// measured "all" against "none": faster alone, 0.7 % slower with 32 evaluations in flight)
+constexpr int kSweepSplitTailPermille = 250;
 // host: the device layout of the erfc table, 3 * 512 double2 = (c0,c1)[512], (c2,c3)[512], (c4,c5)[512]  (erfc_table.cpp)
 constexpr int kErfTableDouble2 = 3 * 512;
 void erfc_table_device_layout(double2 *out /*[kErfTableDouble2]*/);
@@ -170,8 +172,8 @@ int pair_sweep_blocks(int n_tiles, int2 *out);
 bool pair_sweep_covers(const Box &bx, const FusedParams &fp, double ewald_alpha);
 void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, bool intra /*some molecule has more than one atom*/,
                        const int2 *blocks, int n_blocks, const int *cls, const double4 *tp_shift /*null: no uniform images*/,
-                       const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab, bool split = false,
-                       bool fast_geometry = false, int lds_pad_bytes = 0 /*unused dynamic LDS per workgroup: fewer workgroups per CU*/,
+                       const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab, int split_mode = 0 /*0 | 1 | 2: see PairSweepParams*/,
+                       int n_split_tail = 0 /*mode 2: how many entries at the end of the table are halved*/, bool fast_geometry = false, int lds_pad_bytes = 0 /*unused dynamic LDS per workgroup: fewer workgroups per CU*/,
                        int replicas = 1 /*measurement only: the grid repeated in y (mpmc_debug_time_pair with panel_replicas)*/);
 void launch_reduce_pairs(hipStream_t st, const double *block_part, const int *block_cnt, int nb, double *scal, long long *cnt);
 // polarizable evaluations: launch_polar_energy and launch_reduce_pairs as the two blocks of one launch (the tail of the evaluation)

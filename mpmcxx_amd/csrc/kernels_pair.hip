@@ -259,7 +259,7 @@ __device__ __forceinline__ void sweep_walk(const double2 *__restrict__ s_xy, con
 // blocks: { J, I0 } -- the workgroup's waves take the tile pairs (I0 + w, J), w = 0..3, as far as I0 + w <= J
 // (ORTHO: the orthorhombic instantiation reads the diagonals of the cell and its inverse only, which keeps the rest of the Box out of its
 // scalar registers -- spilled SGPRs are v_writelane / v_readlane on the VALU)
-template <bool FIELD, bool INTRA, bool ORTHO, bool SPLIT>
+template <bool FIELD, bool INTRA, bool ORTHO, int SPLIT>
 __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Box bx, PairSweepParams pp, const int2 *__restrict__ blocks,
                                                                  const int *__restrict__ cls, const double4 *__restrict__ tp_shift,
                                                                  const double2 *__restrict__ erf_tab, double *__restrict__ block_part,
@@ -273,10 +273,16 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_pair_sweep(AtomsDev at, Bo
 	// pp.split: the workgroup takes TWO tile pairs (I0, J), (I0 + 1, J) and two waves share each -- wave w walks half (w >> 1) of the
 	// steps of tile pair (w & 1); the halves meet in LDS behind the walk.  Half-length workgroups: a lone launch drains on a tail half as
 	// long (CUs busy 77 % -> ~90 % of the launch at 10 000 atoms).  The table stays { J, I0 in steps of 4 }: two workgroups per entry.
-	constexpr bool split = SPLIT;
-	const int2 blk = blocks[split ? (blockIdx.x >> 1) : blockIdx.x];
+	// SPLIT 0: never; 1: every entry; 2 (default, round 5): the LAST entries of the table only -- workgroups [0, n_main) take whole entries, the
+	// ones behind them half entries: the launch ends on units half as long (a lone launch drains on its last units: 17 % of it at 10 000
+	// atoms), while most of the work keeps the cheaper whole form.  Which entries are halved is a function of the table alone, so an
+	// evaluation gives the same bits alone and inside an ensemble.
+	const int n_main = SPLIT == 1 ? 0 : pp.n_main;
+	const bool split = SPLIT == 1 ? true : (SPLIT == 0 ? false : ((int)blockIdx.x >= n_main));
+	const int b_half = (int)blockIdx.x - n_main; // (split workgroups: two per entry)
+	const int2 blk = blocks[split ? n_main + (b_half >> 1) : (int)blockIdx.x];
 	const int pw = split ? (w & 1) : w, half = split ? (w >> 1) : 0;
-	const int J = __builtin_amdgcn_readfirstlane(blk.x), I = __builtin_amdgcn_readfirstlane(blk.y) + (split ? 2 * (int)(blockIdx.x & 1) : 0) + pw;
+	const int J = __builtin_amdgcn_readfirstlane(blk.x), I = __builtin_amdgcn_readfirstlane(blk.y) + (split ? 2 * (b_half & 1) : 0) + pw;
 	const int j0 = J * kTile;
 #pragma unroll
 	for (int k = 0; k < (3 * MPMC_ERFTAB_PIECES) / (64 * kSweepWaves); ++k) s_tab[threadIdx.x + k * 64 * kSweepWaves] = erf_tab[threadIdx.x + k * 64 * kSweepWaves];
@@ -477,9 +483,12 @@ bool pair_sweep_covers(const Box &bx, const FusedParams &fp, double ewald_alpha)
 
 void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const FusedParams &fp, bool intra, const int2 *blocks, int n_blocks,
                        const int *cls, const double4 *tp_shift, const double2 *erf_tab, double *block_part, int *block_cnt, double *fpart, double2 *ab,
-                       bool split, bool fast_geometry, int lds_pad_bytes, int replicas) {
+                       int split_mode, int n_split_tail, bool fast_geometry, int lds_pad_bytes, int replicas) {
 	PairSweepParams pp;
-	pp.split = split ? 1 : 0;
+	// workgroups [0, n_main) take whole entries, the rest half entries (two per entry): mode 0 -> all whole, 1 -> all halved, 2 -> the last n_split_tail halved
+	const int n_tail = split_mode == 1 ? n_blocks : (split_mode == 2 ? std::min(std::max(n_split_tail, 0), n_blocks) : 0);
+	pp.split = split_mode;
+	pp.n_main = n_blocks - n_tail;
 	pp.alpha_scaled_half = 0.5 * (fp.ewald_alpha * MPMC_ERFTAB_INV_H); // (powers of two: (alpha r) / H and (alpha / 2H) (2r) are the same double)
 	pp.polar_damp_half = 0.5 * fp.polar_damp;
 	pp.thole_far_x = fp.thole_far_x;
@@ -487,17 +496,20 @@ void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const 
 	pp.nt = at.n_pad / kTile;
 	pp.have_shift = tp_shift ? 1 : 0;
 	pp.fast = fast_geometry ? 1 : 0; // (the per-tile-pair band comes from k_classify: tp_shift.w)
-	dim3 grid(split ? 2 * n_blocks : n_blocks, replicas > 1 ? replicas : 1), block(64 * kSweepWaves); // (replicas: measurement only -- the same work blockIdx.y times)
+	dim3 grid(pp.n_main + 2 * n_tail, replicas > 1 ? replicas : 1), block(64 * kSweepWaves); // (replicas: measurement only -- the same work blockIdx.y times)
 	const unsigned lds = lds_pad_bytes > 0 ? (unsigned)lds_pad_bytes : 0u; // unused dynamic LDS: caps the workgroups per CU (see evaluate.cpp)
-#define MPMC_PS(F, N)                                                                                                                                 \
-	do {                                                                                                                                          \
-		if (bx.ortho) {                                                                                                                           \
-			if (split) hipLaunchKernelGGL((k_pair_sweep<F, N, true, true>), grid, block, lds, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab); \
-			else hipLaunchKernelGGL((k_pair_sweep<F, N, true, false>), grid, block, lds, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab);    \
-		} else {                                                                                                                                  \
-			if (split) hipLaunchKernelGGL((k_pair_sweep<F, N, false, true>), grid, block, lds, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab); \
-			else hipLaunchKernelGGL((k_pair_sweep<F, N, false, false>), grid, block, lds, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab);   \
-		}                                                                                                                                         \
+#define MPMC_PS2(F, N, O, S) hipLaunchKernelGGL((k_pair_sweep<F, N, O, S>), grid, block, lds, st, at, bx, pp, blocks, cls, tp_shift, erf_tab, block_part, block_cnt, fpart, ab)
+#define MPMC_PS(F, N)                                    \
+	do {                                                 \
+		if (bx.ortho) {                                  \
+			if (n_tail == 0) MPMC_PS2(F, N, true, 0);    \
+			else if (n_tail == n_blocks) MPMC_PS2(F, N, true, 1); \
+			else MPMC_PS2(F, N, true, 2);                \
+		} else {                                         \
+			if (n_tail == 0) MPMC_PS2(F, N, false, 0);   \
+			else if (n_tail == n_blocks) MPMC_PS2(F, N, false, 1); \
+			else MPMC_PS2(F, N, false, 2);               \
+		}                                                \
 	} while (0)
 	if (fp.do_field == 1) {
 		if (intra) MPMC_PS(true, true);
@@ -507,6 +519,7 @@ void launch_pair_sweep(hipStream_t st, const AtomsDev &at, const Box &bx, const 
 		else MPMC_PS(false, false);
 	}
 #undef MPMC_PS
+#undef MPMC_PS2
 }
 
 } // namespace mpmc
