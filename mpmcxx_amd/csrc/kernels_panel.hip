@@ -40,13 +40,19 @@
 
 namespace mpmc {
 
-// Work table: one entry per workgroup of four waves, which split the entry's walk by steps (short waves: the launch fills and drains
-// the chip in small units).  Entries of j-tile J occupy [seg[J], seg[J + 1]) (host-made): its diagonal tile pair, at most floor(J / 2)
+// Work table: one entry per workgroup of kPanelWaves waves, which split the entry's walk by steps.  Entries of j-tile J occupy [seg[J], seg[J + 1]) (host-made): its diagonal tile pair, at most floor(J / 2)
 // panels of two tile pairs and up to two single off-diagonal tile pairs (one per kind); unused entries carry tp = -1.
 //   entry = { tile pair A, tile pair B (-1: single), uniform mask | far << 3 | diagonal << 4, J }
 int panel_segment_entries(int J) { return J / 2 + 3; }
 constexpr int kPanFar = 8, kPanDiag = 16;
-constexpr int kPanelWaves = 4; // waves per workgroup: they split the steps of ONE entry's walk
+#ifndef MPMC_PANEL_WAVES
+#define MPMC_PANEL_WAVES 2
+#endif
+// waves per workgroup: they split the steps of ONE entry's walk.  TWO since round 5 (32 steps each): a wave's prologue and epilogue -- atom
+// loads, the partial sums' trip through LDS, the closing wave's fold -- are ~90 VALU instructions, 7 % of the launch with four waves of 16
+// steps; same-box builds (tools/ab_panel_waves.sh, two boxes): 2 waves +1.8 % evaluations/s with 32 beads in flight and level alone,
+// 1 wave +1 % in flight and 8 % slower alone (units of 48 us), 8 waves -13 %.
+constexpr int kPanelWaves = MPMC_PANEL_WAVES;
 #ifndef MPMC_PANEL_PIPE
 #define MPMC_PANEL_PIPE 4 // depth of the stored walk's prefetch ring (steps ahead): 2 / 8 measured in round 5, tools/README.md
 #endif
@@ -345,7 +351,7 @@ __device__ __forceinline__ void panel_block(const AtomsDev &at, const Box &bx, c
 	}
 	__syncthreads();
 	const bool pad = (at.n != at.n_pad) && (J == at.n_pad / kTile - 1);
-	// the four waves split the walk: 16 steps each of the 64 of an off-diagonal tile pair (s = 0..63), 8 each of the 32 of a diagonal one (s = 1..32)
+	// the waves split the walk: 64 / kPanelWaves steps each of the 64 of an off-diagonal tile pair (s = 0..63), 32 / kPanelWaves of the 32 of a diagonal one (s = 1..32)
 	const int n_steps = (diag ? 32 : 64) / kPanelWaves, s_first = (diag ? 1 : 0) + w * n_steps;
 	PanAcc<NI> A = {};
 #define MPMC_PWALK(F, N) pan_walk<F, N, NI, PIPE, false>(bx, s_xy, s_zm, s_mm, s_valid, pad, lane, src4, L, iL, q, m, ab, ab_tile, s_first, n_steps, A)
@@ -565,8 +571,8 @@ __device__ __forceinline__ void panel_update_tile(const AtomsDev &at, const Pane
 
 // (per FUSED two instantiations: the orthorhombic one reads three diagonal elements of the cell and its inverse, which keeps most of the
 // Box out of its scalar registers; the other holds the walks of skewed cells)
-constexpr int kPanelLdsDouble2 = 6 * kTile + kTile + (kPanelWaves * 2 * 3 * kTile + kPanelWaves * 3 * kTile) / 2; // j-tile image (every value twice), valid flags, s_F, s_G
-static_assert(kPanelLdsDouble2 * 2 >= kUpdGroups * kTile * 3, "the update's group sums reuse the walk's LDS");
+constexpr int kPanelWalkDouble2 = 6 * kTile + kTile + (kPanelWaves * 2 * 3 * kTile + kPanelWaves * 3 * kTile) / 2; // j-tile image (every value twice), valid flags, s_F, s_G
+constexpr int kPanelLdsDouble2 = kPanelWalkDouble2; // (the fused update's group sums reuse the walk's LDS: with four waves and more it is large enough)
 template <int PIPE, bool ORTHO, bool FUSED>
 __global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev at, Box bx, const double *__restrict__ mu,
                                                                         const int2 *__restrict__ tile_pairs, const double4 *__restrict__ tp_shift,
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(64 * kPanelWaves) void k_dipole_iter_panel(AtomsDev
                                                                         const PanelUpdate u) {
 	long long t_start = 0;
 	if (trace) t_start = wall_clock64();
-	__shared__ double2 s_all[kPanelLdsDouble2];
+	__shared__ double2 s_all[(FUSED && kPanelLdsDouble2 * 2 < kUpdGroups * kTile * 3) ? (kUpdGroups * kTile * 3) / 2 : kPanelLdsDouble2];
 	__shared__ int s_todo[4];
 	if (converged && *converged != 0) return; // an iteration enqueued ahead of the verdict: nothing to do
 	double2 *s_xy = s_all, *s_zm = s_all + 2 * kTile, *s_mm = s_all + 4 * kTile;
