@@ -39,7 +39,7 @@ def _hub_worker(rank, world, path, case, q):
         q.put((rank, {"error": repr(e)}))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_hub_all_gathers_exactly_and_in_rank_order(world):
     path = os.path.join(tempfile.mkdtemp(), "hub.json")
     ctx = mp.get_context("spawn")
